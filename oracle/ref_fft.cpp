@@ -1,0 +1,73 @@
+// ORACLE -- test infrastructure only (see ref_fft.h).
+#include "ref_fft.h"
+#include <utility>
+
+static unsigned log2_exact(size_t n) {
+  unsigned l = 0;
+  while (((size_t)1 << l) < n) l++;
+  return l;
+}
+
+static void fft_core(std::vector<u64>& a, u64 root) {
+  const size_t n = a.size();
+  const unsigned lg = log2_exact(n);
+  for (size_t i = 0; i < n; i++) {
+    size_t j = rbits(i, lg);
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  std::vector<u64> tw(n / 2 ? n / 2 : 1);
+  tw[0] = 1;
+  for (size_t i = 1; i < n / 2; i++) tw[i] = rf_mul(tw[i - 1], root);
+  for (size_t len = 1; len < n; len <<= 1) {
+    size_t step = n / (2 * len);
+    for (size_t s = 0; s < n; s += 2 * len)
+      for (size_t j = 0; j < len; j++) {
+        u64 u = a[s + j], v = rf_mul(a[s + j + len], tw[j * step]);
+        a[s + j] = rf_add(u, v);
+        a[s + j + len] = rf_sub(u, v);
+      }
+  }
+}
+
+void ref_fft(std::vector<u64>& a) { fft_core(a, rf_root_of_unity(log2_exact(a.size()))); }
+void ref_ifft(std::vector<u64>& a) {
+  fft_core(a, rf_inv(rf_root_of_unity(log2_exact(a.size()))));
+  u64 ninv = rf_inv((u64)a.size());
+  for (auto& x : a) x = rf_mul(x, ninv);
+}
+void ref_coset_fft(std::vector<u64>& a, u64 shift) {
+  u64 p = 1;
+  for (auto& x : a) {
+    x = rf_mul(x, p);
+    p = rf_mul(p, shift);
+  }
+  ref_fft(a);
+}
+void ref_coset_ifft(std::vector<u64>& a, u64 shift) {
+  ref_ifft(a);
+  u64 si = rf_inv(shift), p = 1;
+  for (auto& x : a) {
+    x = rf_mul(x, p);
+    p = rf_mul(p, si);
+  }
+}
+void ref_fft_ext(std::vector<RE2>& a) {
+  std::vector<u64> x(a.size()), y(a.size());
+  for (size_t i = 0; i < a.size(); i++) x[i] = a[i].a, y[i] = a[i].b;
+  ref_fft(x);
+  ref_fft(y);
+  for (size_t i = 0; i < a.size(); i++) a[i] = RE2{x[i], y[i]};
+}
+void ref_coset_fft_ext(std::vector<RE2>& a, u64 shift) {
+  std::vector<u64> x(a.size()), y(a.size());
+  for (size_t i = 0; i < a.size(); i++) x[i] = a[i].a, y[i] = a[i].b;
+  ref_coset_fft(x, shift);
+  ref_coset_fft(y, shift);
+  for (size_t i = 0; i < a.size(); i++) a[i] = RE2{x[i], y[i]};
+}
+std::vector<u64> ref_lde_values(const std::vector<u64>& coeffs, unsigned rate_bits, u64 shift) {
+  std::vector<u64> v(coeffs);
+  v.resize(coeffs.size() << rate_bits, 0);
+  ref_coset_fft(v, shift);
+  return v;
+}

@@ -1,0 +1,82 @@
+// Internal declarations shared by the HIP translation units of libp25 (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <map>
+#include "gl.h"
+
+namespace p25 {
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+#define P25_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      throw p25::HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " +        \
+                          __FILE__ + ":" + std::to_string(__LINE__));                         \
+  } while (0)
+
+// ---------------- hashing (kernels_hash.hip) ----------------
+void launch_poseidon_permute(u64* d_states, size_t n, hipStream_t st);
+void launch_poseidon2_permute(u64* d_states, size_t n, hipStream_t st);
+size_t merkle_tree_words(size_t n_leaves, unsigned cap_height);
+size_t merkle_level_offset(size_t n_leaves, unsigned level);
+u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t n_leaves,
+                        unsigned cap_height, u64* d_tree, hipStream_t st);
+
+// ---------------- NTT (kernels_ntt.hip) ----------------
+// One pass of a two-pass (four-step) NTT: a block transforms a tile of 2^log_t independent
+// length-2^log_r sub-transforms held in LDS.  See kernels_ntt.hip for the addressing kinds.
+struct NttPass {
+  const u64* in;
+  u64* out;
+  size_t in_poly_stride, out_poly_stride;
+  size_t coset_out_off[8];
+  int log_r, log_nt, log_t;
+  int in_kind, in_br_t, in_br_i;
+  int out_kind, out_br_t, out_br_i;
+  const u64* pow_table;  // w_N^e (forward) or w_N^-e (inverse), e < N = 2^log_n_table
+  int log_n_table;
+  int use_twiddle;       // multiply output (t, j) by pow_table[t*j] (N = R*NT required)
+  const u64* pre_t;      // optional [n_cosets][NT]
+  const u64* pre_i;      // optional [n_cosets][R]
+  const u64* post_t;     // optional [NT]
+  const u64* post_i;     // optional [R]
+};
+void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st);
+
+class NttTables {
+ public:
+  ~NttTables();
+  // device table of w^e, e < 2^log_n, w = primitive 2^log_n-th root (or its inverse)
+  const u64* pow_table(int log_n, bool inverse);
+  // device table of base^e for e < len (cached by (base, len))
+  const u64* geom_table(u64 first, u64 ratio, size_t len);
+  const u64* upload(const std::vector<u64>& host);
+
+ private:
+  std::map<std::pair<int, bool>, u64*> pow_;
+  std::map<std::tuple<u64, u64, size_t>, u64*> geom_;
+  std::vector<u64*> owned_;
+};
+
+// values (natural order) -> coefficients (natural order); in/out/tmp are [n_polys][n] with the
+// given strides; tmp must not alias in or out (in may alias tmp's role only if in == tmp is never
+// reused).  If `coset_shift` != 1 computes the coset iNTT (coefficients of f given f(shift*w^i)).
+void ntt_inverse(NttTables& tb, const u64* d_in, size_t in_stride, bool in_bitrev, u64* d_tmp,
+                 size_t tmp_stride, u64* d_out, size_t out_stride, int log_n, int n_polys,
+                 u64 coset_shift, hipStream_t st);
+// coefficients (natural order, n each) -> values of the rate-2^rate_bits LDE on the coset
+// shift*<w_{n*2^rate_bits}>, stored at BIT-REVERSED index (position rev(i) holds f(shift*w^i)):
+// exactly the leaf order of upstream's PolynomialBatch (transpose + reverse_index_bits).
+void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64* d_lde,
+                    size_t lde_stride, int log_n, int rate_bits, int n_polys, u64 shift,
+                    hipStream_t st);
+
+}  // namespace p25

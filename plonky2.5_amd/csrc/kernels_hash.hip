@@ -1,0 +1,114 @@
+// Poseidon-v1 hashing kernels for gfx950: batch permutation, Merkle leaf sponge, 2-to-1 tree levels.
+//
+// Replaces (upstream plonky2 @ 3de92d9, called from /root/reference/src/p3/mod.rs:260):
+//   PoseidonHash::hash_or_noop / two_to_one and MerkleTree::new.
+//
+// Design: one lane per hash.  A Poseidon state is 12 x u64 = 24 VGPRs; the work per hash
+// (>= 1 permutation ~ 1.5k 64-bit modular multiply-equivalents) dwarfs its memory traffic, so the
+// kernel is integer-VALU bound and the job of the memory layout is only to stay out of the way:
+// leaves are read from a COLUMN-major matrix (column c of leaf l at cols[c * col_stride + l]), so
+// the 64 lanes of a wave read 64 consecutive u64 of one column per load -- fully coalesced with no
+// transpose pass (upstream transposes the LDE to row-major leaves first; the digest is the same).
+// Digests are stored as 4 consecutive u64 per node (32 B per lane, contiguous across lanes).
+#include "kernels.h"
+#include "poseidon.h"
+#include "poseidon2.h"
+
+namespace p25 {
+
+__global__ __launch_bounds__(256) void k_poseidon_permute(u64* states, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = states[i * 12 + k];
+  poseidon::permute(s);
+#pragma unroll
+  for (int k = 0; k < 12; k++) states[i * 12 + k] = s[k];
+}
+
+__global__ __launch_bounds__(256) void k_poseidon2_permute(u64* states, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = states[i * 12 + k];
+  poseidon2::permute(s);
+#pragma unroll
+  for (int k = 0; k < 12; k++) states[i * 12 + k] = s[k];
+}
+
+// digests[l] = hash_or_noop(leaf l), leaf l = (cols[c*col_stride + l])_{c < width}
+__global__ __launch_bounds__(256) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
+                                                     int width, size_t n_leaves,
+                                                     u64* __restrict__ digests) {
+  size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_leaves) return;
+  u64 out[4];
+  poseidon::hash_or_noop_strided(cols + l, col_stride, width, out);
+  u64* d = digests + 4 * l;
+#pragma unroll
+  for (int i = 0; i < 4; i++) d[i] = out[i];
+}
+
+// parents[m] = two_to_one(children[2m], children[2m+1])
+__global__ __launch_bounds__(256) void k_tree_level(const u64* __restrict__ children,
+                                                    u64* __restrict__ parents, size_t n_parents) {
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_parents) return;
+  u64 l[4], r[4], o[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    l[i] = children[8 * m + i];
+    r[i] = children[8 * m + 4 + i];
+  }
+  poseidon::two_to_one(l, r, o);
+#pragma unroll
+  for (int i = 0; i < 4; i++) parents[4 * m + i] = o[i];
+}
+
+void launch_poseidon_permute(u64* d_states, size_t n, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_poseidon_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_states, n);
+}
+void launch_poseidon2_permute(u64* d_states, size_t n, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_poseidon2_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_states, n);
+}
+
+size_t merkle_tree_words(size_t n_leaves, unsigned cap_height) {
+  // levels 0 (leaf digests) .. log2(n) - cap_height (the cap), 4 words per node
+  size_t total = 0;
+  for (size_t m = n_leaves; m >= ((size_t)1 << cap_height); m >>= 1) {
+    total += 4 * m;
+    if (m == 1) break;
+  }
+  return total;
+}
+size_t merkle_level_offset(size_t n_leaves, unsigned level) {
+  size_t off = 0;
+  size_t m = n_leaves;
+  for (unsigned k = 0; k < level; k++) {
+    off += 4 * m;
+    m >>= 1;
+  }
+  return off;
+}
+
+// Builds every level up to the cap in `tree` (layout: merkle_level_offset).  Returns pointer to cap.
+u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t n_leaves,
+                        unsigned cap_height, u64* d_tree, hipStream_t st) {
+  hipLaunchKernelGGL(k_hash_leaves, dim3((unsigned)((n_leaves + 255) / 256)), dim3(256), 0, st, d_cols,
+                     col_stride, width, n_leaves, d_tree);
+  u64* cur = d_tree;
+  size_t m = n_leaves;
+  while (m > ((size_t)1 << cap_height)) {
+    u64* nxt = cur + 4 * m;
+    m >>= 1;
+    hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, cur, nxt, m);
+    cur = nxt;
+  }
+  return cur;
+}
+
+}  // namespace p25

@@ -1,0 +1,272 @@
+// Goldilocks NTT for gfx950: two-pass (four-step) transform with LDS-resident sub-transforms.
+//
+// Replaces (upstream plonky2_field @ 3de92d9, reached from /root/reference/src/p3/mod.rs:260 via
+// PolynomialBatch::from_values / from_coeffs): PolynomialValues::ifft, PolynomialCoeffs::lde +
+// coset_fft, and the transpose + reverse_index_bits that orders the LDE as Merkle leaves.
+//
+// A length-N transform (N = R1*R2) is two launches of ONE kernel, `k_ntt_tile`:
+//   pass 1: input index k = k1 + R1*k2.  A block takes a tile of T adjacent k1 (T*8 B contiguous
+//           per row -> coalesced) and all R2 values of k2, runs T radix-2 DIF transforms of length
+//           R2 in LDS, multiplies by the four-step twiddle w_N^(k1*j2) and stores.
+//   pass 2: a block takes T rows (each R1 contiguous words), transforms them in LDS and stores.
+// LDS twiddles: the R/2 powers of the sub-transform root are staged in LDS once per block.
+// The DIF network leaves its result in bit-reversed LDS order, which is exactly what the prover
+// wants: the LDE is stored at bit-reversed index (Merkle-leaf order) with NO separate
+// transpose / bit-reversal pass -- pass 1 scatters rows to rev(j2) and pass 2 then runs in place.
+// The rate-8 LDE is computed as 8 coset transforms of length n (shift*w_8n^c, c < 8) rather than
+// one zero-padded length-8n transform: the same values, 3 fewer butterfly stages, and coset c
+// lands in the contiguous leaf block rev3(c).
+//
+// Addressing kinds (element (t, i): sub-transform t of the launch, element i of it; NT = number
+// of sub-transforms per polynomial, R = their length):
+//   kind 0 ("t-contiguous"): addr = t + imap(i) * NT
+//   kind 1 ("i-contiguous"): addr = tmap(t) * R + imap(i)
+// where imap/tmap are the identity or a bit reversal.  All values are canonical field elements.
+#include <tuple>
+#include "kernels.h"
+
+namespace p25 {
+
+__global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
+  extern __shared__ u64 lds[];
+  const int R = 1 << a.log_r, T = 1 << a.log_t;
+  const int TP = T > 1 ? T + 1 : 1;  // row padding: conflict-free for both access directions
+  u64* wl = lds + (size_t)R * TP;    // R/2 twiddles of the sub-transform
+  const u32 NT = 1u << a.log_nt;
+  const u32 tg0 = blockIdx.x * T;
+  const int poly = blockIdx.y, coset = blockIdx.z;
+  const u64* in = a.in + (size_t)poly * a.in_poly_stride;
+  u64* out = a.out + (size_t)poly * a.out_poly_stride + a.coset_out_off[coset];
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int wstride_log = a.log_n_table - a.log_r;  // w_R^k = w_N^(k * N/R)
+
+  for (int k = tid; k < R / 2; k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
+
+  const u64* pre_t = a.pre_t ? a.pre_t + (size_t)coset * NT : nullptr;
+  const u64* pre_i = a.pre_i ? a.pre_i + (size_t)coset * R : nullptr;
+  for (int e = tid; e < T * R; e += nth) {
+    int t, i;
+    size_t addr;
+    if (a.in_kind == 0) {
+      t = e & (T - 1);
+      i = e >> a.log_t;
+      u32 ipos = a.in_br_i ? gl::bitrev(i, a.log_r) : i;
+      addr = (size_t)(tg0 + t) + (size_t)ipos * NT;
+    } else {
+      int off = e & (R - 1);
+      t = e >> a.log_r;
+      i = a.in_br_i ? (int)gl::bitrev(off, a.log_r) : off;
+      u32 trow = a.in_br_t ? gl::bitrev(tg0 + t, a.log_nt) : tg0 + t;
+      addr = (size_t)trow * R + off;
+    }
+    u64 x = in[addr];
+    if (pre_t) x = gl::mul(x, gl::mul(pre_t[tg0 + t], pre_i[i]));
+    lds[i * TP + t] = x;
+  }
+  __syncthreads();
+
+  // radix-2 DIF, natural in -> bit-reversed out
+  for (int len = R >> 1, sh = 0; len >= 1; len >>= 1, sh++) {
+    for (int b = tid; b < T * (R >> 1); b += nth) {
+      int t = b & (T - 1);
+      int p = b >> a.log_t;
+      int j = p & (len - 1);
+      int i0 = ((p - j) << 1) + j;
+      u64 u = lds[i0 * TP + t], v = lds[(i0 + len) * TP + t];
+      lds[i0 * TP + t] = gl::add(u, v);
+      lds[(i0 + len) * TP + t] = gl::mul(gl::sub(u, v), wl[j << sh]);
+    }
+    __syncthreads();
+  }
+
+  for (int e = tid; e < T * R; e += nth) {
+    int t, q;
+    u32 j;  // frequency index held at LDS position q
+    size_t addr;
+    if (a.out_kind == 0) {
+      t = e & (T - 1);
+      q = e >> a.log_t;
+      j = gl::bitrev(q, a.log_r);
+      u32 ipos = a.out_br_i ? (u32)q : j;
+      addr = (size_t)(tg0 + t) + (size_t)ipos * NT;
+    } else {
+      int off = e & (R - 1);
+      t = e >> a.log_r;
+      q = a.out_br_i ? off : (int)gl::bitrev(off, a.log_r);
+      j = gl::bitrev(q, a.log_r);
+      u32 trow = a.out_br_t ? gl::bitrev(tg0 + t, a.log_nt) : tg0 + t;
+      addr = (size_t)trow * R + off;
+    }
+    u64 x = lds[q * TP + t];
+    if (a.use_twiddle) x = gl::mul(x, a.pow_table[(size_t)(tg0 + t) * j]);
+    if (a.post_t) x = gl::mul(x, gl::mul(a.post_t[tg0 + t], a.post_i[j]));
+    out[addr] = x;
+  }
+}
+
+void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st) {
+  const int R = 1 << p.log_r, T = 1 << p.log_t;
+  const int TP = T > 1 ? T + 1 : 1;
+  size_t lds = ((size_t)R * TP + R / 2) * sizeof(u64);
+  dim3 grid(1u << (p.log_nt - p.log_t), n_polys, n_cosets);
+  hipLaunchKernelGGL(k_ntt_tile, grid, dim3(256), lds, st, p);
+}
+
+static int pick_log_t(int log_r, int log_nt) {
+  int lt = 12 - log_r;
+  if (lt > 4) lt = 4;
+  if (lt > log_nt) lt = log_nt;
+  if (lt < 0) lt = 0;
+  return lt;
+}
+
+NttTables::~NttTables() {
+  for (u64* p : owned_) (void)hipFree(p);
+}
+const u64* NttTables::upload(const std::vector<u64>& host) {
+  u64* d = nullptr;
+  P25_HIP(hipMalloc(&d, host.size() * sizeof(u64)));
+  owned_.push_back(d);
+  P25_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
+  return d;
+}
+const u64* NttTables::pow_table(int log_n, bool inverse) {
+  auto key = std::make_pair(log_n, inverse);
+  auto it = pow_.find(key);
+  if (it != pow_.end()) return it->second;
+  u64 w = gl::root_of_unity(log_n);
+  if (inverse) w = gl::inv(w);
+  std::vector<u64> h((size_t)1 << log_n);
+  u64 x = 1;
+  for (auto& v : h) {
+    v = x;
+    x = gl::mul(x, w);
+  }
+  u64* d = const_cast<u64*>(upload(h));
+  pow_[key] = d;
+  return d;
+}
+const u64* NttTables::geom_table(u64 first, u64 ratio, size_t len) {
+  auto key = std::make_tuple(first, ratio, len);
+  auto it = geom_.find(key);
+  if (it != geom_.end()) return it->second;
+  std::vector<u64> h(len);
+  u64 x = first;
+  for (auto& v : h) {
+    v = x;
+    x = gl::mul(x, ratio);
+  }
+  u64* d = const_cast<u64*>(upload(h));
+  geom_[key] = d;
+  return d;
+}
+
+static void split(int log_n, int& log_r1, int& log_r2) {
+  if (log_n <= 10) {
+    log_r1 = 0;
+    log_r2 = log_n;
+  } else {
+    log_r2 = (log_n + 1) / 2;  // pass-1 sub-transform (over k2)
+    log_r1 = log_n - log_r2;   // pass-2 sub-transform (over k1)
+  }
+  if (log_r1 > 10 || log_r2 > 10) throw std::runtime_error("NTT size above 2^20 not supported");
+}
+
+void ntt_inverse(NttTables& tb, const u64* d_in, size_t in_stride, bool in_bitrev, u64* d_tmp,
+                 size_t tmp_stride, u64* d_out, size_t out_stride, int log_n, int n_polys,
+                 u64 coset_shift, hipStream_t st) {
+  int l1, l2;
+  split(log_n, l1, l2);
+  const u64* pw = tb.pow_table(log_n, true);
+  u64 n_inv = gl::inv((u64)1 << log_n);
+  u64 s_inv = gl::inv(coset_shift);
+  NttPass p{};
+  p.pow_table = pw;
+  p.log_n_table = log_n;
+  if (l1 == 0) {  // single pass
+    p.in = d_in; p.out = d_out;
+    p.in_poly_stride = in_stride; p.out_poly_stride = out_stride;
+    p.log_r = l2; p.log_nt = 0; p.log_t = 0;
+    p.in_kind = 1; p.in_br_i = in_bitrev;
+    p.out_kind = 1; p.out_br_i = 0;
+    p.post_t = tb.geom_table(n_inv, 1, 1);
+    p.post_i = tb.geom_table(1, s_inv, (size_t)1 << l2);
+    launch_ntt_pass(p, n_polys, 1, st);
+    return;
+  }
+  // pass 1: t = k1 (NT = R1), i = k2 (R = R2); writes Y[k1][j2] at k1 + R1*j2
+  p.in = d_in; p.out = d_tmp;
+  p.in_poly_stride = in_stride; p.out_poly_stride = tmp_stride;
+  p.log_r = l2; p.log_nt = l1; p.log_t = pick_log_t(l2, l1);
+  if (in_bitrev) { p.in_kind = 1; p.in_br_t = 1; p.in_br_i = 1; } else { p.in_kind = 0; }
+  p.out_kind = 0; p.out_br_i = 0;
+  p.use_twiddle = 1;
+  launch_ntt_pass(p, n_polys, 1, st);
+  // pass 2: t = j2 (NT = R2), i = k1 (R = R1); output coefficient j2 + R2*j1, scaled
+  NttPass q{};
+  q.pow_table = pw; q.log_n_table = log_n;
+  q.in = d_tmp; q.out = d_out;
+  q.in_poly_stride = tmp_stride; q.out_poly_stride = out_stride;
+  q.log_r = l1; q.log_nt = l2; q.log_t = pick_log_t(l1, l2);
+  q.in_kind = 1;
+  q.out_kind = 0; q.out_br_i = 0;
+  q.post_t = tb.geom_table(n_inv, s_inv, (size_t)1 << l2);
+  q.post_i = tb.geom_table(1, gl::pow(s_inv, (u64)1 << l2), (size_t)1 << l1);
+  launch_ntt_pass(q, n_polys, 1, st);
+}
+
+void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64* d_lde,
+                    size_t lde_stride, int log_n, int rate_bits, int n_polys, u64 shift,
+                    hipStream_t st) {
+  int l1, l2;
+  split(log_n, l1, l2);
+  const int nc = 1 << rate_bits;
+  if (nc > 8) throw std::runtime_error("rate_bits > 3 not supported");
+  const size_t n = (size_t)1 << log_n;
+  const u64* pw = tb.pow_table(log_n, false);
+  const u64 w_big = gl::root_of_unity(log_n + rate_bits);
+  // per-coset pre-scale tables: coefficient k = t + NT*i (pass 1) gets shift_c^k
+  const size_t NT1 = (size_t)1 << l1, R1 = (size_t)1 << l2;  // pass-1 geometry
+  std::vector<u64> ht(nc * NT1), hi(nc * R1);
+  for (int c = 0; c < nc; c++) {
+    u64 sc = gl::mul(shift, gl::pow(w_big, c));
+    u64 x = 1;
+    for (size_t k = 0; k < NT1; k++) { ht[c * NT1 + k] = x; x = gl::mul(x, sc); }
+    u64 sr = gl::pow(sc, NT1);
+    x = 1;
+    for (size_t k = 0; k < R1; k++) { hi[c * R1 + k] = x; x = gl::mul(x, sr); }
+  }
+  // cache by content is overkill: tables are tiny; cache by (log_n, rate_bits, shift)
+  static thread_local std::map<std::tuple<NttTables*, int, int, u64>, std::pair<const u64*, const u64*>> cache;
+  auto key = std::make_tuple(&tb, log_n, rate_bits, shift);
+  auto it = cache.find(key);
+  if (it == cache.end()) it = cache.emplace(key, std::make_pair(tb.upload(ht), tb.upload(hi))).first;
+
+  NttPass p{};
+  p.pow_table = pw; p.log_n_table = log_n;
+  p.in = d_coeffs; p.out = d_lde;
+  p.in_poly_stride = coeff_stride; p.out_poly_stride = lde_stride;
+  for (int c = 0; c < nc; c++) p.coset_out_off[c] = (size_t)gl::bitrev(c, rate_bits) * n;
+  p.pre_t = it->second.first; p.pre_i = it->second.second;
+  if (l1 == 0) {
+    p.log_r = l2; p.log_nt = 0; p.log_t = 0;
+    p.in_kind = 1; p.out_kind = 1; p.out_br_i = 1;
+    launch_ntt_pass(p, n_polys, nc, st);
+    return;
+  }
+  // pass 1: scale, length-R2 transforms over k2, twiddle, store row rev(j2)
+  p.log_r = l2; p.log_nt = l1; p.log_t = pick_log_t(l2, l1);
+  p.in_kind = 0; p.out_kind = 0; p.out_br_i = 1;
+  p.use_twiddle = 1;
+  launch_ntt_pass(p, n_polys, nc, st);
+  // pass 2: every row (all cosets: nc*R2 rows of R1 words) in place, bit-reversed within the row
+  NttPass q{};
+  q.pow_table = pw; q.log_n_table = log_n;
+  q.in = d_lde; q.out = d_lde;
+  q.in_poly_stride = lde_stride; q.out_poly_stride = lde_stride;
+  q.log_r = l1; q.log_nt = l2 + rate_bits; q.log_t = pick_log_t(l1, l2 + rate_bits);
+  q.in_kind = 1; q.out_kind = 1; q.out_br_i = 1;
+  launch_ntt_pass(q, n_polys, 1, st);
+}
+
+}  // namespace p25

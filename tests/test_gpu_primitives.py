@@ -1,0 +1,82 @@
+"""GPU parity (through the C ABI) of the hash / Merkle / NTT primitives against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, P, splitmix_field
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_poseidon_kats_gpu(gpu):
+    g = json.load(open(os.path.join(GOLD, "poseidon_v1_constants.json")))
+    ins = np.array([k["input"] for k in g["kats"]], dtype=np.uint64)
+    outs = gpu.poseidon_permute(ins)
+    for o, k in zip(outs, g["kats"]):
+        assert [int(x) for x in o] == k["output"]
+
+
+def test_poseidon_random_vs_oracle(gpu, oracle):
+    s = splitmix_field(12 * 5000).reshape(-1, 12)
+    s[0, :] = P - 1
+    s[1, :] = 0
+    assert (gpu.poseidon_permute(s) == oracle.poseidon_permute(s)).all()
+
+
+def test_poseidon2_vs_oracle(gpu, oracle):
+    s = splitmix_field(12 * 3000, seed=5).reshape(-1, 12)
+    s[0, :] = 0
+    s[1, :] = np.arange(12)
+    got = gpu.poseidon2_permute(s)
+    assert (got == oracle.poseidon2_permute(s)).all()
+    assert hex(int(got[0][0])) == "0xb7c3a0ee7dfdcedf"
+
+
+@pytest.mark.parametrize("n,w,cap", [(16, 3, 4), (64, 4, 2), (256, 5, 0), (1024, 8, 4), (2048, 9, 4),
+                                     (512, 135, 4), (4096, 20, 4), (32, 16, 5), (16, 1, 0)])
+def test_merkle_vs_oracle(gpu, oracle, n, w, cap):
+    leaves = splitmix_field(n * w, seed=n * 131 + w).reshape(n, w)
+    cap_o, tree_o = oracle.merkle_commit(leaves, cap, want_tree=True)
+    cap_g, tree_g = gpu.merkle_commit(np.ascontiguousarray(leaves.T), cap, want_tree=True)
+    assert (cap_g == cap_o).all()
+    assert (tree_g == tree_o).all()
+
+
+@pytest.mark.parametrize("log_n,npolys,from_coeffs", [(3, 2, False), (6, 3, False), (8, 5, True),
+                                                      (10, 2, False), (11, 3, False), (12, 4, False),
+                                                      (13, 2, True), (16, 3, False)])
+def test_lde_commit_vs_oracle(gpu, oracle, log_n, npolys, from_coeffs):
+    n = 1 << log_n
+    vals = splitmix_field(n * npolys, seed=77 + log_n).reshape(npolys, n)
+    co, lo, capo = oracle.lde_commit(vals, 3, min(4, log_n + 3), from_coeffs)
+    cg, lg, capg = gpu.lde_commit(vals, 3, min(4, log_n + 3), from_coeffs)
+    assert (cg == co).all()
+    assert (lg == lo).all()
+    assert (capg == capo).all()
+
+
+def test_lde_rate_bits_1_and_2(gpu, oracle):
+    vals = splitmix_field(4 * 4096, seed=9).reshape(4, 4096)
+    for rb in (1, 2):
+        co, lo, capo = oracle.lde_commit(vals, rb, 2)
+        cg, lg, capg = gpu.lde_commit(vals, rb, 2)
+        assert (cg == co).all() and (lg == lo).all() and (capg == capo).all()
+
+
+def test_full_size_merkle_properties(gpu, oracle):
+    """2^19 x 135 (BASELINE workload size): spot-check digests + subtree consistency."""
+    n, w = 1 << 19, 135
+    cols = splitmix_field(n * w, seed=3).reshape(w, n)
+    cap, tree = gpu.merkle_commit(cols, 4, want_tree=True)
+    # leaf digests of a few leaves against the oracle sponge
+    for l in (0, 1, 12345, n - 1):
+        assert (tree[4 * l:4 * l + 4] == oracle.hash_no_pad(np.ascontiguousarray(cols[:, l]))).all()
+    # a 4096-leaf subtree recomputed by the oracle must equal the stored inner node
+    sub = np.ascontiguousarray(cols[:, :4096].T)
+    capo = oracle.merkle_commit(sub, 0)
+    off = sum(4 * (n >> k) for k in range(12))
+    assert (tree[off:off + 4] == capo[0]).all()
+    assert cap.shape == (16, 4)
