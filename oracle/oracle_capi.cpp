@@ -3,6 +3,10 @@
 #include <string.h>
 #include "ref_fft.h"
 #include "ref_hash.h"
+#include "ref_gates.h"
+#include "ref_prover.h"
+#include <memory>
+#include <stdio.h>
 
 extern "C" {
 
@@ -58,6 +62,130 @@ void p25o_lde_commit(const u64* polys, unsigned log_n, size_t n_polys, int from_
     RMerkleTree t = ref_merkle_build(leaves, cap_height);
     memcpy(cap_out, t.cap().data(), t.cap().size() * 32);
   }
+}
+
+
+// ---------------------------------------------------------------- circuit-level entry points
+struct OracleCircuit {
+  RCircuit c;
+  std::unique_ptr<RPrecomputed> pre;
+};
+static void put_msg(char* dst, size_t cap, const std::string& m) {
+  if (dst && cap) snprintf(dst, cap, "%s", m.c_str());
+}
+
+void p25o_set_threads(int n) { ref_set_threads(n); }
+
+void* p25o_circuit_load(const unsigned char* blob, size_t len) {
+  try {
+    auto* oc = new OracleCircuit();
+    oc->c = ref_circuit_parse(blob, len);
+    return oc;
+  } catch (...) {
+    return nullptr;
+  }
+}
+void p25o_circuit_free(void* h) { delete (OracleCircuit*)h; }
+int p25o_circuit_info(void* h, u64* out /*[8]*/) {
+  auto* oc = (OracleCircuit*)h;
+  out[0] = oc->c.degree_bits; out[1] = oc->c.num_wires; out[2] = oc->c.num_inputs; out[3] = oc->c.gens.size();
+  out[4] = ref_proof_words(oc->c); out[5] = oc->c.num_cs(); out[6] = oc->c.gates.size(); out[7] = oc->c.num_gate_constraints;
+  return 0;
+}
+// wires_out: [num_wires][n]
+int p25o_witness(void* h, const u64* inputs, u64 seed, u64* wires_out, char* msg, size_t msglen) {
+  auto* oc = (OracleCircuit*)h;
+  RWitnessResult r = ref_generate_witness(oc->c, inputs, seed);
+  put_msg(msg, msglen, r.message);
+  if (r.status) return r.status;
+  const size_t n = oc->c.n();
+  for (int col = 0; col < oc->c.num_wires; col++) memcpy(wires_out + (size_t)col * n, r.wires[col].data(), n * 8);
+  return 0;
+}
+// Evaluates every row's own gate on the witness; returns the number of non-zero constraints
+// (0 = witness satisfies the circuit) and reports the first offender.
+long p25o_check_constraints(void* h, const u64* wires, char* msg, size_t msglen) {
+  auto* oc = (OracleCircuit*)h;
+  const RCircuit& c = oc->c;
+  const size_t n = c.n();
+  long bad = 0;
+  std::vector<FB> w(c.num_wires), out(c.num_gate_constraints + 8);
+  FB pih[4] = {FB{0}, FB{0}, FB{0}, FB{0}};
+  for (size_t row = 0; row < n; row++) {
+    for (int col = 0; col < c.num_wires; col++) w[col] = FB{wires[(size_t)col * n + row]};
+    FB k[2] = {FB{c.constants_sigmas[c.num_selectors][row]}, FB{c.constants_sigmas[c.num_selectors + 1][row]}};
+    int nc = ref_eval_gate<FB>(c.row_kind[row], w.data(), k, pih, out.data());
+    for (int j = 0; j < nc; j++)
+      if (out[j].v != 0) {
+        if (!bad) put_msg(msg, msglen, "row " + std::to_string(row) + " gate kind " + std::to_string(c.row_kind[row]) +
+                                           " constraint " + std::to_string(j) + " = " + std::to_string(out[j].v));
+        bad++;
+      }
+  }
+  // copy constraints: every routed wire equals its representative's value
+  std::vector<u64> rep_val(c.num_targets(), 0);
+  std::vector<unsigned char> seen(c.num_targets(), 0);
+  for (size_t row = 0; row < n; row++)
+    for (int col = 0; col < c.num_routed; col++) {
+      u32 r = c.rep[row * c.num_wires + col];
+      u64 v = wires[(size_t)col * n + row];
+      if (!seen[r]) {
+        seen[r] = 1;
+        rep_val[r] = v;
+      } else if (rep_val[r] != v) {
+        if (!bad) put_msg(msg, msglen, "copy constraint violated at row " + std::to_string(row) + " col " + std::to_string(col));
+        bad++;
+      }
+    }
+  return bad;
+}
+int p25o_precompute(void* h) {
+  auto* oc = (OracleCircuit*)h;
+  if (!oc->pre) oc->pre.reset(new RPrecomputed(ref_precompute(oc->c)));
+  return 0;
+}
+void p25o_circuit_digest(void* h, u64* digest4, u64* cs_cap /*[2^cap][4]*/) {
+  auto* oc = (OracleCircuit*)h;
+  p25o_precompute(h);
+  memcpy(digest4, oc->pre->circuit_digest.e, 32);
+  if (cs_cap) memcpy(cs_cap, oc->pre->constants_sigmas.tree.cap().data(), oc->pre->constants_sigmas.tree.cap().size() * 32);
+}
+size_t p25o_proof_words(void* h) { return ref_proof_words(((OracleCircuit*)h)->c); }
+// timings_out[9]: witness, wires_commit, zs, zs_commit, quotient, quotient_commit, openings, fri, total (seconds)
+int p25o_prove(void* h, const u64* inputs, u64 seed, u64* proof_out, double* timings_out, char* msg, size_t msglen) {
+  auto* oc = (OracleCircuit*)h;
+  p25o_precompute(h);
+  RProof pr;
+  RTimings tm;
+  std::string m;
+  int st = ref_prove(oc->c, *oc->pre, inputs, seed, pr, &tm, &m);
+  put_msg(msg, msglen, m);
+  if (st) return st;
+  std::vector<u64> flat = ref_proof_flatten(oc->c, pr);
+  if (flat.size() != ref_proof_words(oc->c)) {
+    put_msg(msg, msglen, "internal: proof size mismatch");
+    return 7;
+  }
+  memcpy(proof_out, flat.data(), flat.size() * 8);
+  if (timings_out) {
+    double t[9] = {tm.witness, tm.wires_commit, tm.zs, tm.zs_commit, tm.quotient, tm.quotient_commit, tm.openings, tm.fri, tm.total};
+    memcpy(timings_out, t, sizeof(t));
+  }
+  return 0;
+}
+// digest4 / cs_cap: the verifier-side circuit data (VerifierOnlyCircuitData); pass the oracle's own
+// (p25o_circuit_digest) or the product's to cross-check.
+int p25o_verify(void* h, const u64* digest4, const u64* cs_cap, const u64* proof_words, char* msg, size_t msglen) {
+  auto* oc = (OracleCircuit*)h;
+  RProof pr = ref_proof_unflatten(oc->c, proof_words);
+  RHash d;
+  memcpy(d.e, digest4, 32);
+  std::vector<RHash> cap((size_t)1 << oc->c.cap_height);
+  memcpy(cap.data(), cs_cap, cap.size() * 32);
+  std::string m;
+  int st = ref_verify(oc->c, d, cap, pr, &m);
+  put_msg(msg, msglen, m);
+  return st;
 }
 
 }  // extern "C"

@@ -1,0 +1,683 @@
+// See p3_circuit.h.  Each function cites the reference lines it restates.  Statement order follows
+// the Rust source exactly (Rust evaluates arguments left to right), because gate placement --
+// and therefore the circuit -- depends on call order.
+#include "p3_circuit.h"
+#include <algorithm>
+#include <stdexcept>
+
+namespace p25 {
+
+namespace {
+constexpr int WIDTH = 12, DIGEST_ELEMS = 4, RATE = 4;  // src/p3/constants.rs
+constexpr u64 TWO_ADIC_BASE = 1753635133440165772ULL;
+
+int log2_strict(size_t n) {
+  int r = 0;
+  while (((size_t)1 << r) < n) r++;
+  if (((size_t)1 << r) != n) throw std::logic_error("not a power of two");
+  return r;
+}
+int log2_ceil(size_t n) {
+  int r = 0;
+  while (((size_t)1 << r) < n) r++;
+  return r;
+}
+}  // namespace
+
+// ---------------------------------------------------------------- src/p3/mod.rs:51-147
+Target p3_constant(CircuitBuilder& cb, u64 v) { return cb.constant(v % gl::P); }
+
+static Target combine_u64(CircuitBuilder& cb, std::array<Target, 2> lh) {
+  return cb.mul_const_add((u64)1 << 32, lh[1], lh[0]);
+}
+Target p3_and(CircuitBuilder& cb, Target x, Target y) {
+  auto [x_low, x_high] = cb.split_low_high(x, 32, 64);
+  auto [y_low, y_high] = cb.split_low_high(y, 32, 64);
+  auto r = cb.and_u64({x_low, x_high}, {y_low, y_high});
+  return combine_u64(cb, r);
+}
+Target p3_xor(CircuitBuilder& cb, Target x, Target y) {
+  auto [x_low, x_high] = cb.split_low_high(x, 32, 64);
+  auto [y_low, y_high] = cb.split_low_high(y, 32, 64);
+  auto r = cb.xor_u64({x_low, x_high}, {y_low, y_high});
+  return combine_u64(cb, r);
+}
+Target p3_lsh(CircuitBuilder& cb, Target x, int n) {
+  auto [x_low, x_high] = cb.split_low_high(x, 32, 64);
+  auto r = cb.lsh_u64({x_low, x_high}, n);
+  return combine_u64(cb, r);
+}
+Target p3_rsh(CircuitBuilder& cb, Target x, int n) {
+  auto [x_low, x_high] = cb.split_low_high(x, 32, 64);
+  auto r = cb.rsh_u64({x_low, x_high}, n);
+  return combine_u64(cb, r);
+}
+// mod.rs:128-136 with binary_u32.rs:39-75 (convert_u32_bin32 = split_le 32, reverse_bin64,
+// convert_bin32_u32 = le_sum)
+Target reverse_p3(CircuitBuilder& cb, Target x) {
+  auto [x_low, x_high] = cb.split_low_high(x, 32, 64);
+  std::vector<BoolTarget> low_bits = cb.split_le(x_low, 32);
+  std::vector<BoolTarget> high_bits = cb.split_le(x_high, 32);
+  std::vector<BoolTarget> low_rev(high_bits.rbegin(), high_bits.rend());
+  std::vector<BoolTarget> high_rev(low_bits.rbegin(), low_bits.rend());
+  Target low_u32 = cb.le_sum(low_rev);
+  Target high_u32 = cb.le_sum(high_rev);
+  return cb.mul_const_add((u64)1 << 32, high_u32, low_u32);
+}
+Target reverse_p3_bits_len(CircuitBuilder& cb, Target x, int bit_len) {
+  Target r = reverse_p3(cb, x);
+  return p3_rsh(cb, r, 64 - bit_len);
+}
+static std::array<Target, 12> p3_arr12(CircuitBuilder& cb) {
+  std::array<Target, 12> a;
+  for (auto& t : a) t = cb.zero();
+  return a;
+}
+static Ext p3_field_to_arr(CircuitBuilder& cb, Target x) {
+  Ext r = {cb.zero(), cb.zero()};
+  r[0] = x;
+  return r;
+}
+
+// ---------------------------------------------------------------- src/p3/extension.rs
+static Target p3_w(CircuitBuilder& cb) { return p3_constant(cb, 7); }
+static Target p3_two_adic_generator(CircuitBuilder& cb, int bits) {
+  Target base = p3_constant(cb, TWO_ADIC_BASE);
+  return cb.exp_power_of_2(base, 32 - bits);
+}
+static Ext p3_ext_two_adic_generator(CircuitBuilder& cb, int bits) {
+  Target base = p3_constant(cb, TWO_ADIC_BASE);
+  Target x = cb.exp_power_of_2(base, 32 - bits);
+  return p3_field_to_arr(cb, x);  // bits == 33 branch unreachable
+}
+static Ext p3_ext_one(CircuitBuilder& cb) {
+  Target one = p3_constant(cb, 1);
+  return p3_field_to_arr(cb, one);
+}
+static Ext p3_ext_zero(CircuitBuilder& cb) {
+  Target zero = p3_constant(cb, 0);
+  return p3_field_to_arr(cb, zero);
+}
+static Ext p3_ext_if(CircuitBuilder& cb, BoolTarget cond, Ext x, Ext y) {
+  Ext res = {cb.zero(), cb.zero()};
+  for (int i = 0; i < 2; i++) res[i] = cb._if(cond, x[i], y[i]);
+  return res;
+}
+static Ext p3_ext_neg(CircuitBuilder& cb, Ext x) {
+  for (auto& r : x) r = cb.neg(r);
+  return x;
+}
+static Ext p3_ext_add(CircuitBuilder& cb, Ext x, Ext y) {
+  for (int i = 0; i < 2; i++) x[i] = cb.add(x[i], y[i]);
+  return x;
+}
+static Ext p3_ext_add_single(CircuitBuilder& cb, Ext x, Target y) {
+  x[0] = cb.add(x[0], y);
+  return x;
+}
+static Ext p3_ext_sub(CircuitBuilder& cb, Ext x, Ext y) {
+  for (int i = 0; i < 2; i++) x[i] = cb.sub(x[i], y[i]);
+  return x;
+}
+static Ext p3_ext_sub_single(CircuitBuilder& cb, Ext x, Target y) {
+  x[0] = cb.sub(x[0], y);
+  return x;
+}
+static Ext p3_ext_mul_single(CircuitBuilder& cb, const Ext& x, Target y) {
+  Ext r;
+  for (int i = 0; i < 2; i++) r[i] = cb.mul(x[i], y);
+  return r;
+}
+// extension.rs:446-471 (EXT_DEGREE = 2 arm)
+static Ext p3_ext_mul(CircuitBuilder& cb, const Ext& x, const Ext& y) {
+  Target w_af = p3_w(cb);
+  Ext res = {cb.zero(), cb.zero()};
+  Target a0b0 = cb.mul(x[0], y[0]);
+  Target w_b1 = cb.mul(w_af, y[1]);
+  Target a1_w_b1 = cb.mul(x[1], w_b1);
+  Target a0b1 = cb.mul(x[0], y[1]);
+  Target a1b0 = cb.mul(x[1], y[0]);
+  res[0] = cb.add(a0b0, a1_w_b1);
+  res[1] = cb.add(a0b1, a1b0);
+  return res;
+}
+// extension.rs:298-321 (EXT_DEGREE = 2 arm)
+static Ext p3_ext_inverse(CircuitBuilder& cb, Ext a) {
+  Target w = p3_w(cb);
+  Target a0_sq = cb.square(a[0]);
+  Target a1_sq = cb.square(a[1]);
+  Target w_a1_sq = cb.mul(w, a1_sq);
+  Target norm = cb.sub(a0_sq, w_a1_sq);
+  Target scalar = cb.inverse(norm);
+  Target a0s = cb.mul(a[0], scalar);
+  Target a1_neg = cb.neg(a[1]);
+  Target a1ns = cb.mul(a1_neg, scalar);
+  Ext value = {cb.zero(), cb.zero()};
+  value[0] = a0s;
+  value[1] = a1ns;
+  return value;
+}
+static Ext p3_ext_div(CircuitBuilder& cb, Ext x, Ext y) {
+  Ext y_inv = p3_ext_inverse(cb, y);
+  return p3_ext_mul(cb, y_inv, x);
+}
+static Ext p3_ext_exp_power_of_2(CircuitBuilder& cb, Ext x, int power_log) {
+  Ext res = x;
+  for (int i = 0; i < power_log; i++) res = p3_ext_mul(cb, res, res);
+  return res;
+}
+static Ext p3_ext_monomial(CircuitBuilder& cb, int exponent) {
+  Ext v = {cb.zero(), cb.zero()};
+  v[exponent] = cb.one();
+  return v;
+}
+static Ext p3_ext_mul_add(CircuitBuilder& cb, Ext x, Ext y, Ext z) {
+  Ext xy = p3_ext_mul(cb, x, y);
+  return p3_ext_add(cb, xy, z);
+}
+static void connect_p3_ext(CircuitBuilder& cb, const Ext& x, const Ext& y) {
+  for (int i = 0; i < 2; i++) cb.connect(x[i], y[i]);
+}
+
+// ---------------------------------------------------------------- src/p3/challenger.rs
+namespace {
+struct DuplexChallengerTarget {
+  std::vector<Target> sponge_state, input_buffer, output_buffer;
+};
+void p3_duplexing(CircuitBuilder& cb, DuplexChallengerTarget& x) {
+  if (x.input_buffer.size() > (size_t)WIDTH) throw std::logic_error("challenger overflow");
+  for (size_t i = 0; i < x.input_buffer.size(); i++) x.sponge_state[i] = x.input_buffer[i];
+  x.input_buffer.clear();
+  std::array<Target, 12> st;
+  std::copy(x.sponge_state.begin(), x.sponge_state.end(), st.begin());
+  auto out = cb.poseidon2_permute_targets(st);
+  x.sponge_state.assign(out.begin(), out.end());
+  x.output_buffer = x.sponge_state;
+}
+void p3_observe_single(CircuitBuilder& cb, DuplexChallengerTarget& x, Target v) {
+  x.output_buffer.clear();
+  x.input_buffer.push_back(v);
+  if (x.input_buffer.size() == (size_t)WIDTH) p3_duplexing(cb, x);
+}
+template <class It>
+void p3_observe(CircuitBuilder& cb, DuplexChallengerTarget& x, It b, It e) {
+  for (; b != e; ++b) p3_observe_single(cb, x, *b);
+}
+Target p3_sample(CircuitBuilder& cb, DuplexChallengerTarget& x) {
+  if (!x.input_buffer.empty() || x.output_buffer.empty()) p3_duplexing(cb, x);
+  Target t = x.output_buffer.back();
+  x.output_buffer.pop_back();
+  return t;
+}
+Ext p3_sample_ext(CircuitBuilder& cb, DuplexChallengerTarget& x) {
+  Target a = p3_sample(cb, x);
+  Target b = p3_sample(cb, x);
+  return Ext{a, b};
+}
+// challenger.rs:126-148
+Target p3_sample_bits(CircuitBuilder& cb, DuplexChallengerTarget& x, int bits) {
+  Target rand_f = p3_sample(cb, x);
+  auto [rl, rh] = cb.split_low_high(rand_f, 32, 64);
+  Target one = cb.one();
+  Target power_of_bits = p3_constant(cb, (u64)1 << bits);
+  Target pm1 = cb.sub(power_of_bits, one);
+  auto [pl, ph] = cb.split_low_high(pm1, 32, 64);
+  auto r = cb.and_u64({rl, rh}, {pl, ph});
+  return cb.mul_const_add((u64)1 << 32, r[1], r[0]);
+}
+void p3_check_witness(CircuitBuilder& cb, DuplexChallengerTarget& x, int bits, Target witness) {
+  p3_observe_single(cb, x, witness);
+  Target res = p3_sample_bits(cb, x, bits);
+  Target zero = cb.zero();
+  cb.connect(res, zero);
+}
+
+// ---------------------------------------------------------------- src/p3/commit.rs
+struct Dimensions {
+  size_t width, height;
+};
+std::array<Target, 4> hash_iter_slices(CircuitBuilder& cb, const std::vector<const std::vector<Target>*>& slices) {
+  auto state = p3_arr12(cb);
+  std::vector<Target> flat;
+  for (auto* s : slices) flat.insert(flat.end(), s->begin(), s->end());
+  for (size_t off = 0; off < flat.size(); off += RATE) {
+    size_t m = std::min((size_t)RATE, flat.size() - off);
+    for (size_t i = 0; i < m; i++) state[i] = flat[off + i];
+    state = cb.poseidon2_permute_targets(state);
+  }
+  return {state[0], state[1], state[2], state[3]};
+}
+std::array<Target, 4> compress(CircuitBuilder& cb, const std::array<Target, 4>& l, const std::array<Target, 4>& r) {
+  auto state = p3_arr12(cb);
+  for (int i = 0; i < 4; i++) {
+    state[i] = l[i];
+    state[4 + i] = r[i];
+  }
+  state = cb.poseidon2_permute_targets(state);
+  return {state[0], state[1], state[2], state[3]};
+}
+size_t npo2(size_t x) {
+  size_t r = 1;
+  while (r < x) r <<= 1;
+  return r;
+}
+// commit.rs:62-129
+void verify_batch(CircuitBuilder& cb, const std::array<Target, 4>& commit, const std::vector<Dimensions>& dims,
+                  Target index, const std::vector<std::vector<Target>>& opened_values,
+                  const std::vector<std::array<Target, 4>>& proof) {
+  std::vector<size_t> order(dims.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dims[a].height > dims[b].height; });
+  size_t pos = 0;
+  size_t curr_height_padded = npo2(dims[order[0]].height);
+  std::vector<const std::vector<Target>*> sl;
+  while (pos < order.size() && npo2(dims[order[pos]].height) == curr_height_padded) sl.push_back(&opened_values[order[pos++]]);
+  auto root = hash_iter_slices(cb, sl);
+  for (const auto& sibling : proof) {
+    Target one = cb.one();
+    Target index_and_one = p3_and(cb, index, one);
+    BoolTarget is_odd = index_and_one;
+    std::array<Target, 4> left, right;
+    for (int i = 0; i < DIGEST_ELEMS; i++) {
+      left[i] = cb.zero();
+      right[i] = cb.zero();
+    }
+    for (int i = 0; i < DIGEST_ELEMS; i++) {
+      left[i] = cb._if(is_odd, sibling[i], root[i]);
+      right[i] = cb._if(is_odd, root[i], sibling[i]);
+    }
+    root = compress(cb, left, right);
+    index = p3_rsh(cb, index, 1);
+    curr_height_padded >>= 1;
+    if (pos < order.size() && npo2(dims[order[pos]].height) == curr_height_padded) {
+      size_t next_height = dims[order[pos]].height;
+      std::vector<const std::vector<Target>*> s2;
+      while (pos < order.size() && dims[order[pos]].height == next_height) s2.push_back(&opened_values[order[pos++]]);
+      auto d = hash_iter_slices(cb, s2);
+      root = compress(cb, root, d);
+    }
+  }
+  for (int i = 0; i < 4; i++) cb.connect(commit[i], root[i]);
+}
+
+// ---------------------------------------------------------------- src/p3/serde/two_adic.rs
+struct Coset {
+  int log_n;
+  Target shift;
+  size_t size() const { return (size_t)1 << log_n; }
+};
+Target coset_gen(CircuitBuilder& cb, const Coset& d) {
+  Target base = cb.constant(TWO_ADIC_BASE);
+  return cb.exp_power_of_2(base, 32 - d.log_n);
+}
+Ext coset_next_point(CircuitBuilder& cb, const Coset& d, Ext x) {
+  Target g = coset_gen(cb, d);
+  return p3_ext_mul_single(cb, x, g);
+}
+Ext coset_zp_at_point(CircuitBuilder& cb, const Coset& d, Ext point) {
+  Target shift_inv = cb.inverse(d.shift);
+  Ext p = p3_ext_mul_single(cb, point, shift_inv);
+  Ext pw = p3_ext_exp_power_of_2(cb, p, d.log_n);
+  Ext one = p3_ext_one(cb);
+  return p3_ext_sub(cb, pw, one);
+}
+Target coset_zp_at_single_point(CircuitBuilder& cb, const Coset& d, Target point) {
+  Target shift_inv = cb.inverse(d.shift);
+  Target p = cb.mul(shift_inv, point);
+  Target pw = cb.exp_power_of_2(p, d.log_n);
+  Target one = cb.one();
+  return cb.sub(pw, one);
+}
+struct LagrangeSelectors {
+  Ext is_first_row, is_last_row, is_transition, inv_zeroifier;
+};
+// two_adic.rs:92-122
+LagrangeSelectors selectors_at_point(CircuitBuilder& cb, const Coset& d, Ext point) {
+  Target shift_inv = cb.inverse(d.shift);
+  Ext unshifted = p3_ext_mul_single(cb, point, shift_inv);
+  Ext un_pow = p3_ext_exp_power_of_2(cb, unshifted, d.log_n);
+  Ext one = p3_ext_one(cb);
+  Ext z_h = p3_ext_sub(cb, un_pow, one);
+  Ext un_m1 = p3_ext_sub(cb, unshifted, one);
+  Ext first = p3_ext_div(cb, z_h, un_m1);
+  Target g = coset_gen(cb, d);
+  Target g_inv = cb.inverse(g);
+  Ext un_m_ginv = p3_ext_sub_single(cb, unshifted, g_inv);
+  Ext last = p3_ext_div(cb, z_h, un_m_ginv);
+  LagrangeSelectors s;
+  s.is_first_row = first;
+  s.is_last_row = last;
+  s.is_transition = un_m_ginv;
+  s.inv_zeroifier = p3_ext_inverse(cb, z_h);
+  return s;
+}
+}  // namespace
+
+// ---------------------------------------------------------------- src/p3/air.rs
+void VerifierConstraintFolder::assert_zero(CircuitBuilder& cb, Ext x) {
+  accumulator = p3_ext_mul_add(cb, accumulator, alpha, x);
+}
+void VerifierConstraintFolder::assert_eq(CircuitBuilder& cb, Ext x, Ext y) {
+  Ext d = p3_ext_sub(cb, x, y);
+  assert_zero(cb, d);
+}
+void VerifierConstraintFolder::when_assert_eq(CircuitBuilder& cb, Ext condition, Ext x, Ext y) {
+  Ext d = p3_ext_sub(cb, x, y);
+  Ext f = p3_ext_mul(cb, condition, d);
+  assert_zero(cb, f);
+}
+// src/p3/mod.rs:176-221
+void FibonacciAir::eval(VerifierConstraintFolder& folder, CircuitBuilder& cb) const {
+  Ext la = folder.trace_local[0], lb = folder.trace_local[1], lc = folder.trace_local[2];
+  Ext na = folder.trace_next[0], nb = folder.trace_next[1];
+  Ext a_plus_b = p3_ext_add(cb, la, lb);
+  folder.assert_eq(cb, a_plus_b, lc);
+  Ext one = p3_ext_one(cb);
+  folder.when_assert_eq(cb, folder.is_first_row, one, la);
+  folder.when_assert_eq(cb, folder.is_first_row, one, lb);
+  folder.when_assert_eq(cb, folder.is_transition, na, lb);
+  folder.when_assert_eq(cb, folder.is_transition, nb, lc);
+}
+
+// ---------------------------------------------------------------- src/p3/serde/proof.rs:357-373
+size_t P3Config::num_inputs() const {
+  size_t n = 8 + (size_t)trace_width * 4 + 4;
+  n += (size_t)log_trace_height * 4;
+  size_t per_query = 0;
+  for (int i = 0; i < log_trace_height; i++) per_query += 2 + 4 * (size_t)(log_trace_height - i);
+  n += per_query * fri_config.num_queries + 3;
+  n += (size_t)fri_config.num_queries *
+       ((trace_width + 4 * opening_matrix_log_max_height) +
+        (opening_proof_query_openings_opened_values_length + 4 * opening_matrix_log_max_height));
+  return n;
+}
+static P3ProofTarget add_virtual_proof(CircuitBuilder& cb, const P3Config& cfg) {
+  std::vector<Target>& in = cb.input_targets;
+  auto vt = [&]() {
+    Target t = cb.add_virtual_target();
+    in.push_back(t);
+    return t;
+  };
+  auto v4 = [&]() { return std::array<Target, 4>{vt(), vt(), vt(), vt()}; };
+  auto vext = [&]() { return Ext{vt(), vt()}; };
+  P3ProofTarget p;
+  p.trace_commit = v4();
+  p.quotient_commit = v4();
+  for (int i = 0; i < cfg.trace_width; i++) p.trace_local.push_back(vext());
+  for (int i = 0; i < cfg.trace_width; i++) p.trace_next.push_back(vext());
+  {
+    Ext a = vext();
+    Ext b = vext();
+    p.quotient_chunks.push_back({a, b});  // proof.rs:41-48: exactly one chunk
+  }
+  for (int i = 0; i < cfg.log_trace_height; i++) p.commit_phase_commits.push_back(v4());
+  for (int q = 0; q < cfg.fri_config.num_queries; q++) {
+    std::vector<P3CommitPhaseStep> steps;
+    for (int i = 0; i < cfg.log_trace_height; i++) {
+      P3CommitPhaseStep s;
+      s.sibling_value = vext();
+      for (int k = 0; k < cfg.log_trace_height - i; k++) s.opening_proof.push_back(v4());
+      steps.push_back(std::move(s));
+    }
+    p.query_proofs.push_back(std::move(steps));
+  }
+  p.final_poly = vext();
+  p.pow_witness = vt();
+  for (int q = 0; q < cfg.fri_config.num_queries; q++) {
+    std::array<P3BatchOpening, 2> bo;
+    int widths[2] = {cfg.trace_width, cfg.opening_proof_query_openings_opened_values_length};
+    for (int b = 0; b < 2; b++) {
+      std::vector<Target> row;
+      for (int i = 0; i < widths[b]; i++) row.push_back(vt());
+      bo[b].opened_values.push_back(row);
+      for (int k = 0; k < cfg.opening_matrix_log_max_height; k++) bo[b].opening_proof.push_back(v4());
+    }
+    p.query_openings.push_back(std::move(bo));
+  }
+  p.degree_bits = cfg.degree_bits;
+  return p;
+}
+
+// ---------------------------------------------------------------- src/p3/verifier.rs
+namespace {
+struct MatPoints {
+  Coset domain;
+  std::vector<std::pair<Ext, std::vector<Ext>>> points_and_values;
+};
+struct CommitAndPoints {
+  std::array<Target, 4> commit;
+  std::vector<MatPoints> mats;
+};
+
+// verifier.rs:424-519
+Ext p3_verify_query(CircuitBuilder& cb, const std::vector<std::array<Target, 4>>& commit_phase_commits,
+                    Target index, const std::vector<P3CommitPhaseStep>& steps, const std::vector<Ext>& betas,
+                    const std::vector<Ext>& reduced_openings, int log_max_height) {
+  Ext folded_eval = p3_ext_zero(cb);
+  Target two_adic_generator = p3_two_adic_generator(cb, log_max_height);
+  Target rev_index_shifted = reverse_p3_bits_len(cb, index, log_max_height);
+  Target x0 = cb.exp(two_adic_generator, rev_index_shifted, 64);
+  Ext x = p3_field_to_arr(cb, x0);
+  Target one = cb.one();
+  size_t n_steps = std::min({(size_t)log_max_height, commit_phase_commits.size(), steps.size(), betas.size()});
+  for (size_t s = 0; s < n_steps; s++) {
+    int log_folded_height = log_max_height - 1 - (int)s;
+    const auto& commit = commit_phase_commits[s];
+    const P3CommitPhaseStep& step = steps[s];
+    const Ext& beta = betas[s];
+    folded_eval = p3_ext_add(cb, reduced_openings[log_folded_height + 1], folded_eval);
+    Target index_sibling = p3_xor(cb, index, one);
+    Target index_pair = p3_rsh(cb, index, 1);
+    Target isao = p3_and(cb, index_sibling, one);
+    BoolTarget is_odd = isao;
+    Ext evals[2] = {folded_eval, folded_eval};
+    evals[0] = p3_ext_if(cb, is_odd, evals[0], step.sibling_value);
+    evals[1] = p3_ext_if(cb, is_odd, step.sibling_value, evals[1]);
+    std::vector<Dimensions> dims = {{2 * 2, (size_t)1 << log_folded_height}};
+    std::vector<std::vector<Target>> ov = {{evals[0][0], evals[0][1], evals[1][0], evals[1][1]}};
+    verify_batch(cb, commit, dims, index_pair, ov, step.opening_proof);
+
+    Ext xs[2] = {x, x};
+    Ext tag = p3_ext_two_adic_generator(cb, 1);
+    Ext xs0g = p3_ext_mul(cb, xs[0], tag);
+    Ext xs1g = p3_ext_mul(cb, xs[1], tag);
+    Target one2 = cb.one();
+    Target isao2 = p3_and(cb, index_sibling, one2);
+    BoolTarget is_odd2 = isao2;
+    xs[0] = p3_ext_if(cb, is_odd2, xs[0], xs0g);
+    xs[1] = p3_ext_if(cb, is_odd2, xs1g, xs[1]);
+    // interpolate and evaluate at beta
+    Ext beta_minus_xs0 = p3_ext_sub(cb, beta, xs[0]);
+    Ext e1_minus_e0 = p3_ext_sub(cb, evals[1], evals[0]);
+    Ext xs1_minus_xs0 = p3_ext_sub(cb, xs[1], xs[0]);
+    Ext num = p3_ext_mul(cb, e1_minus_e0, beta_minus_xs0);
+    Ext q = p3_ext_div(cb, num, xs1_minus_xs0);
+    folded_eval = p3_ext_add(cb, evals[0], q);
+    index = index_pair;
+    x = p3_ext_mul(cb, x, x);
+  }
+  return folded_eval;
+}
+
+// verifier.rs:242-355, 357-388, 390-422
+void p3_verify_opening_proof(CircuitBuilder& cb, const P3FriConfig& config,
+                             const std::vector<CommitAndPoints>& commits_and_points, const P3ProofTarget& proof,
+                             DuplexChallengerTarget& challenger) {
+  Ext alpha = p3_sample_ext(cb, challenger);
+  // p3_verify_shape_and_sample_challenges
+  std::vector<Ext> betas;
+  for (const auto& comm : proof.commit_phase_commits) {
+    p3_observe(cb, challenger, comm.begin(), comm.end());
+    betas.push_back(p3_sample_ext(cb, challenger));
+  }
+  if ((int)proof.query_proofs.size() != config.num_queries) throw std::logic_error("InvalidProofShape");
+  p3_check_witness(cb, challenger, config.proof_of_work_bits, proof.pow_witness);
+  const int log_max_height = (int)proof.commit_phase_commits.size() + config.log_blowup;
+  std::vector<Target> query_indices;
+  for (int i = 0; i < config.num_queries; i++) query_indices.push_back(p3_sample_bits(cb, challenger, log_max_height));
+
+  std::vector<std::vector<Ext>> reduced_openings;
+  for (size_t qi = 0; qi < proof.query_openings.size() && qi < query_indices.size(); qi++) {
+    const auto& query_opening = proof.query_openings[qi];
+    Target index = query_indices[qi];
+    std::vector<Ext> ro(32);
+    for (auto& e : ro) e = Ext{cb.zero(), cb.zero()};
+    Ext one = p3_ext_one(cb);
+    std::vector<Ext> alpha_pow(32, one);
+    for (size_t b = 0; b < 2 && b < commits_and_points.size(); b++) {
+      const P3BatchOpening& batch_opening = query_opening[b];
+      const CommitAndPoints& cp = commits_and_points[b];
+      std::vector<Dimensions> batch_dims;
+      for (const auto& m : cp.mats) batch_dims.push_back({0, m.domain.size()});
+      verify_batch(cb, cp.commit, batch_dims, index, batch_opening.opened_values, batch_opening.opening_proof);
+      for (size_t mi = 0; mi < batch_opening.opened_values.size() && mi < cp.mats.size(); mi++) {
+        const std::vector<Target>& mat_opening = batch_opening.opened_values[mi];
+        const MatPoints& mp = cp.mats[mi];
+        int log_height = log2_strict(mp.domain.size()) + config.log_blowup;
+        int bits_reduced = log_max_height - log_height;
+        Target index_rs = p3_rsh(cb, index, bits_reduced);
+        Target rev_reduced_index = reverse_p3_bits_len(cb, index_rs, log_height);
+        Target generator = p3_w(cb);
+        Target tag = p3_two_adic_generator(cb, log_height);
+        Target tag_pow = cb.exp(tag, rev_reduced_index, 64);
+        Target x = cb.mul(generator, tag_pow);
+        for (const auto& [z, ps_at_z] : mp.points_and_values) {
+          size_t cnt = std::min(mat_opening.size(), ps_at_z.size());
+          for (size_t k = 0; k < cnt; k++) {
+            Target p_at_x = mat_opening[k];
+            const Ext& p_at_z = ps_at_z[k];
+            Ext p_at_z_neg = p3_ext_neg(cb, p_at_z);
+            Ext z_neg = p3_ext_neg(cb, z);
+            Ext numer = p3_ext_add_single(cb, p_at_z_neg, p_at_x);
+            Ext denom = p3_ext_add_single(cb, z_neg, x);
+            Ext quotient = p3_ext_div(cb, numer, denom);
+            Ext t = p3_ext_mul(cb, alpha_pow[log_height], quotient);
+            ro[log_height] = p3_ext_add(cb, ro[log_height], t);
+            alpha_pow[log_height] = p3_ext_mul(cb, alpha_pow[log_height], alpha);
+          }
+        }
+      }
+    }
+    reduced_openings.push_back(std::move(ro));
+  }
+  // p3_verify_challenges
+  for (size_t qi = 0; qi < query_indices.size() && qi < proof.query_proofs.size() && qi < reduced_openings.size(); qi++) {
+    Ext folded = p3_verify_query(cb, proof.commit_phase_commits, query_indices[qi], proof.query_proofs[qi], betas,
+                                 reduced_openings[qi], log_max_height);
+    connect_p3_ext(cb, folded, proof.final_poly);
+  }
+}
+}  // namespace
+
+// verifier.rs:100-240 (__p3_verify_proof__) behind mod.rs:66-94 (p3_verify_proof)
+P3ProofTarget p3_verify_proof(CircuitBuilder& cb, const P3Config& config, const Air& air) {
+  DuplexChallengerTarget challenger;
+  {
+    auto st = p3_arr12(cb);
+    challenger.sponge_state.assign(st.begin(), st.end());
+  }
+  P3ProofTarget proof = add_virtual_proof(cb, config);
+
+  const int degree_bits = proof.degree_bits;
+  const size_t degree = (size_t)1 << degree_bits;
+  const size_t quotient_degree = (size_t)1 << config.log_quotient_degree;
+
+  // TwoAdicMultiplicativeCoset::natural_domain_for_degree
+  if (log2_strict(degree) > config.log_trace_height) throw std::logic_error("degree above trace height");
+  Coset trace_domain{log2_strict(degree), cb.one()};
+  // create_disjoint_domain
+  Coset quotient_domain;
+  {
+    Target generator = cb.constant(7);
+    quotient_domain.log_n = log2_ceil((size_t)1 << (degree_bits + config.log_quotient_degree));
+    quotient_domain.shift = cb.mul(trace_domain.shift, generator);
+  }
+  // split_domains
+  std::vector<Coset> quotient_chunks_domains;
+  {
+    int log_chunks = log2_strict(quotient_degree);
+    Target g = coset_gen(cb, quotient_domain);
+    for (size_t i = 0; i < quotient_degree; i++) {
+      Target gi = cb.exp_u64(g, i);
+      Target shift = cb.mul(quotient_domain.shift, gi);
+      quotient_chunks_domains.push_back(Coset{quotient_domain.log_n - log_chunks, shift});
+    }
+  }
+  const int air_width = air.width();
+  bool valid_shape = (int)proof.trace_local.size() == air_width && (int)proof.trace_next.size() == air_width &&
+                     proof.quotient_chunks.size() == quotient_degree;
+  for (auto& qc : proof.quotient_chunks) valid_shape = valid_shape && qc.size() == 2;
+  if (!valid_shape) throw std::logic_error("Invalid Proof Shape");  // verifier.rs:131-133
+
+  p3_observe(cb, challenger, proof.trace_commit.begin(), proof.trace_commit.end());
+  Ext alpha = p3_sample_ext(cb, challenger);
+  p3_observe(cb, challenger, proof.quotient_commit.begin(), proof.quotient_commit.end());
+  Ext zeta = p3_sample_ext(cb, challenger);
+  Ext zeta_next = coset_next_point(cb, trace_domain, zeta);
+
+  std::vector<CommitAndPoints> cps(2);
+  cps[0].commit = proof.trace_commit;
+  cps[0].mats.push_back(MatPoints{trace_domain, {{zeta, proof.trace_local}, {zeta_next, proof.trace_next}}});
+  cps[1].commit = proof.quotient_commit;
+  for (size_t i = 0; i < quotient_chunks_domains.size() && i < proof.quotient_chunks.size(); i++)
+    cps[1].mats.push_back(MatPoints{quotient_chunks_domains[i], {{zeta, proof.quotient_chunks[i]}}});
+  p3_verify_opening_proof(cb, config.fri_config, cps, proof, challenger);
+
+  // zps (verifier.rs:169-198)
+  std::vector<Ext> zps;
+  for (size_t i = 0; i < quotient_chunks_domains.size(); i++) {
+    const Coset& domain = quotient_chunks_domains[i];
+    std::vector<Ext> terms;
+    for (size_t j = 0; j < quotient_chunks_domains.size(); j++) {
+      if (j == i) continue;
+      const Coset& other = quotient_chunks_domains[j];
+      Ext other_zeta = coset_zp_at_point(cb, other, zeta);
+      Target first_point = domain.shift;
+      Target other_first = coset_zp_at_single_point(cb, other, first_point);
+      Target other_first_inv = cb.inverse(other_first);
+      terms.push_back(p3_ext_mul_single(cb, other_zeta, other_first_inv));
+    }
+    // `.unwrap_or({..})` evaluates its argument eagerly
+    Target one = cb.one();
+    Ext dflt = p3_field_to_arr(cb, one);
+    if (terms.empty()) {
+      zps.push_back(dflt);
+    } else {
+      Ext acc = terms[0];
+      for (size_t k = 1; k < terms.size(); k++) acc = p3_ext_mul(cb, acc, terms[k]);
+      zps.push_back(acc);
+    }
+  }
+  // quotient recomposition (verifier.rs:200-221)
+  std::vector<Ext> per_chunk;
+  for (size_t ch_i = 0; ch_i < proof.quotient_chunks.size(); ch_i++) {
+    std::vector<Ext> parts;
+    for (size_t e_i = 0; e_i < proof.quotient_chunks[ch_i].size(); e_i++) {
+      Ext monomial = p3_ext_monomial(cb, (int)e_i);
+      Ext mc = p3_ext_mul(cb, monomial, proof.quotient_chunks[ch_i][e_i]);
+      parts.push_back(p3_ext_mul(cb, zps[ch_i], mc));
+    }
+    Ext acc = parts[0];
+    for (size_t k = 1; k < parts.size(); k++) acc = p3_ext_add(cb, acc, parts[k]);
+    per_chunk.push_back(acc);
+  }
+  Ext quotient = per_chunk[0];
+  for (size_t k = 1; k < per_chunk.size(); k++) quotient = p3_ext_add(cb, quotient, per_chunk[k]);
+
+  LagrangeSelectors sels = selectors_at_point(cb, trace_domain, zeta);
+  VerifierConstraintFolder folder;
+  folder.trace_local = proof.trace_local;
+  folder.trace_next = proof.trace_next;
+  folder.is_first_row = sels.is_first_row;
+  folder.is_last_row = sels.is_last_row;
+  folder.is_transition = sels.is_transition;
+  folder.alpha = alpha;
+  folder.accumulator = p3_ext_zero(cb);
+  air.eval(folder, cb);
+  Ext folded_constraints = folder.accumulator;
+  Ext lhs = p3_ext_mul(cb, folded_constraints, sels.inv_zeroifier);
+  connect_p3_ext(cb, lhs, quotient);
+  return proof;
+}
+
+}  // namespace p25
