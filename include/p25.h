@@ -86,6 +86,99 @@ p25_status p25_lde_commit_dev(const uint64_t* d_polys, unsigned log_n, size_t n_
                               uint64_t* d_tmp, uint64_t* d_lde, uint64_t* d_tree, void* stream);
 p25_status p25_poseidon_permute_dev(uint64_t* d_states, size_t n, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Circuits.  A p25_circuit is the built plonky2 circuit (upstream `CircuitData`): immutable after
+ * creation, reusable for any number of proofs (`prove` borrows it immutably upstream too).
+ * Building / import / export / info are host-only and work without a GPU; proving needs one.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct p25_circuit p25_circuit;
+
+/* Shape of the plonky3 proof being verified in-circuit: the reference's FriConfig
+ * (src/p3/serde/fri.rs:3-8, values at src/p3/mod.rs:242-246) + P3Config derived from the proof's
+ * shape (src/p3/mod.rs:74-87, src/p3/serde/proof.rs:401-410). */
+typedef struct {
+  int32_t log_blowup, num_queries, proof_of_work_bits;
+  int32_t log_quotient_degree, log_trace_height, trace_width;
+  int32_t opening_matrix_log_max_height, quotient_opened_len, degree_bits;
+} p25_p3_config;
+
+enum { P25_AIR_FIBONACCI = 0 }; /* the test AIR of src/p3/mod.rs:160-221 */
+
+/* Replaces: CircuitBuilder::new(CircuitConfig::standard_recursion_config());
+ *           builder.p3_verify_proof::<PoseidonHash>(proof, &air, fri_config);
+ *           builder.build::<PoseidonGoldilocksConfig>()          (src/p3/mod.rs:231-250). */
+p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, p25_circuit** out);
+/* Circuit blob (format: plonky2.5_amd/csrc/circuit_io.h): persist a built circuit / hand it to
+ * another process.  export: pass buf = NULL to query the size. */
+p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out);
+p25_status p25_circuit_import(const uint8_t* blob, size_t len, p25_circuit** out);
+void p25_circuit_destroy(p25_circuit* c);
+
+typedef struct {
+  uint64_t degree_bits, num_rows_used, num_wires, num_routed_wires, num_inputs, num_generators;
+  uint64_t num_gate_types, num_selectors, num_constants_sigmas, num_gate_constraints;
+  uint64_t proof_words, witness_levels, witness_slots, reserved;
+} p25_circuit_info_t;
+p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out);
+/* Rows per gate type, in sorted-gate order; ids_out receives up to cap gate-id strings joined by '\n'. */
+p25_status p25_circuit_gate_counts(const p25_circuit* c, uint64_t* counts_out, size_t cap, char* ids_out, size_t ids_cap);
+/* Verifier data (upstream VerifierOnlyCircuitData): circuit_digest[4] and the constants/sigmas cap
+ * [2^cap_height][4].  Computed on the GPU at first use. */
+p25_status p25_circuit_digest(p25_circuit* c, uint64_t* digest4, uint64_t* constants_sigmas_cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Proving.  Replaces `data.prove(pw)` (src/p3/mod.rs:260) for a batch of independent witnesses.
+ *
+ *   inputs[n_proofs][num_inputs]  the plonky3 proof's field elements in `add_virtual_to` order
+ *                                 (src/p3/serde/proof.rs:357-373) = what set_witness assigns (:374-383)
+ *   seeds[n_proofs] (nullable)    upstream fills the PublicInputGate's 131 unused wires from the OS RNG
+ *                                 (RandomValueGenerator), so real proofs are not reproducible; here the
+ *                                 filler is SplitMix64(seed, wire) and proofs are deterministic.
+ *                                 NULL = seed i for proof i.
+ *   proofs_out[n_proofs][proof_stride_words]   flat proofs (layout below), stride >= proof_words
+ *   per_proof_status[n_proofs]    P25_OK or the upstream failure mode (P25_ERR_WITNESS_CONFLICT ...);
+ *                                 a bad witness fails that proof only.
+ *   timings (nullable)            device milliseconds per upstream phase, summed over the batch.
+ *
+ * Proof layout (u64 words; E = extension element as (c0, c1); H = 4-word hash; CAP = 2^cap_height H):
+ *   wires_cap CAP | plonk_zs_partial_products_cap CAP | quotient_polys_cap CAP |
+ *   openings: constants E[5] | plonk_sigmas E[80] | wires E[135] | plonk_zs E[2] | plonk_zs_next E[2] |
+ *             partial_products E[18] | quotient_polys E[16] |
+ *   commit_phase_merkle_caps CAP[3] |
+ *   query_round_proofs[28]: for each of the 4 oracles {leaf row u64[width], siblings H[15]};
+ *                           for each FRI layer {evals E[16], siblings H[11,7,3]} |
+ *   final_poly E[16] | pow_witness u64           (sizes shown for the fib-64 circuit; total 19,861 words)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  float witness_ms, wires_commit_ms, partial_products_ms, zs_commit_ms, quotient_ms, quotient_commit_ms,
+      openings_ms, fri_ms, total_ms;
+} p25_timings;
+p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* seeds,
+                           uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status,
+                           p25_timings* timings);
+/* Same with every buffer resident in HBM (device pointers; d_status is uint32_t[n_proofs]).
+ * Enqueues on the circuit's stream and returns; p25_circuit_sync waits. */
+p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t n_proofs, const uint64_t* d_seeds,
+                               uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status,
+                               p25_timings* timings);
+p25_status p25_circuit_sync(p25_circuit* c);
+/* Witness only (parity tests): wires_out[num_wires][2^degree_bits], column-major. */
+p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, uint64_t* wires_out,
+                       p25_status* proof_status);
+
+/* ------------------------------------------------------------------------------------------
+ * Data formats either side of the path.
+ * ------------------------------------------------------------------------------------------ */
+/* plonky3 proof JSON (serde form of src/p3/serde/proof.rs:349-355, e.g. artifacts/proof_fibonacci.json)
+ * -> input vector + shape.  Replaces serde_json::from_str::<P3ProofField> + set_witness
+ * (src/p3/mod.rs:233-234, 254-257).  inputs_out may be NULL to query *n_out. */
+p25_status p25_p3_proof_from_json(const char* json, size_t len, uint64_t* inputs_out, size_t cap, size_t* n_out,
+                                  p25_p3_config* cfg_out);
+/* Flat proof -> JSON shaped like serde_json::to_string(&ProofWithPublicInputs) (src/p3/mod.rs:261).
+ * buf may be NULL to query *len_out. */
+p25_status p25_proof_to_json(p25_circuit* c, const uint64_t* proof, char* buf, size_t cap, size_t* len_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,10 +1,12 @@
 """ctypes binding of libp25.so (C ABI: include/p25.h)."""
 import ctypes as C
 import os
+
 import numpy as np
 
 __all__ = ["P25Error", "lib", "lib_path", "device_init", "poseidon_permute", "poseidon2_permute",
-           "merkle_commit", "merkle_tree_words", "lde_commit", "EXPORTED_SYMBOLS", "P"]
+           "merkle_commit", "merkle_tree_words", "lde_commit", "EXPORTED_SYMBOLS", "P",
+           "P3Config", "Circuit", "p3_proof_from_json", "Timings"]
 
 P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,25 +22,61 @@ class P25Error(RuntimeError):
         self.status = status
 
 
+class P3Config(C.Structure):
+    """p25_p3_config: FriConfig (src/p3/mod.rs:242-246) + P3Config (src/p3/mod.rs:74-87)."""
+    _fields_ = [(n, C.c_int32) for n in ("log_blowup", "num_queries", "proof_of_work_bits",
+                                         "log_quotient_degree", "log_trace_height", "trace_width",
+                                         "opening_matrix_log_max_height", "quotient_opened_len", "degree_bits")]
+
+    @classmethod
+    def fib64(cls):
+        return cls(1, 100, 16, 0, 6, 3, 7, 2, 6)
+
+
+class CircuitInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("degree_bits", "num_rows_used", "num_wires", "num_routed_wires",
+                                          "num_inputs", "num_generators", "num_gate_types", "num_selectors",
+                                          "num_constants_sigmas", "num_gate_constraints", "proof_words",
+                                          "witness_levels", "witness_slots", "reserved")]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("witness_ms", "wires_commit_ms", "partial_products_ms", "zs_commit_ms",
+                                         "quotient_ms", "quotient_commit_ms", "openings_ms", "fri_ms", "total_ms")]
+
+    def as_dict(self):
+        return {n: float(getattr(self, n)) for n, _ in self._fields_}
+
+
 _lib = None
-u64p = C.POINTER(C.c_uint64)
+vp, sz, ui, i32 = C.c_void_p, C.c_size_t, C.c_uint, C.c_int32
 
 # name -> (restype, argtypes); every symbol include/p25.h declares
 EXPORTED_SYMBOLS = {
     "p25_last_error": (C.c_char_p, []),
     "p25_version": (C.c_char_p, []),
-    "p25_device_init": (C.c_int32, [C.c_int]),
-    "p25_poseidon_permute": (C.c_int32, [C.c_void_p, C.c_size_t]),
-    "p25_poseidon2_permute": (C.c_int32, [C.c_void_p, C.c_size_t]),
-    "p25_merkle_commit": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p]),
-    "p25_merkle_tree_words": (C.c_size_t, [C.c_size_t, C.c_uint]),
-    "p25_lde_commit": (C.c_int32, [C.c_void_p, C.c_uint, C.c_size_t, C.c_int, C.c_uint, C.c_uint,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]),
-    "p25_merkle_commit_dev": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint,
-                                          C.c_void_p, C.c_void_p]),
-    "p25_lde_commit_dev": (C.c_int32, [C.c_void_p, C.c_uint, C.c_size_t, C.c_int, C.c_uint, C.c_uint,
-                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "p25_poseidon_permute_dev": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "p25_device_init": (i32, [C.c_int]),
+    "p25_poseidon_permute": (i32, [vp, sz]),
+    "p25_poseidon2_permute": (i32, [vp, sz]),
+    "p25_merkle_commit": (i32, [vp, sz, sz, ui, vp, vp]),
+    "p25_merkle_tree_words": (sz, [sz, ui]),
+    "p25_lde_commit": (i32, [vp, ui, sz, C.c_int, ui, ui, vp, vp, vp]),
+    "p25_merkle_commit_dev": (i32, [vp, sz, sz, sz, ui, vp, vp]),
+    "p25_lde_commit_dev": (i32, [vp, ui, sz, C.c_int, ui, ui, vp, vp, vp, vp, vp]),
+    "p25_poseidon_permute_dev": (i32, [vp, sz, vp]),
+    "p25_circuit_build_p3_verifier": (i32, [C.POINTER(P3Config), i32, C.POINTER(vp)]),
+    "p25_circuit_export": (i32, [vp, vp, sz, C.POINTER(sz)]),
+    "p25_circuit_import": (i32, [vp, sz, C.POINTER(vp)]),
+    "p25_circuit_destroy": (None, [vp]),
+    "p25_circuit_info": (i32, [vp, C.POINTER(CircuitInfo)]),
+    "p25_circuit_gate_counts": (i32, [vp, vp, sz, C.c_char_p, sz]),
+    "p25_circuit_digest": (i32, [vp, vp, vp]),
+    "p25_prove_batch": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
+    "p25_prove_batch_dev": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
+    "p25_circuit_sync": (i32, [vp]),
+    "p25_witness": (i32, [vp, vp, C.c_uint64, vp, C.POINTER(i32)]),
+    "p25_p3_proof_from_json": (i32, [C.c_char_p, sz, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
+    "p25_proof_to_json": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
 }
 
 
@@ -62,8 +100,7 @@ def _check(status):
 
 
 def _u64(a):
-    a = np.ascontiguousarray(a, dtype=np.uint64)
-    return a
+    return np.ascontiguousarray(a, dtype=np.uint64)
 
 
 def _ptr(a):
@@ -112,3 +149,118 @@ def lde_commit(polys, rate_bits, cap_height, from_coeffs=False, want_lde=True):
     _check(lib().p25_lde_commit(_ptr(a), log_n, n_polys, int(from_coeffs), rate_bits, cap_height,
                                 _ptr(coeffs), _ptr(lde), _ptr(cap)))
     return coeffs, lde, cap
+
+
+def p3_proof_from_json(text):
+    """plonky3 proof JSON (str/bytes) -> (inputs uint64[n], P3Config).  Mirrors
+    serde_json::from_str::<P3ProofField> + Proof::set_witness (src/p3/mod.rs:233-234, 254-257)."""
+    if isinstance(text, str):
+        text = text.encode()
+    n = sz(0)
+    cfg = P3Config()
+    _check(lib().p25_p3_proof_from_json(text, len(text), None, 0, C.byref(n), C.byref(cfg)))
+    out = np.zeros(n.value, dtype=np.uint64)
+    _check(lib().p25_p3_proof_from_json(text, len(text), _ptr(out), out.size, C.byref(n), C.byref(cfg)))
+    return out, cfg
+
+
+class Circuit:
+    """Built plonky2 circuit (upstream CircuitData); mirrors the reference's
+    `builder.p3_verify_proof(..); let data = builder.build::<C>(); data.prove(pw)` (src/p3/mod.rs:239-260)."""
+
+    def __init__(self, handle):
+        self._h = vp(handle)
+        self._info = None
+
+    @classmethod
+    def build_p3_verifier(cls, cfg=None, air=0):
+        cfg = cfg or P3Config.fib64()
+        h = vp()
+        _check(lib().p25_circuit_build_p3_verifier(C.byref(cfg), air, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_blob(cls, blob):
+        h = vp()
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        _check(lib().p25_circuit_import(_ptr(buf), buf.size, C.byref(h)))
+        return cls(h.value)
+
+    def to_blob(self):
+        n = sz(0)
+        _check(lib().p25_circuit_export(self._h, None, 0, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        _check(lib().p25_circuit_export(self._h, _ptr(buf), buf.size, C.byref(n)))
+        return buf.tobytes()
+
+    def close(self):
+        if self._h:
+            lib().p25_circuit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def info(self):
+        if self._info is None:
+            ci = CircuitInfo()
+            _check(lib().p25_circuit_info(self._h, C.byref(ci)))
+            self._info = ci
+        return self._info
+
+    def gate_counts(self):
+        counts = np.zeros(16, dtype=np.uint64)
+        ids = C.create_string_buffer(4096)
+        _check(lib().p25_circuit_gate_counts(self._h, _ptr(counts), 16, ids, 4096))
+        names = [s for s in ids.value.decode().split("\n") if s]
+        return {n: int(c) for n, c in zip(names, counts)}
+
+    def digest(self):
+        d = np.zeros(4, dtype=np.uint64)
+        cap = np.zeros((16, 4), dtype=np.uint64)
+        _check(lib().p25_circuit_digest(self._h, _ptr(d), _ptr(cap)))
+        return d, cap
+
+    def witness(self, inputs, seed=0):
+        inp = _u64(inputs)
+        n = 1 << int(self.info.degree_bits)
+        wires = np.zeros((int(self.info.num_wires), n), dtype=np.uint64)
+        st = i32(0)
+        _check(lib().p25_witness(self._h, _ptr(inp), seed, _ptr(wires), C.byref(st)))
+        return wires, st.value
+
+    def prove(self, inputs, seeds=None, timings=False):
+        """inputs: [n_proofs][num_inputs].  Returns (proofs [n_proofs][proof_words], statuses[, timings])."""
+        inp = _u64(inputs)
+        if inp.ndim == 1:
+            inp = inp.reshape(1, -1)
+        n = inp.shape[0]
+        assert inp.shape[1] == int(self.info.num_inputs)
+        pw = int(self.info.proof_words)
+        proofs = np.zeros((n, pw), dtype=np.uint64)
+        st = np.zeros(n, dtype=np.int32)
+        sd = _u64(seeds) if seeds is not None else None
+        tm = Timings()
+        _check(lib().p25_prove_batch(self._h, _ptr(inp), n, _ptr(sd), _ptr(proofs), pw, _ptr(st),
+                                     C.byref(tm) if timings else None))
+        return (proofs, st, tm) if timings else (proofs, st)
+
+    def prove_dev(self, d_inputs, n_proofs, d_seeds, d_proofs, proof_stride, d_status, timings=None):
+        """Device-resident batch (raw device addresses, e.g. torch tensor .data_ptr())."""
+        _check(lib().p25_prove_batch_dev(self._h, d_inputs, n_proofs, d_seeds, d_proofs, proof_stride, d_status,
+                                         C.byref(timings) if timings is not None else None))
+
+    def sync(self):
+        _check(lib().p25_circuit_sync(self._h))
+
+    def proof_to_json(self, proof):
+        p = _u64(proof)
+        n = sz(0)
+        _check(lib().p25_proof_to_json(self._h, _ptr(p), None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(lib().p25_proof_to_json(self._h, _ptr(p), buf, n.value, C.byref(n)))
+        return buf.raw[:n.value].decode()

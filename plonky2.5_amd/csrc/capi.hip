@@ -209,3 +209,245 @@ p25_status p25_lde_commit_dev(const uint64_t* d_polys, unsigned log_n, size_t n_
 }
 
 }  // extern "C"
+
+// ======================================================================================
+// circuits, proving, data formats
+// ======================================================================================
+#include "circuit_io.h"
+#include "json_io.h"
+#include "p3_circuit.h"
+#include "prover.h"
+
+struct p25_circuit {
+  p25::Circuit circuit;                       // host tables (moved into dev on first device use)
+  std::unique_ptr<p25::DeviceCircuit> dev;
+  std::unique_ptr<p25::WitnessProgram> wp_info;
+  bool moved = false;
+  const p25::Circuit& c() const { return dev ? dev->circuit() : circuit; }
+  p25::DeviceCircuit& device() {
+    if (!dev) {
+      dev.reset(new p25::DeviceCircuit(std::move(circuit)));
+      moved = true;
+    }
+    return *dev;
+  }
+};
+
+template <class F>
+static p25_status host_guarded(F&& f) {
+  try {
+    return f();
+  } catch (const p25::HipError& e) {
+    p25::g_last_error = e.what();
+    return P25_ERR_HIP;
+  } catch (const std::invalid_argument& e) {
+    p25::g_last_error = e.what();
+    return P25_ERR_INVALID_ARG;
+  } catch (const std::exception& e) {
+    p25::g_last_error = e.what();
+    return P25_ERR_INTERNAL;
+  }
+}
+
+extern "C" {
+
+p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, p25_circuit** out) {
+  return host_guarded([&]() -> p25_status {
+    if (!cfg || !out) throw std::invalid_argument("null argument");
+    if (air != P25_AIR_FIBONACCI) throw std::invalid_argument("unknown AIR");
+    if (cfg->log_quotient_degree != 0) throw std::invalid_argument("only one quotient chunk is supported (proof.rs:41-48)");
+    if (cfg->trace_width < 1 || cfg->trace_width > 64 || cfg->log_trace_height < 1 || cfg->log_trace_height > 24 ||
+        cfg->num_queries < 1 || cfg->num_queries > 1000 || cfg->degree_bits < 1 || cfg->degree_bits > cfg->log_trace_height ||
+        cfg->opening_matrix_log_max_height < 1 || cfg->opening_matrix_log_max_height > 30 || cfg->quotient_opened_len < 1 ||
+        cfg->log_blowup < 1 || cfg->log_blowup > 4 || cfg->proof_of_work_bits < 0 || cfg->proof_of_work_bits > 32)
+      throw std::invalid_argument("p25_p3_config out of range");
+    p25::P3Config pc;
+    pc.fri_config.log_blowup = cfg->log_blowup;
+    pc.fri_config.num_queries = cfg->num_queries;
+    pc.fri_config.proof_of_work_bits = cfg->proof_of_work_bits;
+    pc.log_quotient_degree = cfg->log_quotient_degree;
+    pc.log_trace_height = cfg->log_trace_height;
+    pc.trace_width = cfg->trace_width;
+    pc.opening_matrix_log_max_height = cfg->opening_matrix_log_max_height;
+    pc.opening_proof_query_openings_opened_values_length = cfg->quotient_opened_len;
+    pc.degree_bits = cfg->degree_bits;
+    p25::CircuitBuilder cb;
+    p25::FibonacciAir fib;
+    if (pc.trace_width != fib.width()) throw std::invalid_argument("Invalid Proof Shape");
+    p25::p3_verify_proof(cb, pc, fib);
+    auto* h = new p25_circuit();
+    h->circuit = cb.build();
+    *out = h;
+    return P25_OK;
+  });
+}
+
+p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out) {
+  return host_guarded([&]() -> p25_status {
+    if (!c || !len_out) throw std::invalid_argument("null argument");
+    std::vector<uint8_t> b = p25::circuit_to_blob(c->c());
+    *len_out = b.size();
+    if (buf) {
+      if (cap < b.size()) throw std::invalid_argument("buffer too small");
+      memcpy(buf, b.data(), b.size());
+    }
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_import(const uint8_t* blob, size_t len, p25_circuit** out) {
+  return host_guarded([&]() -> p25_status {
+    if (!blob || !out) throw std::invalid_argument("null argument");
+    auto* h = new p25_circuit();
+    try {
+      h->circuit = p25::circuit_from_blob(blob, len);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+    return P25_OK;
+  });
+}
+void p25_circuit_destroy(p25_circuit* c) { delete c; }
+
+p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out) {
+  return host_guarded([&]() -> p25_status {
+    if (!c || !out) throw std::invalid_argument("null argument");
+    const p25::Circuit& k = c->c();
+    memset(out, 0, sizeof(*out));
+    out->degree_bits = k.degree_bits;
+    size_t used = 0;
+    for (auto& r : k.rows) used += r.kind != p25::G_NOOP;
+    out->num_rows_used = used;
+    out->num_wires = k.cfg.num_wires;
+    out->num_routed_wires = k.cfg.num_routed_wires;
+    out->num_inputs = k.input_targets.size();
+    out->num_generators = k.generators.size();
+    out->num_gate_types = k.gates.size();
+    out->num_selectors = k.num_selectors;
+    out->num_constants_sigmas = k.constants_sigmas.size();
+    out->num_gate_constraints = k.num_gate_constraints;
+    out->proof_words = p25::make_proof_layout(k).total;
+    if (!c->wp_info) c->wp_info.reset(new p25::WitnessProgram(p25::build_witness_program(k)));
+    out->witness_levels = c->wp_info->level_start.size() - 1;
+    out->witness_slots = c->wp_info->num_slots;
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_gate_counts(const p25_circuit* c, uint64_t* counts_out, size_t cap, char* ids_out, size_t ids_cap) {
+  return host_guarded([&]() -> p25_status {
+    if (!c || !counts_out) throw std::invalid_argument("null argument");
+    const p25::Circuit& k = c->c();
+    if (cap < k.gates.size()) throw std::invalid_argument("buffer too small");
+    std::string ids;
+    for (size_t i = 0; i < k.gates.size(); i++) {
+      size_t n = 0;
+      for (auto& r : k.rows) n += r.kind == k.gates[i];
+      counts_out[i] = n;
+      ids += p25::gate_info(k.gates[i]).id;
+      ids += '\n';
+    }
+    if (ids_out && ids_cap) snprintf(ids_out, ids_cap, "%s", ids.c_str());
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_digest(p25_circuit* c, uint64_t* digest4, uint64_t* cs_cap) {
+  return guarded([&]() -> p25_status {
+    if (!c || !digest4) throw std::invalid_argument("null argument");
+    p25::DeviceCircuit& d = c->device();
+    memcpy(digest4, d.digest(), 32);
+    if (cs_cap) memcpy(cs_cap, d.cs_cap().data(), d.cs_cap().size() * 8);
+    return P25_OK;
+  });
+}
+
+static void fill_timings(p25_timings* t, const p25::PhaseTimes& pt) {
+  if (!t) return;
+  t->witness_ms = pt.witness; t->wires_commit_ms = pt.wires_commit; t->partial_products_ms = pt.zs_pp;
+  t->zs_commit_ms = pt.zs_commit; t->quotient_ms = pt.quotient; t->quotient_commit_ms = pt.quotient_commit;
+  t->openings_ms = pt.openings; t->fri_ms = pt.fri; t->total_ms = pt.total;
+}
+
+p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* seeds,
+                           uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status,
+                           p25_timings* timings) {
+  return guarded([&]() -> p25_status {
+    if (!c || !inputs || !proofs_out || !per_proof_status) throw std::invalid_argument("null argument");
+    if (!n_proofs) return P25_OK;
+    p25::PhaseTimes pt;
+    c->device().prove_batch(inputs, n_proofs, seeds, proofs_out, proof_stride_words, per_proof_status, timings ? &pt : nullptr);
+    fill_timings(timings, pt);
+    return P25_OK;
+  });
+}
+p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t n_proofs, const uint64_t* d_seeds,
+                               uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status, p25_timings* timings) {
+  return guarded([&]() -> p25_status {
+    if (!c || !d_inputs || !d_seeds || !d_proofs || !d_status) throw std::invalid_argument("null argument");
+    p25::DeviceCircuit& d = c->device();
+    if (proof_stride_words < d.layout().total) throw std::invalid_argument("proof_stride smaller than the proof");
+    p25::PhaseTimes pt;
+    d.prove_batch_dev(d_inputs, n_proofs, d_seeds, d_proofs, proof_stride_words, d_status, timings ? &pt : nullptr);
+    fill_timings(timings, pt);
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_sync(p25_circuit* c) {
+  return guarded([&]() -> p25_status {
+    if (!c) throw std::invalid_argument("null argument");
+    c->device().sync();
+    return P25_OK;
+  });
+}
+p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, uint64_t* wires_out, p25_status* proof_status) {
+  return guarded([&]() -> p25_status {
+    if (!c || !inputs || !wires_out) throw std::invalid_argument("null argument");
+    int32_t st = c->device().witness(inputs, seed, wires_out);
+    if (proof_status) *proof_status = st;
+    return P25_OK;
+  });
+}
+
+p25_status p25_p3_proof_from_json(const char* json, size_t len, uint64_t* inputs_out, size_t cap, size_t* n_out,
+                                  p25_p3_config* cfg_out) {
+  p25_status s = host_guarded([&]() -> p25_status {
+    if (!json || !n_out) throw std::invalid_argument("null argument");
+    std::vector<u64> in;
+    p25::P3Config pc;
+    p25::p3_proof_from_json(json, len, in, pc);
+    *n_out = in.size();
+    if (inputs_out) {
+      if (cap < in.size()) throw std::invalid_argument("buffer too small");
+      memcpy(inputs_out, in.data(), in.size() * 8);
+    }
+    if (cfg_out) {
+      cfg_out->log_blowup = pc.fri_config.log_blowup;
+      cfg_out->num_queries = pc.fri_config.num_queries;
+      cfg_out->proof_of_work_bits = pc.fri_config.proof_of_work_bits;
+      cfg_out->log_quotient_degree = pc.log_quotient_degree;
+      cfg_out->log_trace_height = pc.log_trace_height;
+      cfg_out->trace_width = pc.trace_width;
+      cfg_out->opening_matrix_log_max_height = pc.opening_matrix_log_max_height;
+      cfg_out->quotient_opened_len = pc.opening_proof_query_openings_opened_values_length;
+      cfg_out->degree_bits = pc.degree_bits;
+    }
+    return P25_OK;
+  });
+  if (s == P25_ERR_INVALID_ARG && p25::g_last_error.rfind("p3 proof JSON", 0) == 0) return P25_ERR_PARSE;
+  return s;
+}
+p25_status p25_proof_to_json(p25_circuit* c, const uint64_t* proof, char* buf, size_t cap, size_t* len_out) {
+  return host_guarded([&]() -> p25_status {
+    if (!c || !proof || !len_out) throw std::invalid_argument("null argument");
+    const p25::Circuit& k = c->c();
+    std::string s = p25::proof_to_json(k, p25::make_proof_layout(k), proof);
+    *len_out = s.size();
+    if (buf) {
+      if (cap < s.size()) throw std::invalid_argument("buffer too small");
+      memcpy(buf, s.data(), s.size());
+    }
+    return P25_OK;
+  });
+}
+
+}  // extern "C"

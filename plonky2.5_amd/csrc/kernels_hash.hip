@@ -111,4 +111,16 @@ u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t 
   return cur;
 }
 
+// Same as launch_merkle_tree but the leaf digests (level 0) are already in d_tree.
+void launch_tree_from_digests(u64* d_tree, size_t n_leaves, unsigned cap_height, hipStream_t st) {
+  u64* cur = d_tree;
+  size_t m = n_leaves;
+  while (m > ((size_t)1 << cap_height)) {
+    u64* nxt = cur + 4 * m;
+    m >>= 1;
+    hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, cur, nxt, m);
+    cur = nxt;
+  }
+}
+
 }  // namespace p25

@@ -1,0 +1,315 @@
+// Quotient-polynomial evaluation on the LDE coset: one lane per coset point.
+//
+// Replaces upstream plonky2 @ 3de92d9 prover.rs `compute_quotient_polys` +
+// vanishing_poly.rs `eval_vanishing_poly_base_batch` (reached from
+// /root/reference/src/p3/mod.rs:260) and the gate callbacks it invokes -- the reference's own
+//   Poseidon2Gate::eval_unfiltered_base_one          src/common/poseidon2/poseidon2_gate.rs:233-310
+//   U32ArithmeticGate::eval_unfiltered_base_packed   src/common/u32/gates/arithmetic_u32.rs:303-366
+//   U32InterleaveGate::eval_unfiltered_base_packed   src/common/u32/gates/interleave_u32.rs:250-287
+//   UninterleaveToU32Gate::eval_unfiltered_base_packed  src/common/u32/gates/uninterleave_to_u32.rs:285-335
+// plus upstream's Noop / Constant / PublicInput / BaseSum<2> / Arithmetic / MulExtension /
+// Exponentiation gates.
+//
+// Data layout: every committed matrix is column-major at bit-reversed leaf positions, so lane p of a
+// wave reads word p of each column: 242 fully coalesced column reads per point, no transposes.
+// Instead of materialising the <=134 per-gate constraint slots and reducing them afterwards
+// (upstream's reduce_with_powers_multi), each gate folds its constraints into the two alpha-power
+// sums as they are produced (alpha^j from an LDS table), and the gate's filter multiplies the
+// folded sums once:   sum_j alpha^j sum_g f_g c_{g,j} = sum_g f_g sum_j alpha^j c_{g,j}.
+#include "kernels.h"
+#include "poseidon2.h"
+#include "prover_kernels.h"
+
+namespace p25 {
+
+namespace {
+
+struct Ctx {
+  const u64* wires;  // column base for this point: wires[col * big]
+  size_t big;
+  const u64* ap0;    // alpha_0^j, alpha_1^j tables (LDS)
+  const u64* ap1;
+  u64 acc0, acc1;
+  __device__ __forceinline__ u64 w(int col) const { return wires[(size_t)col * big]; }
+  __device__ __forceinline__ void at(int j, u64 c) {
+    acc0 = gl::add(acc0, gl::mul(c, ap0[j]));
+    acc1 = gl::add(acc1, gl::mul(c, ap1[j]));
+  }
+};
+
+__device__ void gate_constant(Ctx& cx, u64 k0, u64 k1) {
+  cx.at(0, gl::sub(k0, cx.w(0)));
+  cx.at(1, gl::sub(k1, cx.w(1)));
+}
+__device__ void gate_public_input(Ctx& cx) {
+  // public-inputs hash of the empty input list is [0,0,0,0]
+  for (int i = 0; i < 4; i++) cx.at(i, cx.w(i));
+}
+__device__ void gate_base_sum(Ctx& cx) {
+  u64 sum = 0, pw = 1;
+  for (int i = 0; i < BASE_SUM_LIMBS; i++) {
+    u64 l = cx.w(1 + i);
+    sum = gl::add(sum, gl::mul(l, pw));
+    pw = gl::add(pw, pw);
+    cx.at(1 + i, gl::mul(l, gl::sub(l, 1)));
+  }
+  cx.at(0, gl::sub(sum, cx.w(0)));
+}
+__device__ void gate_arithmetic(Ctx& cx, u64 k0, u64 k1) {
+  for (int i = 0; i < 20; i++) {
+    u64 m0 = cx.w(4 * i), m1 = cx.w(4 * i + 1), ad = cx.w(4 * i + 2), o = cx.w(4 * i + 3);
+    u64 comp = gl::add(gl::mul(gl::mul(m0, m1), k0), gl::mul(ad, k1));
+    cx.at(i, gl::sub(o, comp));
+  }
+}
+__device__ void gate_mul_ext(Ctx& cx, u64 k0) {
+  for (int i = 0; i < 13; i++) {
+    gl::E2 a{cx.w(6 * i), cx.w(6 * i + 1)}, b{cx.w(6 * i + 2), cx.w(6 * i + 3)};
+    gl::E2 p = gl::mul(gl::mul(a, b), k0);
+    cx.at(2 * i, gl::sub(cx.w(6 * i + 4), p.a));
+    cx.at(2 * i + 1, gl::sub(cx.w(6 * i + 5), p.b));
+  }
+}
+__device__ void gate_exponentiation(Ctx& cx) {
+  const u64 base = cx.w(0);
+  u64 prev_inter = 1;
+  for (int i = 0; i < EXP_POWER_BITS; i++) {
+    u64 prev = i == 0 ? 1 : gl::mul(prev_inter, prev_inter);
+    u64 bit = cx.w(1 + (EXP_POWER_BITS - 1 - i));
+    u64 sel = gl::add(gl::mul(bit, base), gl::sub(1, bit));
+    u64 inter = cx.w(2 + EXP_POWER_BITS + i);
+    cx.at(i, gl::sub(gl::mul(prev, sel), inter));
+    prev_inter = inter;
+  }
+  cx.at(EXP_POWER_BITS, gl::sub(cx.w(1 + EXP_POWER_BITS), prev_inter));
+}
+__device__ void gate_u32_arithmetic(Ctx& cx) {
+  for (int i = 0; i < 3; i++) {
+    const int cb = 36 * i;
+    u64 m0 = cx.w(6 * i), m1 = cx.w(6 * i + 1), ad = cx.w(6 * i + 2);
+    u64 lo = cx.w(6 * i + 3), hi = cx.w(6 * i + 4), inv = cx.w(6 * i + 5);
+    u64 computed = gl::add(gl::mul(m0, m1), ad);
+    u64 diff = gl::sub(0xFFFFFFFFull, hi);
+    u64 hi_not_max = gl::sub(gl::mul(inv, diff), 1);
+    cx.at(cb, gl::mul(hi_not_max, lo));
+    u64 combined = gl::add(gl::mul(hi, (u64)1 << 32), lo);
+    cx.at(cb + 1, gl::sub(combined, computed));
+    u64 cl = 0, ch = 0;
+    for (int j = 31; j >= 0; j--) {
+      u64 l = cx.w(18 + 32 * i + j);
+      u64 pr = gl::mul(gl::mul(l, gl::sub(l, 1)), gl::mul(gl::sub(l, 2), gl::sub(l, 3)));
+      cx.at(cb + 2 + (31 - j), pr);
+      if (j < 16) {
+        cl = gl::add(gl::add(cl, cl), gl::add(cl, cl));
+        cl = gl::add(cl, l);
+      } else {
+        ch = gl::add(gl::add(ch, ch), gl::add(ch, ch));
+        ch = gl::add(ch, l);
+      }
+    }
+    cx.at(cb + 34, gl::sub(cl, lo));
+    cx.at(cb + 35, gl::sub(ch, hi));
+  }
+}
+__device__ void gate_u32_interleave(Ctx& cx) {
+  for (int i = 0; i < 3; i++) {
+    const int cb = 34 * i;
+    u64 x = 0, xi = 0;
+    for (int b = 0; b < 32; b++) {
+      u64 bit = cx.w(6 + 32 * i + b);
+      x = gl::add(gl::add(x, x), bit);
+      u64 x2 = gl::add(xi, xi);
+      xi = gl::add(gl::add(x2, x2), bit);
+      cx.at(cb + 2 + b, gl::mul(bit, gl::sub(bit, 1)));
+    }
+    cx.at(cb, gl::sub(x, cx.w(2 * i)));
+    cx.at(cb + 1, gl::sub(xi, cx.w(2 * i + 1)));
+  }
+}
+__device__ void gate_u32_uninterleave(Ctx& cx) {
+  for (int i = 0; i < 2; i++) {
+    const int cb = 67 * i;
+    u64 x = 0, ev = 0, od = 0;
+    for (int j = 0; j < 32; j++) {
+      u64 be = cx.w(6 + 64 * i + 2 * j), bo = cx.w(6 + 64 * i + 2 * j + 1);
+      u64 x2 = gl::add(x, x);
+      x = gl::add(gl::add(gl::add(x2, x2), gl::add(be, be)), bo);
+      ev = gl::add(gl::add(ev, ev), be);
+      od = gl::add(gl::add(od, od), bo);
+      cx.at(cb + 3 + 2 * j, gl::mul(be, gl::sub(be, 1)));
+      cx.at(cb + 3 + 2 * j + 1, gl::mul(bo, gl::sub(bo, 1)));
+    }
+    cx.at(cb, gl::sub(x, cx.w(3 * i)));
+    cx.at(cb + 1, gl::sub(ev, cx.w(3 * i + 1)));
+    cx.at(cb + 2, gl::sub(od, cx.w(3 * i + 2)));
+  }
+}
+// poseidon2_gate.rs:233-310
+__device__ void gate_poseidon2(Ctx& cx) {
+  using namespace poseidon2;
+  int nc = 0;
+  u64 swap = cx.w(24);
+  cx.at(nc++, gl::mul(swap, gl::sub(swap, 1)));
+  u64 st[12];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u64 lhs = cx.w(i), rhs = cx.w(i + 4), delta = cx.w(25 + i);
+    cx.at(nc++, gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+    st[i] = gl::add(lhs, delta);
+    st[i + 4] = gl::sub(rhs, delta);
+  }
+#pragma unroll
+  for (int i = 8; i < 12; i++) st[i] = cx.w(i);
+  matmul_external(st);
+  for (int r = 0; r < ROUND_F_BEGIN; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2_RC[12 * r + i]);
+    if (r != 0) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        u64 sb = cx.w(29 + 12 * (r - 1) + i);
+        cx.at(nc++, gl::sub(st[i], sb));
+        st[i] = sb;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = sbox(st[i]);
+    matmul_external(st);
+  }
+  for (int r = 0; r < ROUND_P; r++) {
+    st[0] = gl::add(st[0], P2_RC_MID[r]);
+    u64 sb = cx.w(65 + r);
+    cx.at(nc++, gl::sub(st[0], sb));
+    st[0] = sbox(sb);
+    matmul_internal(st);
+  }
+  for (int r = ROUND_F_BEGIN; r < ROUND_F_END; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2_RC[12 * r + i]);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      u64 sb = cx.w(87 + 12 * (r - ROUND_F_BEGIN) + i);
+      cx.at(nc++, gl::sub(st[i], sb));
+      st[i] = sb;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = sbox(st[i]);
+    matmul_external(st);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) cx.at(nc++, gl::sub(st[i], cx.w(12 + i)));
+}
+
+}  // namespace
+
+// alpha_pows[c][j] = alpha_c^j, j < ALPHA_POWS
+__global__ void k_alpha_pows(const u64* __restrict__ chal, u64* __restrict__ out) {
+  int c = blockIdx.x, j = threadIdx.x;
+  if (j < ALPHA_POWS) out[c * ALPHA_POWS + j] = gl::pow(chal[CH_ALPHAS + c], (u64)j);
+}
+void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
+  hipLaunchKernelGGL(k_alpha_pows, dim3(2), dim3(ALPHA_POWS), 0, st, d_chal, d_alpha_pows);
+}
+
+__global__ __launch_bounds__(128) void k_quotient(QuotientArgs a) {
+  __shared__ u64 ap[2 * ALPHA_POWS];
+  for (int i = threadIdx.x; i < 2 * ALPHA_POWS; i += blockDim.x) ap[i] = a.alpha_pows[i];
+  __syncthreads();
+  const uint32_t lde_bits = a.degree_bits + a.rate_bits;
+  const size_t big = (size_t)1 << lde_bits;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // bit-reversed position
+  if (p >= big) return;
+  const uint32_t i_nat = gl::bitrev((u32)p, lde_bits);
+  const u64 x = gl::mul(gl::GENERATOR, a.pow_big[i_nat]);
+  const uint32_t rate_mask = (1u << a.rate_bits) - 1;
+  const u64 zhx = a.zh[i_nat & rate_mask], zhi = a.zh_inv[i_nat & rate_mask];
+  // position of the "next row" point: natural index + 2^rate_bits
+  const uint32_t i_next = (i_nat + (1u << a.rate_bits)) & (uint32_t)(big - 1);
+  const size_t p_next = gl::bitrev(i_next, lde_bits);
+
+  const int NC = 2, NP = (int)a.num_partial_products, RW = (int)a.num_routed;
+  const int nch = NP + 1, per = (RW + nch - 1) / nch;
+  const u64* cs = a.cs_lde + p;
+  const u64* wr = a.wires_lde + p;
+  const u64* zs = a.zs_lde + p;
+  const int n_consts = (int)a.num_selectors;  // selectors first, then the 2 gate constants
+
+  u64 res[2] = {0, 0};
+  // --- L_0(x) (Z_c(x) - 1): terms 0..NC
+  {
+    u64 n_field = (u64)1 << a.degree_bits;
+    u64 l0 = gl::mul(zhx, gl::inv(gl::mul(n_field, gl::sub(x, 1))));
+    for (int c = 0; c < NC; c++) {
+      u64 t = gl::mul(l0, gl::sub(zs[(size_t)c * big], 1));
+      res[0] = gl::add(res[0], gl::mul(t, ap[c]));
+      res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + c]));
+    }
+  }
+  // --- partial-product checks: terms NC + c*nch + k
+  for (int c = 0; c < NC; c++) {
+    const u64 beta = a.chal[CH_BETAS + c], gamma = a.chal[CH_GAMMAS + c];
+    for (int k = 0; k < nch; k++) {
+      u64 np = 1, dp = 1;
+      for (int j = k * per; j < (k + 1) * per && j < RW; j++) {
+        u64 w = wr[(size_t)j * big];
+        u64 s_id = gl::mul(a.k_is[j], x);
+        u64 sg = cs[(size_t)(n_consts + 2 + j) * big];
+        np = gl::mul(np, gl::add(gl::add(w, gl::mul(beta, s_id)), gamma));
+        dp = gl::mul(dp, gl::add(gl::add(w, gl::mul(beta, sg)), gamma));
+      }
+      u64 prev = k == 0 ? zs[(size_t)c * big] : zs[(size_t)(NC + c * NP + k - 1) * big];
+      u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zs[(size_t)(NC + c * NP + k) * big];
+      u64 t = gl::sub(gl::mul(prev, np), gl::mul(next, dp));
+      int ti = NC + c * nch + k;
+      res[0] = gl::add(res[0], gl::mul(t, ap[ti]));
+      res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + ti]));
+    }
+  }
+  // --- gate constraints, terms NC*(1+nch) + j
+  {
+    Ctx cx;
+    cx.wires = wr;
+    cx.big = big;
+    cx.ap0 = ap;
+    cx.ap1 = ap + ALPHA_POWS;
+    const u64 k0 = cs[(size_t)n_consts * big], k1 = cs[(size_t)(n_consts + 1) * big];
+    u64 g0 = 0, g1 = 0;
+    for (uint32_t gi = 0; gi < a.n_gates; gi++) {
+      const GateEntry ge = a.gates[gi];
+      const u64 s = cs[(size_t)ge.selector_index * big];
+      u64 filter = 1;
+      for (uint32_t k = ge.group_start; k < ge.group_end; k++)
+        if (k != gi) filter = gl::mul(filter, gl::sub((u64)k, s));
+      if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
+      cx.acc0 = 0;
+      cx.acc1 = 0;
+      switch (ge.kind) {
+        case G_CONSTANT: gate_constant(cx, k0, k1); break;
+        case G_PUBLIC_INPUT: gate_public_input(cx); break;
+        case G_BASE_SUM: gate_base_sum(cx); break;
+        case G_U32_INTERLEAVE: gate_u32_interleave(cx); break;
+        case G_U32_UNINTERLEAVE: gate_u32_uninterleave(cx); break;
+        case G_ARITHMETIC: gate_arithmetic(cx, k0, k1); break;
+        case G_MUL_EXT: gate_mul_ext(cx, k0); break;
+        case G_EXPONENTIATION: gate_exponentiation(cx); break;
+        case G_U32_ARITHMETIC: gate_u32_arithmetic(cx); break;
+        case G_POSEIDON2: gate_poseidon2(cx); break;
+        default: break;  // NoopGate: no constraints
+      }
+      g0 = gl::add(g0, gl::mul(filter, cx.acc0));
+      g1 = gl::add(g1, gl::mul(filter, cx.acc1));
+    }
+    const int off = NC * (1 + nch);
+    res[0] = gl::add(res[0], gl::mul(g0, ap[off]));
+    res[1] = gl::add(res[1], gl::mul(g1, ap[ALPHA_POWS + off]));
+  }
+  a.out[p] = gl::mul(res[0], zhi);
+  a.out[big + p] = gl::mul(res[1], zhi);
+}
+
+void launch_quotient(const QuotientArgs& a, hipStream_t st) {
+  const size_t big = (size_t)1 << (a.degree_bits + a.rate_bits);
+  hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
+}
+
+}  // namespace p25

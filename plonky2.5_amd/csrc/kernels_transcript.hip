@@ -1,0 +1,151 @@
+// Device-resident Fiat-Shamir transcript and proof-of-work search.
+//
+// Replaces upstream plonky2 @ 3de92d9 iop/challenger.rs `Challenger<F, PoseidonHash>` and
+// fri/prover.rs `fri_proof_of_work` (reached from /root/reference/src/p3/mod.rs:260).
+// Semantics: duplex sponge, rate 8; `observe` buffers inputs and
+// duplexes at 8; `get_challenge` duplexes if inputs are pending or no outputs remain, then pops
+// from the END of the 8-word output buffer.  PoW: the smallest u64 witness w such that observing
+// w and squeezing yields a challenge with >= pow_bits leading zero bits.
+//
+// The transcript is strictly sequential, so it is latency- not throughput-bound: one wavefront runs
+// it, with sponge lane r living in wavefront lane r and the Poseidon permutation computed
+// cooperatively -- S-boxes in parallel across 12 lanes, the circulant MDS layer as 12 cross-lane
+// reads (ds_bpermute) + multiply-adds per lane.  That cuts a permutation's dependent chain from
+// ~1.5k modular multiplies (one lane doing all 12 state words) to ~30 x (4 + MDS), i.e. a few us.
+#include "kernels.h"
+#include "poseidon.h"
+#include "prover_kernels.h"
+
+namespace p25 {
+
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+  u32 lo = (u32)v, hi = (u32)(v >> 32);
+  lo = __shfl(lo, src);
+  hi = __shfl(hi, src);
+  return ((u64)hi << 32) | lo;
+}
+
+// lane r < 12 holds state word r (canonical); returns the permuted word (canonical)
+__device__ u64 coop_permute(u64 s, int lane) {
+  const int r = lane < 12 ? lane : 0;
+  for (int rd = 0; rd < poseidon::N_ROUNDS; rd++) {
+    u64 t = poseidon::add_rc(s, poseidon::RC[12 * rd + r]);
+    bool full = rd < poseidon::HALF_FULL || rd >= poseidon::HALF_FULL + poseidon::N_PARTIAL;
+    u64 sb = poseidon::sbox(t);
+    s = (full || r == 0) ? sb : t;
+    // MDS: out[r] = sum_i s[(i + r) % 12] * CIRC[i] (+ 8 * s[0] for r == 0)
+    u32 lo = (u32)s, hi = (u32)(s >> 32);
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      int src = i + r;
+      src = src >= 12 ? src - 12 : src;
+      al += (u64)__shfl(lo, src) * poseidon::MDS_CIRC[i];
+      ah += (u64)__shfl(hi, src) * poseidon::MDS_CIRC[i];
+    }
+    if (r == 0) {
+      al += (u64)lo * poseidon::MDS_DIAG0;
+      ah += (u64)hi * poseidon::MDS_DIAG0;
+    }
+    u64 l64 = al + (ah << 32);
+    u32 h32 = (u32)(ah >> 32) + (l64 < al ? 1u : 0u);
+    s = gl::reduce96(l64, h32);
+  }
+  return gl::canon(s);
+}
+
+struct Sponge {
+  u64 state, inb, outb;  // per-lane words (state: lanes 0..11, buffers: lanes 0..7)
+  uint32_t n_in, n_out;  // wave-uniform
+  int lane;
+  __device__ void duplex() {
+    if (lane < (int)n_in) state = inb;
+    n_in = 0;
+    state = coop_permute(state, lane);
+    outb = state;
+    n_out = 8;
+  }
+  __device__ void observe(u64 x) {
+    n_out = 0;
+    if (lane == (int)n_in) inb = x;
+    n_in++;
+    if (n_in == 8) duplex();
+  }
+  __device__ u64 challenge() {
+    if (n_in > 0 || n_out == 0) duplex();
+    u64 v = shfl64(outb, (int)n_out - 1);
+    n_out--;
+    return v;
+  }
+};
+
+__global__ __launch_bounds__(64) void k_transcript(Transcript* tr, int init, const u64* __restrict__ obs,
+                                                   uint32_t n_obs, u64* __restrict__ chal_out, uint32_t n_chal) {
+  const int lane = threadIdx.x;
+  Sponge sp;
+  sp.lane = lane;
+  if (init) {
+    sp.state = 0;
+    sp.inb = 0;
+    sp.outb = 0;
+    sp.n_in = 0;
+    sp.n_out = 0;
+  } else {
+    sp.state = lane < 12 ? tr->state[lane] : 0;
+    sp.inb = lane < 8 ? tr->in[lane] : 0;
+    sp.outb = lane < 8 ? tr->out[lane] : 0;
+    sp.n_in = tr->n_in;
+    sp.n_out = tr->n_out;
+  }
+  for (uint32_t i = 0; i < n_obs; i++) sp.observe(obs[i]);
+  for (uint32_t i = 0; i < n_chal; i++) {
+    u64 c = sp.challenge();
+    if (lane == 0) chal_out[i] = c;
+  }
+  if (lane < 12) tr->state[lane] = sp.state;
+  if (lane < 8) {
+    tr->in[lane] = sp.inb;
+    tr->out[lane] = sp.outb;
+  }
+  if (lane == 0) {
+    tr->n_in = sp.n_in;
+    tr->n_out = sp.n_out;
+  }
+}
+
+void launch_transcript(Transcript* d_tr, int init, const u64* d_obs, uint32_t n_obs, u64* d_chal_out,
+                       uint32_t n_chal, hipStream_t st) {
+  hipLaunchKernelGGL(k_transcript, dim3(1), dim3(64), 0, st, d_tr, init, d_obs, n_obs, d_chal_out, n_chal);
+}
+
+// One candidate per lane: result = min over candidates in [base, base + count) that satisfy the PoW
+// (UINT64_MAX if none).  Skips the whole range if a smaller witness was already found.
+__global__ __launch_bounds__(256) void k_pow_search(const Transcript* __restrict__ tr, int pow_bits, u64 base,
+                                                    u64* __restrict__ result) {
+  if (*result < base) return;
+  u64 cand = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = tr->state[i];
+  const uint32_t pos = tr->n_in;
+  for (uint32_t i = 0; i < pos; i++) s[i] = tr->in[i];
+  // witness goes to sponge position `pos` (an invariant of the challenger: pos < 8)
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if ((uint32_t)i == pos) s[i] = cand;
+  poseidon::permute(s);
+  if (__clzll((long long)s[7]) >= pow_bits) atomicMin((unsigned long long*)result, (unsigned long long)cand);
+}
+__global__ void k_pow_init(u64* result) { *result = ~0ull; }
+
+void launch_pow_search(const Transcript* d_tr, int pow_bits, u64* d_result, hipStream_t st) {
+  hipLaunchKernelGGL(k_pow_init, dim3(1), dim3(1), 0, st, d_result);
+  // expected number of candidates 2^pow_bits; each window is skipped once a witness is known.
+  const u64 window = (u64)1 << 20;
+  int n_windows = pow_bits <= 16 ? 4 : (pow_bits <= 20 ? 32 : 256);
+  for (int w = 0; w < n_windows; w++)
+    hipLaunchKernelGGL(k_pow_search, dim3((unsigned)(window / 256)), dim3(256), 0, st, d_tr, pow_bits,
+                       (u64)w * window, d_result);
+}
+
+}  // namespace p25

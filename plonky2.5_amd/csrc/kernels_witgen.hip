@@ -1,0 +1,231 @@
+// Witness generation on the GPU: one launch per level of the static schedule
+// (witness_program.h), one lane per (generator, proof).  Values live in a slot-major array
+// vals[slot * batch_stride + proof], so lanes of consecutive proofs are coalesced.
+//
+// Generator bodies restate the reference's `SimpleGenerator::run_once` implementations:
+//   Poseidon2Generator           /root/reference/src/common/poseidon2/poseidon2_gate.rs:447-523
+//   U32ArithmeticGenerator       src/common/u32/gates/arithmetic_u32.rs:389-439
+//   U32InterleaveGenerator       src/common/u32/gates/interleave_u32.rs:305-334
+//   UninterleaveToU32Generator   src/common/u32/gates/uninterleave_to_u32.rs:353-390
+// and upstream plonky2 @ 3de92d9's ConstantGenerator, RandomValueGenerator (made deterministic:
+// SplitMix64 of a per-proof seed), ArithmeticBaseGenerator, MulExtensionGenerator,
+// QuotientGeneratorExtension, BaseSplitGenerator<2>, WireSplitGenerator, BaseSumGenerator<2>,
+// LowHighGenerator, ExponentiationGenerator.
+#include "kernels.h"
+#include "poseidon2.h"
+#include "prover_kernels.h"
+
+namespace p25 {
+
+__device__ __forceinline__ u64 random_fill(u64 seed, u64 k) {
+  u64 z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return z >= gl::P ? z - gl::P : z;
+}
+
+struct Emitter {
+  u64* vals;
+  const uint32_t* outs;
+  size_t B;
+  uint32_t p;
+  uint32_t* status;
+  __device__ __forceinline__ void operator()(int k, u64 v) const {
+    uint32_t a = outs[k];
+    size_t idx = (size_t)(a & 0x7FFFFFFFu) * B + p;
+    if (a & WIT_CHECK_FLAG) {
+      if (vals[idx] != v) status[p] = 4;  // P25_ERR_WITNESS_CONFLICT
+    } else {
+      vals[idx] = v;
+    }
+  }
+};
+struct P2Tracer {
+  const Emitter& em;
+  __device__ __forceinline__ void operator()(int i, u64 v) const { em(4 + i, v); }
+};
+
+__global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__ gens,
+                                                      const uint32_t* __restrict__ args, uint32_t g_begin,
+                                                      uint32_t g_count, u64* __restrict__ vals, size_t B,
+                                                      uint32_t n_proofs, const u64* __restrict__ seeds,
+                                                      uint32_t* __restrict__ status) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)g_count * n_proofs) return;
+  const uint32_t gi = g_begin + (uint32_t)(idx / n_proofs);
+  const uint32_t p = (uint32_t)(idx % n_proofs);
+  const WitGen g = gens[gi];
+  const uint32_t* dep = args + g.arg_off;
+  Emitter emit{vals, dep + g.n_deps, B, p, status};
+  auto d = [&](int i) -> u64 { return vals[(size_t)dep[i] * B + p]; };
+  switch (g.kind) {
+    case GEN_CONSTANT:
+      emit(0, g.c0);
+      break;
+    case GEN_RANDOM:
+      emit(0, random_fill(seeds[p], g.aux));
+      break;
+    case GEN_ARITHMETIC:
+      emit(0, gl::add(gl::mul(gl::mul(d(0), d(1)), g.c0), gl::mul(d(2), g.c1)));
+      break;
+    case GEN_MUL_EXT: {
+      gl::E2 r = gl::mul(gl::mul(gl::E2{d(0), d(1)}, gl::E2{d(2), d(3)}), g.c0);
+      emit(0, r.a);
+      emit(1, r.b);
+      break;
+    }
+    case GEN_QUOTIENT_EXT: {
+      gl::E2 r = gl::mul(gl::E2{d(0), d(1)}, gl::inv(gl::E2{d(2), d(3)}));
+      emit(0, r.a);
+      emit(1, r.b);
+      break;
+    }
+    case GEN_BASE_SPLIT: {
+      u64 s = d(0);
+      for (int i = 0; i < g.n_outs; i++) {
+        emit(i, s & 1);
+        s >>= 1;
+      }
+      break;
+    }
+    case GEN_WIRE_SPLIT: {
+      u64 v = d(0);
+      for (int i = 0; i < g.n_outs; i++) {
+        emit(i, v & (((u64)1 << 63) - 1));
+        v >>= 63;
+      }
+      break;
+    }
+    case GEN_BASE_SUM: {
+      u64 s = 0;
+      for (int i = (int)g.n_deps - 1; i >= 0; i--) s = gl::add(gl::add(s, s), d(i) & 1);
+      emit(0, s);
+      break;
+    }
+    case GEN_LOW_HIGH: {
+      u64 v = d(0);
+      emit(0, v & (((u64)1 << g.aux) - 1));
+      emit(1, v >> g.aux);
+      break;
+    }
+    case GEN_EXPONENTIATION: {
+      u64 base = d(0);
+      int nb = (int)g.n_deps - 1;
+      u64 cur = 1;
+      for (int i = 0; i < nb; i++) {
+        u64 prev = i == 0 ? 1 : gl::mul(cur, cur);
+        u64 bit = d(1 + (nb - 1 - i));
+        cur = bit ? gl::mul(prev, base) : prev;
+        emit(i, cur);
+      }
+      emit(nb, cur);
+      break;
+    }
+    case GEN_POSEIDON2: {
+      u64 st[12];
+#pragma unroll
+      for (int i = 0; i < 12; i++) st[i] = d(i);
+      u64 swap = d(12);
+#pragma unroll
+      for (int i = 0; i < 4; i++) emit(i, gl::mul(swap, gl::sub(st[i + 4], st[i])));
+      if (swap == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          u64 t = st[i];
+          st[i] = st[i + 4];
+          st[i + 4] = t;
+        }
+      }
+      P2Tracer tr{emit};
+      poseidon2::permute_impl(st, tr);
+#pragma unroll
+      for (int i = 0; i < 12; i++) emit(4 + 106 + i, st[i]);
+      break;
+    }
+    case GEN_U32_ARITHMETIC: {
+      u64 o = gl::add(gl::mul(d(0), d(1)), d(2));
+      u64 hi = o >> 32, lo = o & 0xFFFFFFFFull;
+      emit(0, lo);
+      emit(1, hi);
+      u64 diff = 0xFFFFFFFFull - hi;
+      emit(2, diff == 0 ? 0 : gl::inv(diff));
+      for (int j = 0; j < 32; j++) {
+        emit(3 + j, o & 3);
+        o >>= 2;
+      }
+      break;
+    }
+    case GEN_U32_INTERLEAVE: {
+      u64 x = d(0);
+      u64 xi = 0;
+      for (int i = 0; i < 32; i++) {
+        u64 bit = (x >> (31 - i)) & 1;
+        emit(i, bit);
+        xi += bit << (2 * (31 - i));
+      }
+      emit(32, xi);
+      break;
+    }
+    case GEN_U32_UNINTERLEAVE: {
+      u64 x = d(0);
+      u64 ev = 0, od = 0;
+      for (int j = 0; j < 32; j++) {
+        int shift = 2 * (31 - j);
+        u64 e = (x >> (shift + 1)) & 1, o = (x >> shift) & 1;
+        emit(2 * j, e);
+        emit(2 * j + 1, o);
+        ev += e << (31 - j);
+        od += o << (31 - j);
+      }
+      emit(64, ev);
+      emit(65, od);
+      break;
+    }
+    default:
+      status[p] = 7;
+  }
+}
+
+// vals[slot 0] = 0; vals[input_slots[i]] = inputs[p][i]
+__global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, const uint32_t* __restrict__ input_slots,
+                                    uint32_t n_inputs, u64* __restrict__ vals, size_t B, uint32_t n_proofs) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)(n_inputs + 1) * n_proofs) return;
+  uint32_t i = (uint32_t)(idx / n_proofs), p = (uint32_t)(idx % n_proofs);
+  if (i == n_inputs)
+    vals[p] = 0;
+  else
+    vals[(size_t)input_slots[i] * B + p] = inputs[(size_t)p * n_inputs + i];
+}
+
+// wires[col][row] (column-major, natural row order) for one proof of the batch
+__global__ void k_witgen_fill_wires(const u64* __restrict__ vals, size_t B, uint32_t p,
+                                    const uint32_t* __restrict__ wire_slot_cm, size_t n_elems,
+                                    u64* __restrict__ wires) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_elems) return;
+  wires[e] = vals[(size_t)wire_slot_cm[e] * B + p];
+}
+
+void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u64* d_seeds, u64* d_vals,
+                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st) {
+  size_t tot = (size_t)(wp.n_inputs + 1) * n_proofs;
+  hipLaunchKernelGGL(k_witgen_set_inputs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_inputs,
+                     wp.d_input_slots, wp.n_inputs, d_vals, B, n_proofs);
+  for (size_t l = 0; l + 1 < wp.level_start.size(); l++) {
+    uint32_t b = wp.level_start[l], cnt = wp.level_start[l + 1] - b;
+    if (!cnt) continue;
+    size_t th = (size_t)cnt * n_proofs;
+    hipLaunchKernelGGL(k_witgen_level, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, wp.d_gens, wp.d_args,
+                       b, cnt, d_vals, B, n_proofs, d_seeds, d_status);
+  }
+}
+void launch_fill_wires(const DeviceWitnessProgram& wp, const u64* d_vals, size_t B, uint32_t p, u64* d_wires,
+                       hipStream_t st) {
+  size_t ne = wp.n_wire_elems;
+  hipLaunchKernelGGL(k_witgen_fill_wires, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, d_vals, B, p,
+                     wp.d_wire_slot_cm, ne, d_wires);
+}
+
+}  // namespace p25

@@ -66,16 +66,20 @@ GL_HD void matmul_internal(u64 s[WIDTH]) {
   for (int i = 0; i < WIDTH; i++) s[i] = gl::add(gl::mul(s[i], P2_MAT_DIAG_M_1[i] - 1), sum);
 }
 
-// Canonical in/out.  If TRACE, writes the S-box inputs the Poseidon2Gate stores as wires.
-template <bool TRACE>
-GL_HD void permute_impl(u64 s[WIDTH], u64* trace) {
+// Canonical in/out.  `tr(i, v)` receives the S-box inputs the Poseidon2Gate stores as wires
+// (trace layout above); NoTrace ignores them.
+struct NoTrace {
+  GL_HD void operator()(int, u64) const {}
+};
+template <class Tracer>
+GL_HD void permute_impl(u64 s[WIDTH], Tracer& tr) {
   matmul_external(s);
   for (int r = 0; r < ROUND_F_BEGIN; r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = gl::add(s[i], P2_RC[12 * r + i]);
-    if (TRACE && r != 0) {
+    if (r != 0) {
 #pragma unroll
-      for (int i = 0; i < WIDTH; i++) trace[12 * (r - 1) + i] = s[i];
+      for (int i = 0; i < WIDTH; i++) tr(12 * (r - 1) + i, s[i]);
     }
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
@@ -83,23 +87,24 @@ GL_HD void permute_impl(u64 s[WIDTH], u64* trace) {
   }
   for (int r = 0; r < ROUND_P; r++) {
     s[0] = gl::add(s[0], P2_RC_MID[r]);
-    if (TRACE) trace[36 + r] = s[0];
+    tr(36 + r, s[0]);
     s[0] = sbox(s[0]);
     matmul_internal(s);
   }
   for (int r = ROUND_F_BEGIN; r < ROUND_F_END; r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = gl::add(s[i], P2_RC[12 * r + i]);
-    if (TRACE) {
 #pragma unroll
-      for (int i = 0; i < WIDTH; i++) trace[58 + 12 * (r - ROUND_F_BEGIN) + i] = s[i];
-    }
+    for (int i = 0; i < WIDTH; i++) tr(58 + 12 * (r - ROUND_F_BEGIN) + i, s[i]);
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
     matmul_external(s);
   }
 }
 
-GL_HD void permute(u64 s[WIDTH]) { permute_impl<false>(s, nullptr); }
+GL_HD void permute(u64 s[WIDTH]) {
+  NoTrace nt;
+  permute_impl(s, nt);
+}
 
 }  // namespace poseidon2

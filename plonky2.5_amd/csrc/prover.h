@@ -1,0 +1,89 @@
+// Host orchestration of the GPU prover: device-resident circuit tables + per-stream proof contexts.
+// Mirrors the phases of upstream plonky2 @ 3de92d9 prover.rs `prove_with_partition_witness`
+// (reached from /root/reference/src/p3/mod.rs:260); phase names follow upstream's timing spans
+// (SURVEY.md App. A.9).  No host computation on the per-proof path: the host only enqueues kernels.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+#include "builder.h"
+#include "prover_kernels.h"
+
+namespace p25 {
+
+struct ProofLayout {
+  // word offsets into the flat proof (include/p25.h "Proof layout")
+  size_t wires_cap, zs_cap, quotient_cap;
+  size_t constants, sigmas, wires, zs, zs_next, pps, quotient;
+  size_t fri_caps, queries, query_stride, final_poly, pow_witness, total;
+  uint32_t oracle_width[4];
+  uint32_t final_poly_len;
+};
+ProofLayout make_proof_layout(const Circuit& c);
+
+struct DevMem {  // owning device allocation
+  u64* p = nullptr;
+  size_t words = 0;
+  DevMem() {}
+  explicit DevMem(size_t w);
+  ~DevMem();
+  DevMem(DevMem&& o) noexcept : p(o.p), words(o.words) { o.p = nullptr; }
+  DevMem& operator=(DevMem&& o) noexcept;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+};
+
+struct PhaseTimes {  // milliseconds, device time measured with HIP events on the proving stream
+  float witness = 0, wires_commit = 0, zs_pp = 0, zs_commit = 0, quotient = 0, quotient_commit = 0, openings = 0,
+        fri = 0, total = 0;
+};
+
+class DeviceCircuit {
+ public:
+  explicit DeviceCircuit(Circuit c);
+  ~DeviceCircuit();
+  const Circuit& circuit() const { return c_; }
+  const ProofLayout& layout() const { return layout_; }
+  const u64* digest() const { return digest_; }                 // host copy [4]
+  const std::vector<u64>& cs_cap() const { return cs_cap_; }    // host copy
+  size_t n() const { return c_.degree(); }
+  size_t big() const { return c_.degree() << c_.cfg.rate_bits; }
+
+  // Proves n_proofs independent inputs.  inputs[n_proofs][num_inputs] (host), seeds (host, nullable),
+  // proofs_out[n_proofs][proof_stride] (host), statuses[n_proofs].  Returns first non-zero HIP-level
+  // failure as exception; per-proof failures go to statuses.
+  void prove_batch(const u64* inputs, size_t n_proofs, const u64* seeds, u64* proofs_out, size_t proof_stride,
+                   int32_t* statuses, PhaseTimes* times);
+  // debug / parity: full witness of one input -> wires[num_wires][n] (host)
+  int32_t witness(const u64* inputs, u64 seed, u64* wires_out);
+
+  // Device-resident API used by bench.py: inputs already in HBM ([n_proofs][num_inputs]), proofs
+  // written to a device buffer; asynchronous on the internal stream until sync().
+  void prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs, size_t proof_stride,
+                       uint32_t* d_status, PhaseTimes* times);
+  void sync();
+  // time (ms) accumulated per kernel family since the last call, for the roofline line of bench.py
+  hipStream_t stream() const { return stream_; }
+
+ private:
+  struct Ctx;  // per-proof working set
+  void prove_one(Ctx& cx, const u64* d_vals, size_t B, uint32_t p, u64* d_proof, uint32_t* d_status, PhaseTimes* t);
+  void ensure_ctx();
+  void ensure_vals(size_t batch);
+
+  Circuit c_;
+  ProofLayout layout_;
+  NttTables tables_;
+  DeviceWitnessProgram wp_;
+  DevMem cs_vals_, cs_coeffs_, cs_lde_, cs_tree_, k_is_, preamble_;
+  u64 digest_[4];
+  std::vector<u64> cs_cap_;
+  QuotientArgs qa_proto_;
+  hipStream_t stream_ = nullptr;
+  std::unique_ptr<Ctx> ctx_;
+  DevMem vals_;
+  size_t vals_batch_ = 0;
+  std::vector<DevMem> owned_;
+};
+
+}  // namespace p25

@@ -1,0 +1,520 @@
+// See prover.h.
+#include "prover.h"
+#include <string.h>
+#include "poseidon.h"
+
+namespace p25 {
+
+DevMem::DevMem(size_t w) : words(w) {
+  if (w) P25_HIP(hipMalloc(&p, w * sizeof(u64)));
+}
+DevMem::~DevMem() {
+  if (p) (void)hipFree(p);
+}
+DevMem& DevMem::operator=(DevMem&& o) noexcept {
+  if (this != &o) {
+    if (p) (void)hipFree(p);
+    p = o.p;
+    words = o.words;
+    o.p = nullptr;
+  }
+  return *this;
+}
+
+static uint32_t final_poly_len(const Circuit& c) {
+  int db = c.degree_bits;
+  for (int a : c.fri_reduction_arity_bits) db -= a;
+  return 1u << db;
+}
+
+ProofLayout make_proof_layout(const Circuit& c) {
+  ProofLayout L;
+  const size_t capw = (size_t)4 << c.cfg.cap_height;
+  const int NC = c.cfg.num_challenges, NP = c.num_partial_products;
+  L.oracle_width[0] = (uint32_t)c.constants_sigmas.size();
+  L.oracle_width[1] = (uint32_t)c.cfg.num_wires;
+  L.oracle_width[2] = (uint32_t)(NC * (1 + NP));
+  L.oracle_width[3] = (uint32_t)(NC * c.cfg.max_quotient_degree_factor);
+  size_t o = 0;
+  L.wires_cap = o; o += capw;
+  L.zs_cap = o; o += capw;
+  L.quotient_cap = o; o += capw;
+  L.constants = o; o += 2 * (size_t)(c.num_selectors + c.cfg.num_constants);
+  L.sigmas = o; o += 2 * (size_t)c.cfg.num_routed_wires;
+  L.wires = o; o += 2 * (size_t)c.cfg.num_wires;
+  L.zs = o; o += 2 * (size_t)NC;
+  L.zs_next = o; o += 2 * (size_t)NC;
+  L.pps = o; o += 2 * (size_t)NC * NP;
+  L.quotient = o; o += 2 * (size_t)L.oracle_width[3];
+  L.fri_caps = o; o += c.fri_reduction_arity_bits.size() * capw;
+  L.queries = o;
+  const int lde_bits = c.degree_bits + c.cfg.rate_bits;
+  size_t per_q = 0;
+  for (int k = 0; k < 4; k++) per_q += L.oracle_width[k] + 4 * (size_t)(lde_bits - c.cfg.cap_height);
+  int bits = lde_bits;
+  for (int a : c.fri_reduction_arity_bits) {
+    bits -= a;
+    per_q += 2 * ((size_t)1 << a) + 4 * (size_t)(bits - c.cfg.cap_height);
+  }
+  L.query_stride = per_q;
+  o += per_q * c.cfg.num_query_rounds;
+  L.final_poly_len = final_poly_len(c);
+  L.final_poly = o; o += 2 * (size_t)L.final_poly_len;
+  L.pow_witness = o; o += 1;
+  L.total = o;
+  return L;
+}
+
+// ---------------------------------------------------------------- small glue kernels
+__global__ void k_check_zeta(const u64* chal, uint32_t degree_bits, uint32_t* status) {
+  gl::E2 z{chal[CH_ZETA], chal[CH_ZETA + 1]};
+  gl::E2 zn = gl::exp_pow2(z, degree_bits);
+  if (zn.a == 1 && zn.b == 0) *status = 6;  // "Opening point is in the subgroup."
+}
+__global__ void k_interleave(const u64* a, const u64* b, uint32_t m, u64* out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) {
+    out[2 * i] = a[i];
+    out[2 * i + 1] = b[i];
+  }
+}
+__global__ void k_finish(const u64* chal, int pow_bits, u64* proof_pow, uint32_t* status) {
+  u64 w = chal[CH_POW_WITNESS];
+  *proof_pow = w;
+  if (w == ~0ull || __clzll((long long)chal[CH_POW_RESPONSE]) < pow_bits) *status = 7;
+}
+
+// ---------------------------------------------------------------- per-proof working set
+struct DeviceCircuit::Ctx {
+  DevMem wires_vals, wires_coeffs, tmp, wires_lde, wires_tree;
+  DevMem zs_vals, zs_coeffs, zs_lde, zs_tree, zpp_chunk, zpp_tot, zpp_btot;
+  DevMem q_vals, q_tmp, q_coeffs, q_lde, q_tree;
+  DevMem transcript, chal, alpha_pows, eval_pows;
+  DevMem fri_comp, fri_scan, fri_coeffs[9], fri_vals[9], fri_tree[9];
+  DevMem proof, status;
+  hipEvent_t ev[12];
+  bool have_events = false;
+};
+
+DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
+  if (c_.cfg.num_challenges != 2 || c_.cfg.rate_bits > 3 || c_.gates.size() > 16)
+    throw std::invalid_argument("unsupported circuit configuration");
+  if (c_.fri_reduction_arity_bits.size() > 8) throw std::invalid_argument("too many FRI layers");
+  P25_HIP(hipStreamCreate(&stream_));
+  layout_ = make_proof_layout(c_);
+  const size_t n = c_.degree();
+  const int ncs = (int)c_.constants_sigmas.size();
+  // witness program
+  WitnessProgram wp = build_witness_program(c_);
+  auto up32 = [&](const std::vector<uint32_t>& v) {
+    DevMem m((v.size() + 1) / 2 + 1);
+    P25_HIP(hipMemcpy(m.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    u64* p = m.p;
+    owned_.push_back(std::move(m));
+    return (uint32_t*)p;
+  };
+  {
+    DevMem m(wp.gens.size() * sizeof(WitGen) / 8 + 1);
+    P25_HIP(hipMemcpy(m.p, wp.gens.data(), wp.gens.size() * sizeof(WitGen), hipMemcpyHostToDevice));
+    wp_.d_gens = (WitGen*)m.p;
+    owned_.push_back(std::move(m));
+  }
+  wp_.d_args = up32(wp.args);
+  wp_.d_input_slots = up32(wp.input_slots);
+  wp_.d_wire_slot_cm = up32(wp.wire_slot_cm);
+  wp_.level_start = wp.level_start;
+  wp_.n_inputs = (uint32_t)wp.input_slots.size();
+  wp_.num_slots = wp.num_slots;
+  wp_.n_wire_elems = wp.wire_slot_cm.size();
+
+  // constants_sigmas commitment (PolynomialBatch::from_values) -- once per circuit
+  cs_vals_ = DevMem((size_t)ncs * n);
+  for (int p = 0; p < ncs; p++)
+    P25_HIP(hipMemcpy(cs_vals_.p + (size_t)p * n, c_.constants_sigmas[p].data(), n * 8, hipMemcpyHostToDevice));
+  cs_coeffs_ = DevMem((size_t)ncs * n);
+  cs_lde_ = DevMem((size_t)ncs * big());
+  const size_t tw = merkle_tree_words(big(), c_.cfg.cap_height);
+  cs_tree_ = DevMem(tw);
+  {
+    DevMem tmp((size_t)ncs * n);
+    ntt_inverse(tables_, cs_vals_.p, n, false, tmp.p, n, cs_coeffs_.p, n, c_.degree_bits, ncs, 1, stream_);
+    ntt_lde_bitrev(tables_, cs_coeffs_.p, n, cs_lde_.p, big(), c_.degree_bits, c_.cfg.rate_bits, ncs, gl::GENERATOR, stream_);
+    launch_merkle_tree(cs_lde_.p, big(), ncs, big(), c_.cfg.cap_height, cs_tree_.p, stream_);
+    P25_HIP(hipStreamSynchronize(stream_));
+  }
+  const size_t capw = (size_t)4 << c_.cfg.cap_height;
+  cs_cap_.resize(capw);
+  P25_HIP(hipMemcpy(cs_cap_.data(), cs_tree_.p + tw - capw, capw * 8, hipMemcpyDeviceToHost));
+  // circuit_digest = H(cap || H_pad([]) || [degree_bits])  (host; once per circuit)
+  {
+    std::vector<u64> parts(cs_cap_);
+    u64 pad[8] = {1, 0, 0, 0, 0, 0, 0, 1}, ds[4];
+    poseidon::hash_no_pad_strided(pad, 1, 8, ds);
+    parts.insert(parts.end(), ds, ds + 4);
+    parts.push_back((u64)c_.degree_bits);
+    poseidon::hash_no_pad_strided(parts.data(), 1, (int)parts.size(), digest_);
+  }
+  // transcript preamble: circuit_digest | public_inputs_hash (= hash_no_pad([]) = zeros)
+  preamble_ = DevMem(8);
+  {
+    u64 pre[8] = {digest_[0], digest_[1], digest_[2], digest_[3], 0, 0, 0, 0};
+    P25_HIP(hipMemcpy(preamble_.p, pre, 64, hipMemcpyHostToDevice));
+  }
+  k_is_ = DevMem(c_.k_is.size());
+  P25_HIP(hipMemcpy(k_is_.p, c_.k_is.data(), c_.k_is.size() * 8, hipMemcpyHostToDevice));
+
+  // quotient argument prototype
+  memset(&qa_proto_, 0, sizeof(qa_proto_));
+  qa_proto_.cs_lde = cs_lde_.p;
+  qa_proto_.pow_big = tables_.pow_table(c_.degree_bits + c_.cfg.rate_bits, false);
+  qa_proto_.k_is = k_is_.p;
+  qa_proto_.n_gates = (uint32_t)c_.gates.size();
+  for (size_t i = 0; i < c_.gates.size(); i++) {
+    int s = c_.selector_index[i];
+    qa_proto_.gates[i] = GateEntry{(uint32_t)c_.gates[i], (uint32_t)s, (uint32_t)c_.groups[s].first, (uint32_t)c_.groups[s].second};
+  }
+  qa_proto_.num_selectors = c_.num_selectors;
+  qa_proto_.num_wires = c_.cfg.num_wires;
+  qa_proto_.num_routed = c_.cfg.num_routed_wires;
+  qa_proto_.num_partial_products = c_.num_partial_products;
+  qa_proto_.degree_bits = c_.degree_bits;
+  qa_proto_.rate_bits = c_.cfg.rate_bits;
+  {
+    u64 g_pow_n = gl::exp_pow2(gl::GENERATOR, c_.degree_bits);
+    u64 wr = gl::root_of_unity(c_.cfg.rate_bits);
+    for (int k = 0; k < (1 << c_.cfg.rate_bits); k++) {
+      qa_proto_.zh[k] = gl::sub(gl::mul(g_pow_n, gl::pow(wr, k)), 1);
+      qa_proto_.zh_inv[k] = gl::inv(qa_proto_.zh[k]);
+    }
+  }
+}
+
+DeviceCircuit::~DeviceCircuit() {
+  if (ctx_ && ctx_->have_events)
+    for (auto& e : ctx_->ev) (void)hipEventDestroy(e);
+  ctx_.reset();
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void DeviceCircuit::ensure_ctx() {
+  if (ctx_) return;
+  ctx_.reset(new Ctx());
+  Ctx& x = *ctx_;
+  const size_t n = c_.degree(), B = big();
+  const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;
+  const int nz = NC * (1 + NP), nq = NC * c_.cfg.max_quotient_degree_factor;
+  const size_t tw = merkle_tree_words(B, c_.cfg.cap_height);
+  x.wires_vals = DevMem((size_t)W * n);
+  x.wires_coeffs = DevMem((size_t)W * n);
+  x.tmp = DevMem((size_t)W * n);
+  x.wires_lde = DevMem((size_t)W * B);
+  x.wires_tree = DevMem(tw);
+  x.zs_vals = DevMem((size_t)nz * n);
+  x.zs_coeffs = DevMem((size_t)nz * n);
+  x.zs_lde = DevMem((size_t)nz * B);
+  x.zs_tree = DevMem(tw);
+  x.zpp_chunk = DevMem((size_t)NC * (NP + 1) * n);
+  x.zpp_tot = DevMem((size_t)NC * n);
+  x.zpp_btot = DevMem((size_t)NC * ((n + 255) / 256) + 16);
+  x.q_vals = DevMem((size_t)NC * B);
+  x.q_tmp = DevMem((size_t)NC * B);
+  x.q_coeffs = DevMem((size_t)NC * B);
+  x.q_lde = DevMem((size_t)nq * B);
+  x.q_tree = DevMem(tw);
+  x.transcript = DevMem(sizeof(Transcript) / 8 + 1);
+  x.chal = DevMem(CH_WORDS);
+  x.alpha_pows = DevMem(2 * ALPHA_POWS);
+  x.eval_pows = DevMem(2 * 258);
+  x.fri_comp = DevMem(4 * n);
+  size_t total_polys = layout_.oracle_width[0] + layout_.oracle_width[1] + layout_.oracle_width[2] + layout_.oracle_width[3];
+  x.fri_scan = DevMem(2 * (total_polys + 1) + 8 * (n + 1) + 4 * ((n + 255) / 256) + 64);
+  size_t m = n;
+  const size_t nl = c_.fri_reduction_arity_bits.size();
+  for (size_t l = 0; l <= nl; l++) {
+    x.fri_coeffs[l] = DevMem(2 * m);
+    if (l < nl) {
+      size_t vals = m << c_.cfg.rate_bits;
+      x.fri_vals[l] = DevMem(2 * vals);
+      x.fri_tree[l] = DevMem(merkle_tree_words(vals >> c_.fri_reduction_arity_bits[l], c_.cfg.cap_height));
+      m >>= c_.fri_reduction_arity_bits[l];
+    }
+  }
+  x.proof = DevMem(layout_.total);
+  x.status = DevMem(1);
+  for (auto& e : x.ev) P25_HIP(hipEventCreate(&e));
+  x.have_events = true;
+}
+
+void DeviceCircuit::ensure_vals(size_t batch) {
+  if (batch <= vals_batch_) return;
+  vals_ = DevMem();
+  vals_ = DevMem((size_t)wp_.num_slots * batch);
+  vals_batch_ = batch;
+}
+
+void DeviceCircuit::sync() { P25_HIP(hipStreamSynchronize(stream_)); }
+
+// One proof, fully enqueued on the stream; no host synchronisation inside.
+void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_t p, u64* d_proof,
+                              uint32_t* d_status, PhaseTimes* t) {
+  hipStream_t st = stream_;
+  const size_t n = c_.degree(), B = big();
+  const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;
+  const int nz = NC * (1 + NP), nq = NC * c_.cfg.max_quotient_degree_factor;
+  const int db = c_.degree_bits, rb = c_.cfg.rate_bits, lde_bits = db + rb;
+  const unsigned cap_h = c_.cfg.cap_height;
+  const size_t capw = (size_t)4 << cap_h;
+  const size_t tw = merkle_tree_words(B, cap_h);
+  const ProofLayout& L = layout_;
+  Transcript* tr = (Transcript*)x.transcript.p;
+  u64* chal = x.chal.p;
+  int evi = 0;
+  auto mark = [&]() {
+    if (t) P25_HIP(hipEventRecord(x.ev[evi++], st));
+  };
+  auto d2d = [&](u64* dst, const u64* src, size_t words) {
+    P25_HIP(hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToDevice, st));
+  };
+  mark();  // 0
+  // "compute full witness" + "compute wire polynomials"
+  launch_fill_wires(wp_, d_vals, Bstride, p, x.wires_vals.p, st);
+  mark();  // 1
+  // "compute wires commitment"
+  ntt_inverse(tables_, x.wires_vals.p, n, false, x.tmp.p, n, x.wires_coeffs.p, n, db, W, 1, st);
+  ntt_lde_bitrev(tables_, x.wires_coeffs.p, n, x.wires_lde.p, B, db, rb, W, gl::GENERATOR, st);
+  launch_merkle_tree(x.wires_lde.p, B, W, B, cap_h, x.wires_tree.p, st);
+  const u64* wires_cap = x.wires_tree.p + tw - capw;
+  d2d(d_proof + L.wires_cap, wires_cap, capw);
+  launch_transcript(tr, 1, preamble_.p, 8, chal, 0, st);
+  launch_transcript(tr, 0, wires_cap, (uint32_t)capw, chal + CH_BETAS, 2 * NC, st);  // betas, gammas
+  mark();  // 2
+  // "compute partial products"
+  {
+    ZppArgs za;
+    za.wires = x.wires_vals.p;
+    za.sigmas = cs_vals_.p + (size_t)(c_.num_selectors + c_.cfg.num_constants) * n;
+    za.pow_n = tables_.pow_table(db, false);
+    za.k_is = k_is_.p;
+    za.chal = chal;
+    za.chunk = x.zpp_chunk.p;
+    za.tot = x.zpp_tot.p;
+    za.block_tot = x.zpp_btot.p;
+    za.out = x.zs_vals.p;
+    za.n = (uint32_t)n;
+    za.num_routed = c_.cfg.num_routed_wires;
+    za.num_partial_products = NP;
+    za.num_challenges = NC;
+    launch_zpp(za, st);
+  }
+  mark();  // 3
+  // "commit to partial products, Z's"
+  ntt_inverse(tables_, x.zs_vals.p, n, false, x.tmp.p, n, x.zs_coeffs.p, n, db, nz, 1, st);
+  ntt_lde_bitrev(tables_, x.zs_coeffs.p, n, x.zs_lde.p, B, db, rb, nz, gl::GENERATOR, st);
+  launch_merkle_tree(x.zs_lde.p, B, nz, B, cap_h, x.zs_tree.p, st);
+  const u64* zs_cap = x.zs_tree.p + tw - capw;
+  d2d(d_proof + L.zs_cap, zs_cap, capw);
+  launch_transcript(tr, 0, zs_cap, (uint32_t)capw, chal + CH_ALPHAS, NC, st);
+  mark();  // 4
+  // "compute quotient polys"
+  launch_alpha_pows(chal, x.alpha_pows.p, st);
+  {
+    QuotientArgs qa = qa_proto_;
+    qa.wires_lde = x.wires_lde.p;
+    qa.zs_lde = x.zs_lde.p;
+    qa.chal = chal;
+    qa.alpha_pows = x.alpha_pows.p;
+    qa.out = x.q_vals.p;
+    launch_quotient(qa, st);
+  }
+  // coset iNTT of the 2 value vectors (stored at bit-reversed positions) -> 8n coefficients each
+  ntt_inverse(tables_, x.q_vals.p, B, true, x.q_tmp.p, B, x.q_coeffs.p, B, lde_bits, NC, gl::GENERATOR, st);
+  mark();  // 5
+  // "split up quotient polys" (chunks of n are contiguous: [NC][8][n] == [16][n]) + "commit to quotient polys"
+  ntt_lde_bitrev(tables_, x.q_coeffs.p, n, x.q_lde.p, B, db, rb, nq, gl::GENERATOR, st);
+  launch_merkle_tree(x.q_lde.p, B, nq, B, cap_h, x.q_tree.p, st);
+  const u64* q_cap = x.q_tree.p + tw - capw;
+  d2d(d_proof + L.quotient_cap, q_cap, capw);
+  launch_transcript(tr, 0, q_cap, (uint32_t)capw, chal + CH_ZETA, 2, st);
+  hipLaunchKernelGGL(k_check_zeta, dim3(1), dim3(1), 0, st, chal, (uint32_t)db, d_status);
+  mark();  // 6
+  // "construct the opening set"
+  {
+    const u64 g = gl::root_of_unity(db);
+    launch_eval_polys(cs_coeffs_.p, L.oracle_width[0], db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.constants, st);
+    launch_eval_polys(x.wires_coeffs.p, W, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.wires, st);
+    launch_eval_polys(x.zs_coeffs.p, NC, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.zs, st);
+    launch_eval_polys(x.zs_coeffs.p + (size_t)NC * n, NC * NP, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.pps, st);
+    launch_eval_polys(x.q_coeffs.p, nq, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.quotient, st);
+    launch_eval_polys(x.zs_coeffs.p, NC, db, chal + CH_ZETA, g, x.eval_pows.p, d_proof + L.zs_next, st);
+    // observe: constants|sigmas|wires|zs, then pps|quotient, then zs_next; then FRI alpha
+    launch_transcript(tr, 0, d_proof + L.constants, (uint32_t)(L.zs_next - L.constants), chal, 0, st);
+    launch_transcript(tr, 0, d_proof + L.pps, (uint32_t)(L.fri_caps - L.pps), chal, 0, st);
+    launch_transcript(tr, 0, d_proof + L.zs_next, (uint32_t)(L.pps - L.zs_next), chal + CH_FRI_ALPHA, 2, st);
+    mark();  // 7
+    // "compute opening proofs": batch, divide, multiply by X
+    FriCombineArgs fa;
+    fa.coeffs[0] = cs_coeffs_.p;
+    fa.coeffs[1] = x.wires_coeffs.p;
+    fa.coeffs[2] = x.zs_coeffs.p;
+    fa.coeffs[3] = x.q_coeffs.p;
+    for (int k = 0; k < 4; k++) fa.n_polys[k] = L.oracle_width[k];
+    fa.log_n = db;
+    fa.num_challenges = NC;
+    fa.chal = chal;
+    fa.g = g;
+    fa.comp = x.fri_comp.p;
+    fa.scan_tmp = x.fri_scan.p;
+    fa.final_a = x.fri_coeffs[0].p;
+    fa.final_b = x.fri_coeffs[0].p + n;
+    launch_fri_combine(fa, st);
+  }
+  // commit phase
+  QueryArgs qy;
+  memset(&qy, 0, sizeof(qy));
+  {
+    size_t m = n;
+    int log_m = db;
+    u64 shift = gl::GENERATOR;
+    const size_t nl = c_.fri_reduction_arity_bits.size();
+    for (size_t l = 0; l < nl; l++) {
+      const int ab = c_.fri_reduction_arity_bits[l];
+      const size_t vals = m << rb;
+      // values of the current polynomial on shift*<w>, bit-reversed positions, components a | b
+      ntt_lde_bitrev(tables_, x.fri_coeffs[l].p, m, x.fri_vals[l].p, vals, log_m, rb, 2, shift, st);
+      const size_t n_leaves = vals >> ab;
+      launch_fri_leaf_hash(x.fri_vals[l].p, x.fri_vals[l].p + vals, (uint32_t)n_leaves, ab, x.fri_tree[l].p, st);
+      launch_tree_from_digests(x.fri_tree[l].p, n_leaves, cap_h, st);
+      const size_t ltw = merkle_tree_words(n_leaves, cap_h);
+      const u64* cap = x.fri_tree[l].p + ltw - capw;
+      d2d(d_proof + L.fri_caps + l * capw, cap, capw);
+      launch_transcript(tr, 0, cap, (uint32_t)capw, chal + CH_FRI_BETAS + 2 * l, 2, st);
+      launch_fri_fold(x.fri_coeffs[l].p, x.fri_coeffs[l].p + m, (uint32_t)(m >> ab), ab, chal + CH_FRI_BETAS + 2 * l,
+                      x.fri_coeffs[l + 1].p, x.fri_coeffs[l + 1].p + (m >> ab), st);
+      qy.arity_bits[l] = ab;
+      qy.layer_va[l] = x.fri_vals[l].p;
+      qy.layer_vb[l] = x.fri_vals[l].p + vals;
+      qy.layer_tree[l] = x.fri_tree[l].p;
+      shift = gl::pow(shift, (u64)1 << ab);
+      m >>= ab;
+      log_m -= ab;
+    }
+    // final polynomial (the coefficients that survive truncation by the rate)
+    hipLaunchKernelGGL(k_interleave, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, x.fri_coeffs[nl].p,
+                       x.fri_coeffs[nl].p + m, (uint32_t)m, d_proof + L.final_poly);
+    launch_transcript(tr, 0, d_proof + L.final_poly, (uint32_t)(2 * m), chal, 0, st);
+    qy.n_layers = (uint32_t)nl;
+  }
+  // "find proof-of-work witness"
+  launch_pow_search(tr, c_.cfg.proof_of_work_bits, chal + CH_POW_WITNESS, st);
+  launch_transcript(tr, 0, chal + CH_POW_WITNESS, 1, chal + CH_POW_RESPONSE, 1 + c_.cfg.num_query_rounds, st);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, chal, c_.cfg.proof_of_work_bits, d_proof + L.pow_witness, d_status);
+  // query rounds
+  qy.chal = chal;
+  qy.num_queries = c_.cfg.num_query_rounds;
+  qy.lde_bits = lde_bits;
+  qy.cap_height = cap_h;
+  const u64* ldes[4] = {cs_lde_.p, x.wires_lde.p, x.zs_lde.p, x.q_lde.p};
+  const u64* trees[4] = {cs_tree_.p, x.wires_tree.p, x.zs_tree.p, x.q_tree.p};
+  for (int k = 0; k < 4; k++) {
+    qy.oracle_lde[k] = ldes[k];
+    qy.oracle_tree[k] = trees[k];
+    qy.oracle_width[k] = L.oracle_width[k];
+  }
+  qy.proof = d_proof;
+  qy.query_offset = (uint32_t)L.queries;
+  qy.query_stride = (uint32_t)L.query_stride;
+  launch_queries(qy, st);
+  mark();  // 8
+  P25_HIP(hipGetLastError());
+  if (t) {
+    P25_HIP(hipEventSynchronize(x.ev[8]));
+    float ms[8];
+    for (int i = 0; i < 8; i++) P25_HIP(hipEventElapsedTime(&ms[i], x.ev[i], x.ev[i + 1]));
+    t->witness += ms[0];
+    t->wires_commit += ms[1];
+    t->zs_pp += ms[2];
+    t->zs_commit += ms[3];
+    t->quotient += ms[4];
+    t->quotient_commit += ms[5];
+    t->openings += ms[6];
+    t->fri += ms[7];
+    float tot;
+    P25_HIP(hipEventElapsedTime(&tot, x.ev[0], x.ev[8]));
+    t->total += tot;
+  }
+}
+
+void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs,
+                                    size_t proof_stride, uint32_t* d_status, PhaseTimes* times) {
+  ensure_ctx();
+  const size_t MAXB = 64;
+  for (size_t base = 0; base < n_proofs; base += MAXB) {
+    size_t bsz = n_proofs - base < MAXB ? n_proofs - base : MAXB;
+    ensure_vals(bsz);
+    P25_HIP(hipMemsetAsync(d_status + base, 0, bsz * 4, stream_));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (times) {
+      P25_HIP(hipEventCreate(&e0));
+      P25_HIP(hipEventCreate(&e1));
+      P25_HIP(hipEventRecord(e0, stream_));
+    }
+    launch_witgen(wp_, d_inputs + base * wp_.n_inputs, d_seeds + base, vals_.p, bsz, (uint32_t)bsz, d_status + base, stream_);
+    if (times) {
+      P25_HIP(hipEventRecord(e1, stream_));
+      P25_HIP(hipEventSynchronize(e1));
+      float ms;
+      P25_HIP(hipEventElapsedTime(&ms, e0, e1));
+      times->witness += ms;
+      times->total += ms;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+    for (size_t p = 0; p < bsz; p++)
+      prove_one(*ctx_, vals_.p, bsz, (uint32_t)p, d_proofs + (base + p) * proof_stride, d_status + base + p, times);
+  }
+  P25_HIP(hipGetLastError());
+}
+
+void DeviceCircuit::prove_batch(const u64* inputs, size_t n_proofs, const u64* seeds, u64* proofs_out,
+                                size_t proof_stride, int32_t* statuses, PhaseTimes* times) {
+  if (proof_stride < layout_.total) throw std::invalid_argument("proof_stride smaller than the proof");
+  const size_t ni = wp_.n_inputs;
+  for (size_t i = 0; i < n_proofs * ni; i++)
+    if (inputs[i] >= gl::P) throw std::invalid_argument("non-canonical input field element");
+  DevMem d_in(n_proofs * ni), d_seeds(n_proofs), d_proofs(n_proofs * layout_.total), d_status((n_proofs + 1) / 2 + 1);
+  std::vector<u64> sd(n_proofs);
+  for (size_t i = 0; i < n_proofs; i++) sd[i] = seeds ? seeds[i] : (u64)i;
+  P25_HIP(hipMemcpyAsync(d_in.p, inputs, n_proofs * ni * 8, hipMemcpyHostToDevice, stream_));
+  P25_HIP(hipMemcpyAsync(d_seeds.p, sd.data(), n_proofs * 8, hipMemcpyHostToDevice, stream_));
+  prove_batch_dev(d_in.p, n_proofs, d_seeds.p, d_proofs.p, layout_.total, (uint32_t*)d_status.p, times);
+  std::vector<uint32_t> hs(n_proofs);
+  P25_HIP(hipMemcpyAsync(hs.data(), d_status.p, n_proofs * 4, hipMemcpyDeviceToHost, stream_));
+  for (size_t i = 0; i < n_proofs; i++)
+    P25_HIP(hipMemcpyAsync(proofs_out + i * proof_stride, d_proofs.p + i * layout_.total, layout_.total * 8,
+                           hipMemcpyDeviceToHost, stream_));
+  P25_HIP(hipStreamSynchronize(stream_));
+  for (size_t i = 0; i < n_proofs; i++) statuses[i] = (int32_t)hs[i];
+}
+
+int32_t DeviceCircuit::witness(const u64* inputs, u64 seed, u64* wires_out) {
+  ensure_ctx();
+  ensure_vals(1);
+  const size_t ni = wp_.n_inputs;
+  for (size_t i = 0; i < ni; i++)
+    if (inputs[i] >= gl::P) throw std::invalid_argument("non-canonical input field element");
+  DevMem d_in(ni), d_seed(1);
+  P25_HIP(hipMemcpyAsync(d_in.p, inputs, ni * 8, hipMemcpyHostToDevice, stream_));
+  P25_HIP(hipMemcpyAsync(d_seed.p, &seed, 8, hipMemcpyHostToDevice, stream_));
+  uint32_t* d_status = (uint32_t*)ctx_->status.p;
+  P25_HIP(hipMemsetAsync(d_status, 0, 4, stream_));
+  launch_witgen(wp_, d_in.p, d_seed.p, vals_.p, 1, 1, d_status, stream_);
+  launch_fill_wires(wp_, vals_.p, 1, 0, ctx_->wires_vals.p, stream_);
+  uint32_t hs = 0;
+  P25_HIP(hipMemcpyAsync(&hs, d_status, 4, hipMemcpyDeviceToHost, stream_));
+  P25_HIP(hipMemcpyAsync(wires_out, ctx_->wires_vals.p, wp_.n_wire_elems * 8, hipMemcpyDeviceToHost, stream_));
+  P25_HIP(hipStreamSynchronize(stream_));
+  P25_HIP(hipGetLastError());
+  return (int32_t)hs;
+}
+
+}  // namespace p25

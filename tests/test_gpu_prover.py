@@ -1,0 +1,66 @@
+"""GPU parity of the whole hot path (through the C ABI) against the oracle on the reference's artifact."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import P
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_witness_equals_oracle(gpu, fib_circuit, fib_oracle, fib_inputs):
+    wg, st = fib_circuit.witness(fib_inputs, seed=99)
+    assert st == 0
+    wo, sto, msg = fib_oracle.witness(fib_inputs, seed=99)
+    assert sto == 0, msg
+    assert (wg == wo).all()
+    bad, msg = fib_oracle.check_constraints(wg)
+    assert bad == 0, msg
+
+
+def test_gpu_circuit_digest_equals_oracle(gpu, fib_circuit, fib_oracle):
+    dg, capg = fib_circuit.digest()
+    do, capo = fib_oracle.digest()
+    assert (capg == capo).all()
+    assert (dg == do).all()
+
+
+def test_gpu_proof_equals_oracle_and_verifies(gpu, fib_circuit, fib_oracle, fib_inputs):
+    proofs, st, tm = fib_circuit.prove(fib_inputs, seeds=[1234], timings=True)
+    assert st.tolist() == [0]
+    po, sto, _tm, msg = fib_oracle.prove(fib_inputs, seed=1234)
+    assert sto == 0, msg
+    diff = np.nonzero(proofs[0] != po)[0]
+    assert diff.size == 0, f"first differing proof word {diff[:8]}"
+    dg, capg = fib_circuit.digest()
+    code, msg = fib_oracle.verify(proofs[0], dg, capg)
+    assert code == 0, msg
+    print("gpu phase ms:", {k: round(v, 3) for k, v in tm.as_dict().items()})
+    js = json.loads(fib_circuit.proof_to_json(proofs[0]))
+    assert js["public_inputs"] == [] and len(js["proof"]["opening_proof"]["query_round_proofs"]) == 28
+    assert js["proof"]["opening_proof"]["pow_witness"] == int(po[-1])
+
+
+def test_gpu_batch_statuses_and_determinism(gpu, fib_circuit, fib_oracle, fib_inputs):
+    """A batch with one corrupted inner proof: that proof alone fails (upstream would panic)."""
+    batch = np.stack([fib_inputs, fib_inputs, fib_inputs, fib_inputs])
+    batch[2, 9000] = (int(batch[2, 9000]) + 1) % P
+    proofs, st = fib_circuit.prove(batch, seeds=[5, 6, 7, 5])
+    assert st.tolist() == [0, 0, 4, 0]
+    assert (proofs[0] == proofs[3]).all()          # same input + same filler seed -> same bytes
+    assert (proofs[0] != proofs[1]).any()          # different filler seed -> different proof
+    dg, capg = fib_circuit.digest()
+    for k in (0, 1, 3):
+        code, msg = fib_oracle.verify(proofs[k], dg, capg)
+        assert code == 0, msg
+    code, _ = fib_oracle.verify(proofs[2], dg, capg)
+    assert code != 0
+
+
+def test_non_canonical_input_rejected(gpu, fib_circuit, fib_inputs, p25):
+    bad = fib_inputs.copy()
+    bad[3] = np.uint64(P)
+    with pytest.raises(p25.P25Error) as e:
+        fib_circuit.prove(bad)
+    assert e.value.status == 1
