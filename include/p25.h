@@ -163,6 +163,10 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
                                uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status,
                                p25_timings* timings);
 p25_status p25_circuit_sync(p25_circuit* c);
+/* Measurement hook for bench.py's roofline line: when enabled, HIP events on the proving stream
+ * bracket every launch of the dominant kernel (the Poseidon leaf sponge over the 135-column wires
+ * LDE).  Returns accumulated device milliseconds and launch count; reset != 0 clears them. */
+p25_status p25_circuit_kernel_stats(p25_circuit* c, int enable, int reset, double* ms_out, uint64_t* launches_out);
 /* Witness only (parity tests): wires_out[num_wires][2^degree_bits], column-major. */
 p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, uint64_t* wires_out,
                        p25_status* proof_status);

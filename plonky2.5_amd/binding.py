@@ -74,6 +74,7 @@ EXPORTED_SYMBOLS = {
     "p25_prove_batch": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
     "p25_prove_batch_dev": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
     "p25_circuit_sync": (i32, [vp]),
+    "p25_circuit_kernel_stats": (i32, [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "p25_witness": (i32, [vp, vp, C.c_uint64, vp, C.POINTER(i32)]),
     "p25_p3_proof_from_json": (i32, [C.c_char_p, sz, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
     "p25_proof_to_json": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
@@ -256,6 +257,12 @@ class Circuit:
 
     def sync(self):
         _check(lib().p25_circuit_sync(self._h))
+
+    def kernel_stats(self, enable=True, reset=False):
+        """(ms, launches) of the dominant kernel (wires leaf sponge), measured with HIP events."""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _check(lib().p25_circuit_kernel_stats(self._h, int(enable), int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def proof_to_json(self, proof):
         p = _u64(proof)

@@ -399,6 +399,17 @@ p25_status p25_circuit_sync(p25_circuit* c) {
     return P25_OK;
   });
 }
+p25_status p25_circuit_kernel_stats(p25_circuit* c, int enable, int reset, double* ms_out, uint64_t* launches_out) {
+  return guarded([&]() -> p25_status {
+    if (!c) throw std::invalid_argument("null argument");
+    p25::DeviceCircuit& d = c->device();
+    d.kernel_stats_enable(enable != 0);
+    u64 n = 0;
+    d.kernel_stats(ms_out, &n, reset != 0);
+    if (launches_out) *launches_out = n;
+    return P25_OK;
+  });
+}
 p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, uint64_t* wires_out, p25_status* proof_status) {
   return guarded([&]() -> p25_status {
     if (!c || !inputs || !wires_out) throw std::invalid_argument("null argument");

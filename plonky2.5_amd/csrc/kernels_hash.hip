@@ -97,9 +97,12 @@ size_t merkle_level_offset(size_t n_leaves, unsigned level) {
 
 // Builds every level up to the cap in `tree` (layout: merkle_level_offset).  Returns pointer to cap.
 u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t n_leaves,
-                        unsigned cap_height, u64* d_tree, hipStream_t st) {
+                        unsigned cap_height, u64* d_tree, hipStream_t st, hipEvent_t ev_begin,
+                        hipEvent_t ev_end) {
+  if (ev_begin) (void)hipEventRecord(ev_begin, st);
   hipLaunchKernelGGL(k_hash_leaves, dim3((unsigned)((n_leaves + 255) / 256)), dim3(256), 0, st, d_cols,
                      col_stride, width, n_leaves, d_tree);
+  if (ev_end) (void)hipEventRecord(ev_end, st);
   u64* cur = d_tree;
   size_t m = n_leaves;
   while (m > ((size_t)1 << cap_height)) {

@@ -62,8 +62,12 @@ class DeviceCircuit {
   void prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs, size_t proof_stride,
                        uint32_t* d_status, PhaseTimes* times);
   void sync();
-  // time (ms) accumulated per kernel family since the last call, for the roofline line of bench.py
   hipStream_t stream() const { return stream_; }
+  // Dominant-kernel accounting for bench.py's roofline line: HIP events bracket every launch of the
+  // wires leaf-sponge kernel (k_hash_leaves over the 135-column LDE) on the proving stream.
+  void kernel_stats_enable(bool on) { kstats_on_ = on; }
+  // drains finished event pairs; returns accumulated (ms, launches) since the last reset
+  void kernel_stats(double* ms, u64* launches, bool reset);
 
  private:
   struct Ctx;  // per-proof working set
@@ -84,6 +88,10 @@ class DeviceCircuit {
   DevMem vals_;
   size_t vals_batch_ = 0;
   std::vector<DevMem> owned_;
+  bool kstats_on_ = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kstats_pending_, kstats_free_;
+  double kstats_ms_ = 0;
+  u64 kstats_launches_ = 0;
 };
 
 }  // namespace p25

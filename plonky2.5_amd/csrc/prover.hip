@@ -193,6 +193,11 @@ DeviceCircuit::~DeviceCircuit() {
   if (ctx_ && ctx_->have_events)
     for (auto& e : ctx_->ev) (void)hipEventDestroy(e);
   ctx_.reset();
+  for (auto* v : {&kstats_pending_, &kstats_free_})
+    for (auto& pr : *v) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -254,6 +259,24 @@ void DeviceCircuit::ensure_vals(size_t batch) {
 
 void DeviceCircuit::sync() { P25_HIP(hipStreamSynchronize(stream_)); }
 
+void DeviceCircuit::kernel_stats(double* ms, u64* launches, bool reset) {
+  P25_HIP(hipStreamSynchronize(stream_));
+  for (auto& pr : kstats_pending_) {
+    float t = 0;
+    P25_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+    kstats_ms_ += t;
+    kstats_launches_++;
+    kstats_free_.push_back(pr);
+  }
+  kstats_pending_.clear();
+  if (ms) *ms = kstats_ms_;
+  if (launches) *launches = kstats_launches_;
+  if (reset) {
+    kstats_ms_ = 0;
+    kstats_launches_ = 0;
+  }
+}
+
 // One proof, fully enqueued on the stream; no host synchronisation inside.
 void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_t p, u64* d_proof,
                               uint32_t* d_status, PhaseTimes* t) {
@@ -282,7 +305,21 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   // "compute wires commitment"
   ntt_inverse(tables_, x.wires_vals.p, n, false, x.tmp.p, n, x.wires_coeffs.p, n, db, W, 1, st);
   ntt_lde_bitrev(tables_, x.wires_coeffs.p, n, x.wires_lde.p, B, db, rb, W, gl::GENERATOR, st);
-  launch_merkle_tree(x.wires_lde.p, B, W, B, cap_h, x.wires_tree.p, st);
+  {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (kstats_on_) {
+      if (kstats_free_.empty()) {
+        P25_HIP(hipEventCreate(&e0));
+        P25_HIP(hipEventCreate(&e1));
+      } else {
+        e0 = kstats_free_.back().first;
+        e1 = kstats_free_.back().second;
+        kstats_free_.pop_back();
+      }
+      kstats_pending_.push_back({e0, e1});
+    }
+    launch_merkle_tree(x.wires_lde.p, B, W, B, cap_h, x.wires_tree.p, st, e0, e1);
+  }
   const u64* wires_cap = x.wires_tree.p + tw - capw;
   d2d(d_proof + L.wires_cap, wires_cap, capw);
   launch_transcript(tr, 1, preamble_.p, 8, chal, 0, st);
