@@ -72,7 +72,7 @@ class DeviceCircuit {
  private:
   struct Ctx;  // per-proof working set
   void prove_one(Ctx& cx, const u64* d_vals, size_t B, uint32_t p, u64* d_proof, uint32_t* d_status, PhaseTimes* t);
-  void ensure_ctx();
+  void ensure_ctx(size_t count);
   void ensure_vals(size_t batch);
 
   Circuit c_;
@@ -84,7 +84,8 @@ class DeviceCircuit {
   std::vector<u64> cs_cap_;
   QuotientArgs qa_proto_;
   hipStream_t stream_ = nullptr;
-  std::unique_ptr<Ctx> ctx_;
+  std::vector<std::unique_ptr<Ctx>> ctxs_;   // proofs in flight: one working set + HIP stream each
+  hipEvent_t ev_witness_ = nullptr;
   DevMem vals_;
   size_t vals_batch_ = 0;
   std::vector<DevMem> owned_;

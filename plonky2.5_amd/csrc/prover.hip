@@ -93,7 +93,15 @@ struct DeviceCircuit::Ctx {
   DevMem fri_comp, fri_scan, fri_coeffs[9], fri_vals[9], fri_tree[9];
   DevMem proof, status;
   hipEvent_t ev[12];
+  hipStream_t st = nullptr;
+  hipEvent_t done = nullptr;  // recorded after the context's last read of the shared witness values
   bool have_events = false;
+  ~Ctx() {
+    if (have_events)
+      for (auto& e : ev) (void)hipEventDestroy(e);
+    if (done) (void)hipEventDestroy(done);
+    if (st) (void)hipStreamDestroy(st);
+  }
 };
 
 DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
@@ -190,9 +198,8 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
 }
 
 DeviceCircuit::~DeviceCircuit() {
-  if (ctx_ && ctx_->have_events)
-    for (auto& e : ctx_->ev) (void)hipEventDestroy(e);
-  ctx_.reset();
+  ctxs_.clear();
+  if (ev_witness_) (void)hipEventDestroy(ev_witness_);
   for (auto* v : {&kstats_pending_, &kstats_free_})
     for (auto& pr : *v) {
       (void)hipEventDestroy(pr.first);
@@ -201,10 +208,13 @@ DeviceCircuit::~DeviceCircuit() {
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-void DeviceCircuit::ensure_ctx() {
-  if (ctx_) return;
-  ctx_.reset(new Ctx());
-  Ctx& x = *ctx_;
+void DeviceCircuit::ensure_ctx(size_t count) {
+  if (!ev_witness_) P25_HIP(hipEventCreateWithFlags(&ev_witness_, hipEventDisableTiming));
+  while (ctxs_.size() < count) {
+  ctxs_.emplace_back(new Ctx());
+  Ctx& x = *ctxs_.back();
+  P25_HIP(hipStreamCreate(&x.st));
+  P25_HIP(hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
   const size_t n = c_.degree(), B = big();
   const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;
   const int nz = NC * (1 + NP), nq = NC * c_.cfg.max_quotient_degree_factor;
@@ -248,6 +258,7 @@ void DeviceCircuit::ensure_ctx() {
   x.status = DevMem(1);
   for (auto& e : x.ev) P25_HIP(hipEventCreate(&e));
   x.have_events = true;
+  }
 }
 
 void DeviceCircuit::ensure_vals(size_t batch) {
@@ -257,10 +268,13 @@ void DeviceCircuit::ensure_vals(size_t batch) {
   vals_batch_ = batch;
 }
 
-void DeviceCircuit::sync() { P25_HIP(hipStreamSynchronize(stream_)); }
+void DeviceCircuit::sync() {
+  P25_HIP(hipStreamSynchronize(stream_));
+  for (auto& c : ctxs_) P25_HIP(hipStreamSynchronize(c->st));
+}
 
 void DeviceCircuit::kernel_stats(double* ms, u64* launches, bool reset) {
-  P25_HIP(hipStreamSynchronize(stream_));
+  sync();
   for (auto& pr : kstats_pending_) {
     float t = 0;
     P25_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
@@ -280,7 +294,7 @@ void DeviceCircuit::kernel_stats(double* ms, u64* launches, bool reset) {
 // One proof, fully enqueued on the stream; no host synchronisation inside.
 void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_t p, u64* d_proof,
                               uint32_t* d_status, PhaseTimes* t) {
-  hipStream_t st = stream_;
+  hipStream_t st = x.st;
   const size_t n = c_.degree(), B = big();
   const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;
   const int nz = NC * (1 + NP), nq = NC * c_.cfg.max_quotient_degree_factor;
@@ -301,6 +315,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   mark();  // 0
   // "compute full witness" + "compute wire polynomials"
   launch_fill_wires(wp_, d_vals, Bstride, p, x.wires_vals.p, st);
+  P25_HIP(hipEventRecord(x.done, st));  // last read of the shared witness-value array by this proof
   mark();  // 1
   // "compute wires commitment"
   ntt_inverse(tables_, x.wires_vals.p, n, false, x.tmp.p, n, x.wires_coeffs.p, n, db, W, 1, st);
@@ -481,13 +496,26 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   }
 }
 
+static size_t streams_in_flight() {
+  const char* e = getenv("P25_STREAMS");
+  int k = e ? atoi(e) : 3;
+  return (size_t)(k < 1 ? 1 : (k > 8 ? 8 : k));
+}
+
+// Batch schedule: witness generation for up to 64 proofs at a time on the main stream (it is
+// parallel ACROSS proofs), then each proof's commit/quotient/FRI pipeline on one of K streams so that
+// the latency-bound stretches of one proof (transcript, Merkle-cap levels, FRI tail) overlap with the
+// throughput-bound kernels of the others.
 void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs,
                                     size_t proof_stride, uint32_t* d_status, PhaseTimes* times) {
-  ensure_ctx();
+  const size_t K = times ? 1 : streams_in_flight();
+  ensure_ctx(K);
   const size_t MAXB = 64;
   for (size_t base = 0; base < n_proofs; base += MAXB) {
     size_t bsz = n_proofs - base < MAXB ? n_proofs - base : MAXB;
     ensure_vals(bsz);
+    // the previous pass's proofs must be done reading vals_ before it is overwritten
+    for (auto& c : ctxs_) P25_HIP(hipStreamWaitEvent(stream_, c->done, 0));
     P25_HIP(hipMemsetAsync(d_status + base, 0, bsz * 4, stream_));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (times) {
@@ -496,6 +524,7 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
       P25_HIP(hipEventRecord(e0, stream_));
     }
     launch_witgen(wp_, d_inputs + base * wp_.n_inputs, d_seeds + base, vals_.p, bsz, (uint32_t)bsz, d_status + base, stream_);
+    P25_HIP(hipEventRecord(ev_witness_, stream_));
     if (times) {
       P25_HIP(hipEventRecord(e1, stream_));
       P25_HIP(hipEventSynchronize(e1));
@@ -506,8 +535,9 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
     }
+    for (size_t k = 0; k < K && k < bsz; k++) P25_HIP(hipStreamWaitEvent(ctxs_[k]->st, ev_witness_, 0));
     for (size_t p = 0; p < bsz; p++)
-      prove_one(*ctx_, vals_.p, bsz, (uint32_t)p, d_proofs + (base + p) * proof_stride, d_status + base + p, times);
+      prove_one(*ctxs_[p % K], vals_.p, bsz, (uint32_t)p, d_proofs + (base + p) * proof_stride, d_status + base + p, times);
   }
   P25_HIP(hipGetLastError());
 }
@@ -524,6 +554,7 @@ void DeviceCircuit::prove_batch(const u64* inputs, size_t n_proofs, const u64* s
   P25_HIP(hipMemcpyAsync(d_in.p, inputs, n_proofs * ni * 8, hipMemcpyHostToDevice, stream_));
   P25_HIP(hipMemcpyAsync(d_seeds.p, sd.data(), n_proofs * 8, hipMemcpyHostToDevice, stream_));
   prove_batch_dev(d_in.p, n_proofs, d_seeds.p, d_proofs.p, layout_.total, (uint32_t*)d_status.p, times);
+  sync();
   std::vector<uint32_t> hs(n_proofs);
   P25_HIP(hipMemcpyAsync(hs.data(), d_status.p, n_proofs * 4, hipMemcpyDeviceToHost, stream_));
   for (size_t i = 0; i < n_proofs; i++)
@@ -534,8 +565,10 @@ void DeviceCircuit::prove_batch(const u64* inputs, size_t n_proofs, const u64* s
 }
 
 int32_t DeviceCircuit::witness(const u64* inputs, u64 seed, u64* wires_out) {
-  ensure_ctx();
+  ensure_ctx(1);
+  sync();
   ensure_vals(1);
+  Ctx* ctx_ = ctxs_[0].get();
   const size_t ni = wp_.n_inputs;
   for (size_t i = 0; i < ni; i++)
     if (inputs[i] >= gl::P) throw std::invalid_argument("non-canonical input field element");
