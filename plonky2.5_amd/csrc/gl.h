@@ -54,13 +54,10 @@ GL_HD u64 mulhi64(u64 a, u64 b) {
 
 // (hi:lo) mod p, result possibly non-canonical (any u64 congruent to the input).
 GL_HD u64 reduce128(u64 lo, u64 hi) {
-  u64 hi_hi = hi >> 32;
-  u32 h0 = (u32)hi;
+  u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
   u64 t0 = lo - hi_hi;
   if (lo < hi_hi) t0 -= EPS;
-  // t1 = h0 * (2^32 - 1), built from 32-bit halves so that no integer multiply is spent on it
-  u32 t1_lo = 0u - h0, t1_hi = h0 - (h0 != 0 ? 1u : 0u);
-  u64 t1 = ((u64)t1_hi << 32) | t1_lo;
+  u64 t1 = hi_lo * EPS;  // < 2^64
   u64 t2 = t0 + t1;
   if (t2 < t1) t2 += EPS;
   return t2;

@@ -35,40 +35,6 @@ GL_HD u64 sbox(u64 x) {
 
 // s[] any u64 representatives in, non-canonical out.  out[r] = sum_i s[(i+r)%12]*CIRC[i] + s[r]*DIAG[r].
 GL_HD void mds(u64 s[WIDTH]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // gfx950 path: 32x32 integer multiplies are quarter rate, but v_mad_u32_u24 is full rate.  Split
-  // each word into 22/22/20-bit limbs; every limb column sum_i limb[(i+r)%12] * CIRC[i] is
-  // < 12 * 41 * 2^22 < 2^32, so 36 full-rate mad24 per output replace 24 quarter-rate mad_u64_u32.
-  u32 x0[WIDTH], x1[WIDTH], x2[WIDTH];
-#pragma unroll
-  for (int i = 0; i < WIDTH; i++) {
-    x0[i] = (u32)s[i] & 0x3FFFFFu;
-    x1[i] = (u32)(s[i] >> 22) & 0x3FFFFFu;
-    x2[i] = (u32)(s[i] >> 44);
-  }
-#pragma unroll
-  for (int r = 0; r < WIDTH; r++) {
-    u32 a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-    for (int i = 0; i < WIDTH; i++) {
-      a0 = __umul24(x0[(i + r) % WIDTH], MDS_CIRC[i]) + a0;
-      a1 = __umul24(x1[(i + r) % WIDTH], MDS_CIRC[i]) + a1;
-      a2 = __umul24(x2[(i + r) % WIDTH], MDS_CIRC[i]) + a2;
-    }
-    if (r == 0) {
-      a0 += x0[0] * MDS_DIAG0;
-      a1 += x1[0] * MDS_DIAG0;
-      a2 += x2[0] * MDS_DIAG0;
-    }
-    // value = a0 + a1 * 2^22 + a2 * 2^44  (< 2^76)
-    u64 v = (u64)a0 + ((u64)a1 << 22);
-    u64 w = (u64)a2 << 44;
-    u64 l64 = v + w;
-    u32 h32 = (a2 >> 20) + (l64 < w ? 1u : 0u);
-    s[r] = gl::reduce96(l64, h32);
-  }
-  return;
-#endif
   u64 lo[WIDTH], hi[WIDTH];
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) {

@@ -498,8 +498,8 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
 
 static size_t streams_in_flight() {
   const char* e = getenv("P25_STREAMS");
-  int k = e ? atoi(e) : 3;
-  return (size_t)(k < 1 ? 1 : (k > 8 ? 8 : k));
+  int k = e ? atoi(e) : 8;
+  return (size_t)(k < 1 ? 1 : (k > 16 ? 16 : k));
 }
 
 // Batch schedule: witness generation for up to 64 proofs at a time on the main stream (it is

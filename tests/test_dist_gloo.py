@@ -1,0 +1,29 @@
+"""CPU: the N>1 path (block sharding of independent proofs + final gather) on gloo, world_size 2."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def test_shard_range(p25):
+    from plonky25_amd import dist as pd
+    for n, w in ((2048, 8), (256, 2), (7, 3), (1, 2), (0, 4)):
+        ranges = [pd.shard_range(n, r, w) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("n_total", [6, 7])
+def test_gather_world2_gloo(n_total):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29531 + n_total),
+           os.path.join(ROOT, "tests", "_dist_worker.py"), str(n_total)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert f"DIST_OK {n_total}" in out.stdout
