@@ -109,6 +109,12 @@ enum { P25_AIR_FIBONACCI = 0 }; /* the test AIR of src/p3/mod.rs:160-221 */
  *           builder.p3_verify_proof::<PoseidonHash>(proof, &air, fri_config);
  *           builder.build::<PoseidonGoldilocksConfig>()          (src/p3/mod.rs:231-250). */
 p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, p25_circuit** out);
+/* Small circuits mirroring the reference's gadget tests (src/p3/mod.rs:271-494 test_p3_and / xor / lsh /
+ * rsh / reverse, src/p3/commit.rs:173-198 test_compress): kind 0 and(x,y) 1 xor(x,y) 2 lsh(x,param)
+ * 3 rsh(x,param) 4 reverse_bits_len(x,param) 5 Poseidon2 compress(l[4],r[4]) 6 7*w_param^e with inverse.
+ * Inputs = operands followed by the expected result(s); a wrong expectation fails the proof with
+ * P25_ERR_WITNESS_CONFLICT, as the failing `connect` panics upstream. */
+p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** out);
 /* Circuit blob (format: plonky2.5_amd/csrc/circuit_io.h): persist a built circuit / hand it to
  * another process.  export: pass buf = NULL to query the size. */
 p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out);

@@ -65,6 +65,7 @@ EXPORTED_SYMBOLS = {
     "p25_lde_commit_dev": (i32, [vp, ui, sz, C.c_int, ui, ui, vp, vp, vp, vp, vp]),
     "p25_poseidon_permute_dev": (i32, [vp, sz, vp]),
     "p25_circuit_build_p3_verifier": (i32, [C.POINTER(P3Config), i32, C.POINTER(vp)]),
+    "p25_circuit_build_gadget": (i32, [i32, i32, C.POINTER(vp)]),
     "p25_circuit_export": (i32, [vp, vp, sz, C.POINTER(sz)]),
     "p25_circuit_import": (i32, [vp, sz, C.POINTER(vp)]),
     "p25_circuit_destroy": (None, [vp]),
@@ -178,6 +179,13 @@ class Circuit:
         cfg = cfg or P3Config.fib64()
         h = vp()
         _check(lib().p25_circuit_build_p3_verifier(C.byref(cfg), air, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def build_gadget(cls, kind, param=0):
+        """kind: 0 and, 1 xor, 2 lsh, 3 rsh, 4 reverse_bits_len, 5 compress, 6 exp (include/p25.h)."""
+        h = vp()
+        _check(lib().p25_circuit_build_gadget(kind, param, C.byref(h)))
         return cls(h.value)
 
     @classmethod

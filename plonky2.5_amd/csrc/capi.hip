@@ -282,6 +282,21 @@ p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, 
   });
 }
 
+p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** out) {
+  return host_guarded([&]() -> p25_status {
+    if (!out) throw std::invalid_argument("null argument");
+    auto* h = new p25_circuit();
+    try {
+      h->circuit = p25::build_gadget_circuit(kind, param);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+    return P25_OK;
+  });
+}
+
 p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out) {
   return host_guarded([&]() -> p25_status {
     if (!c || !len_out) throw std::invalid_argument("null argument");

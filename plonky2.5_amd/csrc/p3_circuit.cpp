@@ -680,4 +680,60 @@ P3ProofTarget p3_verify_proof(CircuitBuilder& cb, const P3Config& config, const 
   return proof;
 }
 
+
+Circuit build_gadget_circuit(int kind, int param) {
+  CircuitBuilder cb;
+  auto in = [&]() {
+    Target t = cb.add_virtual_target();
+    cb.input_targets.push_back(t);
+    return t;
+  };
+  switch (kind) {
+    case GADGET_AND:
+    case GADGET_XOR: {
+      Target x = in(), y = in(), expected = in();
+      Target r = kind == GADGET_AND ? p3_and(cb, x, y) : p3_xor(cb, x, y);
+      cb.connect(r, expected);
+      break;
+    }
+    case GADGET_LSH:
+    case GADGET_RSH: {
+      if (param < 0 || param > 63 || param == 32) throw std::invalid_argument("shift amount");
+      Target x = in(), expected = in();
+      Target r = kind == GADGET_LSH ? p3_lsh(cb, x, param) : p3_rsh(cb, x, param);
+      cb.connect(r, expected);
+      break;
+    }
+    case GADGET_REVERSE: {
+      if (param < 1 || param > 64) throw std::invalid_argument("bit length");
+      Target x = in(), expected = in();
+      Target r = reverse_p3_bits_len(cb, x, param);
+      cb.connect(r, expected);
+      break;
+    }
+    case GADGET_COMPRESS: {  // MerkleTreeMmcs::compress (commit.rs:48-60) on 8 inputs
+      std::array<Target, 4> l, rr;
+      for (auto& t : l) t = in();
+      for (auto& t : rr) t = in();
+      auto out = compress(cb, l, rr);
+      for (int i = 0; i < 4; i++) cb.connect(out[i], in());
+      break;
+    }
+    case GADGET_EXP: {  // x = 7 * w^e as in verifier.rs:299-311
+      Target e = in(), expected = in();
+      Target g = p3_two_adic_generator(cb, param);
+      Target pw = cb.exp(g, e, 64);
+      Target x = cb.mul(p3_w(cb), pw);
+      Target xi = cb.inverse(x);
+      Target one = cb.mul(x, xi);
+      cb.connect(one, cb.one());
+      cb.connect(x, expected);
+      break;
+    }
+    default:
+      throw std::invalid_argument("unknown gadget kind");
+  }
+  return cb.build();
+}
+
 }  // namespace p25

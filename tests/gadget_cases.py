@@ -1,0 +1,39 @@
+"""Gadget circuits mirroring the reference's gadget tests, with natively computed expectations
+(the reference tests compare against native u64 ops: src/p3/mod.rs:271-494)."""
+import numpy as np
+
+P = 0xFFFFFFFF00000001
+M64 = (1 << 64) - 1
+TWO_ADIC = 1753635133440165772
+
+
+def rev_bits(x, n):
+    return int(format(x, "064b")[::-1], 2) >> (64 - n)
+
+
+def cases(oracle=None):
+    rng = np.random.default_rng(20240611)
+
+    def r64():
+        return int(rng.integers(0, P, dtype=np.uint64))  # canonical field element used as a u64
+
+    out = []
+    x, y = r64(), r64()
+    out.append(("and", 0, 0, [x, y, (x & y) % P]))
+    out.append(("xor", 1, 0, [x, y, (x ^ y) % P]))
+    for n in (1, 7, 31, 33, 63):
+        x = r64()
+        out.append((f"lsh{n}", 2, n, [x, ((x << n) & M64) % P]))
+        out.append((f"rsh{n}", 3, n, [x, (x >> n) % P]))
+    for n in (7, 19, 64):
+        x = r64()
+        out.append((f"rev{n}", 4, n, [x, rev_bits(x, n) % P]))
+    e = int(rng.integers(0, 1 << 19))
+    w = pow(TWO_ADIC, 1 << (32 - 19), P)
+    out.append(("exp19", 6, 19, [e, 7 * pow(w, e, P) % P]))
+    if oracle is not None:
+        l = [r64() for _ in range(4)]
+        r = [r64() for _ in range(4)]
+        st = oracle.poseidon2_permute(np.array(l + r + [0] * 4, dtype=np.uint64))[0]
+        out.append(("compress", 5, 0, l + r + [int(v) for v in st[:4]]))
+    return out
