@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <tuple>
 #include "gl.h"
 
 namespace p25 {
@@ -62,8 +63,11 @@ class NttTables {
   // device table of base^e for e < len (cached by (base, len))
   const u64* geom_table(u64 first, u64 ratio, size_t len);
   const u64* upload(const std::vector<u64>& host);
+  typedef std::map<std::tuple<int, int, u64>, std::pair<const u64*, const u64*>> CosetCache;
+  CosetCache& coset_cache() { return coset_; }
 
  private:
+  CosetCache coset_;
   std::map<std::pair<int, bool>, u64*> pow_;
   std::map<std::tuple<u64, u64, size_t>, u64*> geom_;
   std::vector<u64*> owned_;

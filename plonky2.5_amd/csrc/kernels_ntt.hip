@@ -237,8 +237,9 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
     for (size_t k = 0; k < R1; k++) { hi[c * R1 + k] = x; x = gl::mul(x, sr); }
   }
   // cache by content is overkill: tables are tiny; cache by (log_n, rate_bits, shift)
-  static thread_local std::map<std::tuple<NttTables*, int, int, u64>, std::pair<const u64*, const u64*>> cache;
-  auto key = std::make_tuple(&tb, log_n, rate_bits, shift);
+  // (the cache lives in the NttTables object: device pointers die with it)
+  auto& cache = tb.coset_cache();
+  auto key = std::make_tuple(log_n, rate_bits, shift);
   auto it = cache.find(key);
   if (it == cache.end()) it = cache.emplace(key, std::make_pair(tb.upload(ht), tb.upload(hi))).first;
 
