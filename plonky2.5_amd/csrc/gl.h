@@ -9,6 +9,7 @@
 // value may be held non-canonically (any u64) between `mul_nc`/`reduce*` calls; `canon` brings it
 // back.  All arithmetic is exact integer arithmetic -> results are bit-identical on CPU and GPU.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)

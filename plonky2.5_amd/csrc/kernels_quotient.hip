@@ -29,12 +29,33 @@ struct Ctx {
   size_t big;
   const u64* ap0;    // alpha_0^j, alpha_1^j tables (LDS)
   const u64* ap1;
-  u64 acc0, acc1;
+  // Lazy reduction: the two alpha-sums are kept as 160-bit integers (128-bit + overflow count) and
+  // reduced mod p once per gate instead of once per constraint (4 multiply-adds + a carry chain per
+  // term instead of a full modular multiply and add).
+  unsigned __int128 s0, s1;
+  u32 ov0, ov1;
   __device__ __forceinline__ u64 w(int col) const { return wires[(size_t)col * big]; }
-  __device__ __forceinline__ void at(int j, u64 c) {
-    acc0 = gl::add(acc0, gl::mul(c, ap0[j]));
-    acc1 = gl::add(acc1, gl::mul(c, ap1[j]));
+  __device__ __forceinline__ void reset() {
+    s0 = 0;
+    s1 = 0;
+    ov0 = 0;
+    ov1 = 0;
   }
+  __device__ __forceinline__ void at(int j, u64 c) {
+    unsigned __int128 p0 = (unsigned __int128)c * ap0[j];
+    unsigned __int128 p1 = (unsigned __int128)c * ap1[j];
+    s0 += p0;
+    ov0 += s0 < p0 ? 1u : 0u;
+    s1 += p1;
+    ov1 += s1 < p1 ? 1u : 0u;
+  }
+  // value = s + ov * 2^128, and 2^128 = -2^32 (mod p)
+  __device__ __forceinline__ static u64 fold(unsigned __int128 s, u32 ov) {
+    u64 r = gl::canon(gl::reduce128((u64)s, (u64)(s >> 64)));
+    return gl::sub(r, gl::mul((u64)ov, (u64)1 << 32));
+  }
+  __device__ __forceinline__ u64 acc0() const { return fold(s0, ov0); }
+  __device__ __forceinline__ u64 acc1() const { return fold(s1, ov1); }
 };
 
 __device__ void gate_constant(Ctx& cx, u64 k0, u64 k1) {
@@ -281,8 +302,7 @@ __global__ __launch_bounds__(128) void k_quotient(QuotientArgs a) {
       for (uint32_t k = ge.group_start; k < ge.group_end; k++)
         if (k != gi) filter = gl::mul(filter, gl::sub((u64)k, s));
       if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
-      cx.acc0 = 0;
-      cx.acc1 = 0;
+      cx.reset();
       switch (ge.kind) {
         case G_CONSTANT: gate_constant(cx, k0, k1); break;
         case G_PUBLIC_INPUT: gate_public_input(cx); break;
@@ -296,8 +316,8 @@ __global__ __launch_bounds__(128) void k_quotient(QuotientArgs a) {
         case G_POSEIDON2: gate_poseidon2(cx); break;
         default: break;  // NoopGate: no constraints
       }
-      g0 = gl::add(g0, gl::mul(filter, cx.acc0));
-      g1 = gl::add(g1, gl::mul(filter, cx.acc1));
+      g0 = gl::add(g0, gl::mul(filter, cx.acc0()));
+      g1 = gl::add(g1, gl::mul(filter, cx.acc1()));
     }
     const int off = NC * (1 + nch);
     res[0] = gl::add(res[0], gl::mul(g0, ap[off]));

@@ -74,6 +74,8 @@ GL_HD void permute(u64 s[WIDTH]) {
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(add_rc(s[i], RC[12 * r + i]));
     mds(s);
   }
+  // (The sparse-matrix "fast partial rounds" form -- tools/gen_poseidon_fast.py -- was measured on
+  // MI355X and is slower: 128-bit carry chains cost more than the dense small-constant layer below.)
   for (int k = 0; k < N_PARTIAL; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = add_rc(s[i], RC[12 * r + i]);

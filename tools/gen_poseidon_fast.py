@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Derive the optimised ("fast partial rounds") form of Poseidon-v1 over Goldilocks from the naive
+definition (round constants of tools/gen_poseidon_constants.py + the circulant MDS), and verify it
+against the naive permutation on random states and the four KATs.
+
+Naive partial round i:   x <- M * S(x + c_i),  S = x^7 on lane 0 only.
+Equivalent form (Poseidon paper, "optimised partial rounds"):
+    x <- x + FIRST;  x[1:] <- INIT * x[1:];
+    for i in 0..21:  x0 <- x0^7 + SCALAR[i];  x <- SPARSE_i * x,
+    SPARSE_i = [[m00, VHAT_i^T], [W_i, I]]:  new0 = m00*x0 + <VHAT_i, x[1:]>,  new[j] = x[j] + W_i[j]*x0.
+Derivation (column vectors):
+  constants: walking backwards, the constant vector of round i+1 is pulled through round i's M:
+     u = M^-1 * acc; lane 0 of u becomes the scalar added after round i's S-box, the rest joins c_i.
+  matrices: P = [[p00, v^T],[w, Phat]] = [[p00, v^T Phat^-1],[w, I]] * diag(1, Phat); diag(1, Phat)
+     commutes with S and is absorbed by the previous round's matrix (P_prev = diag(1, Phat) * M).
+Writes plonky2.5_amd/csrc/poseidon_fast_constants.inc."""
+import os, random, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_poseidon_constants import constants, poseidon, KATS, MDS_CIRC, MDS_DIAG, P
+
+T, RF, RP = 12, 8, 22
+
+def inv(a): return pow(a, P - 2, P)
+
+def mat_mul(A, B):
+    n, m, k = len(A), len(B[0]), len(B)
+    return [[sum(A[i][t] * B[t][j] for t in range(k)) % P for j in range(m)] for i in range(n)]
+def mat_vec(A, v): return [sum(a * b for a, b in zip(row, v)) % P for row in A]
+def mat_inv(A):
+    n = len(A); M = [row[:] + [1 if i == j else 0 for j in range(n)] for i, row in enumerate(A)]
+    for c in range(n):
+        p = next(r for r in range(c, n) if M[r][c]); M[c], M[p] = M[p], M[c]
+        iv = inv(M[c][c]); M[c] = [x * iv % P for x in M[c]]
+        for r in range(n):
+            if r != c and M[r][c]:
+                f = M[r][c]; M[r] = [(x - f * y) % P for x, y in zip(M[r], M[c])]
+    return [row[n:] for row in M]
+
+# out[r] = sum_i s[(i+r)%12]*CIRC[i] + s[r]*DIAG[r]  ->  M[r][(i+r)%12] += CIRC[i]
+M = [[0] * T for _ in range(T)]
+for r in range(T):
+    for i in range(T):
+        M[r][(i + r) % T] = (M[r][(i + r) % T] + MDS_CIRC[i]) % P
+    M[r][r] = (M[r][r] + MDS_DIAG[r]) % P
+Minv = mat_inv(M)
+
+rc = constants()
+c = [rc[12 * (4 + i):12 * (5 + i)] for i in range(RP)]   # partial-round constant vectors
+
+# constants
+scal = [0] * RP
+acc = c[RP - 1][:]
+for i in range(RP - 2, -1, -1):
+    u = mat_vec(Minv, acc)
+    scal[i] = u[0]
+    acc = [c[i][0]] + [(c[i][j] + u[j]) % P for j in range(1, T)]
+first = acc
+
+# matrices
+Pm = [row[:] for row in M]
+m00 = []; vhat = [None] * RP; wcol = [None] * RP
+for i in range(RP - 1, -1, -1):
+    p00 = Pm[0][0]; v = Pm[0][1:]; w = [Pm[r][0] for r in range(1, T)]
+    Ph = [row[1:] for row in Pm[1:]]
+    Phi = mat_inv(Ph)
+    vh = [sum(v[t] * Phi[t][j] for t in range(T - 1)) % P for j in range(T - 1)]   # v^T Phat^-1
+    m00.append(p00); vhat[i] = vh; wcol[i] = w
+    D = [[1] + [0] * (T - 1)] + [[0] + Ph[r] for r in range(T - 1)]
+    Pm = mat_mul(D, M)
+init = [row[1:] for row in Pm[1:]]   # leftover diag(1, Phat) of round 0 ... recompute below
+# the leftover dense block is the Phat of the LAST factorisation step (round 0)
+assert len(set(m00)) == 1 and m00[0] == (MDS_CIRC[0] + MDS_DIAG[0]) % P
+# redo to capture Phat of round 0 explicitly
+Pm = [row[:] for row in M]
+for i in range(RP - 1, -1, -1):
+    Ph = [row[1:] for row in Pm[1:]]
+    D = [[1] + [0] * (T - 1)] + [[0] + Ph[r] for r in range(T - 1)]
+    if i == 0:
+        init = Ph
+    Pm = mat_mul(D, M)
+
+def sbox(x): return pow(x, 7, P)
+def mds(s): return mat_vec(M, s)
+
+def poseidon_fast(state):
+    s = list(state); r = 0
+    for _ in range(4):
+        s = [sbox((s[i] + rc[12 * r + i]) % P) for i in range(T)]; s = mds(s); r += 1
+    s = [(s[i] + first[i]) % P for i in range(T)]
+    s = [s[0]] + mat_vec(init, s[1:])
+    for i in range(RP):
+        s0 = (sbox(s[0]) + scal[i]) % P
+        new0 = (m00[0] * s0 + sum(a * b for a, b in zip(vhat[i], s[1:]))) % P
+        s = [new0] + [(s[j] + wcol[i][j - 1] * s0) % P for j in range(1, T)]
+    r += RP
+    for _ in range(4):
+        s = [sbox((s[i] + rc[12 * r + i]) % P) for i in range(T)]; s = mds(s); r += 1
+    return s
+
+if __name__ == "__main__":
+    rnd = random.Random(7)
+    tests = [k[0] for k in KATS] + [[rnd.randrange(P) for _ in range(T)] for _ in range(20)]
+    for t in tests:
+        assert poseidon_fast(t) == poseidon(t, rc), "fast form disagrees with the naive permutation"
+    for inp, exp in KATS:
+        assert poseidon_fast(inp) == exp
+    assert scal[RP - 1] == 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def arr(name, vals, per=4):
+        s = f"static constexpr uint64_t {name}[{len(vals)}] = {{\n"
+        for i in range(0, len(vals), per):
+            s += "  " + " ".join(f"0x{v:016x}ULL," for v in vals[i:i + per]) + "\n"
+        return s + "};\n"
+    body = ("/* generated by tools/gen_poseidon_fast.py (derived from the naive definition and checked against it\n"
+            "   and the reference's KATs) -- do not edit */\n" +
+            arr("PF_FIRST", first) + arr("PF_SCALAR", scal) +
+            "/* PF_INIT[r*11 + c]: new[c+1] = sum_r PF_INIT[r*11+c] * old[r+1]  (stored transposed for the kernel) */\n" +
+            arr("PF_INIT", [init[cidx][r] for r in range(T - 1) for cidx in range(T - 1)]) +
+            arr("PF_VHAT", [x for i in range(RP) for x in vhat[i]]) +
+            arr("PF_W", [x for i in range(RP) for x in wcol[i]]))
+    if "--write" in sys.argv:  # experiment only: the product uses the dense form (measured faster on MI355X)
+        open(os.path.join(root, "plonky2.5_amd/csrc/poseidon_fast_constants.inc"), "w").write(body)
+    print("ok: fast form == naive on", len(tests), "states incl. 4 KATs; m00 =", m00[0])
