@@ -185,6 +185,18 @@ p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, ui
  * (src/p3/mod.rs:233-234, 254-257).  inputs_out may be NULL to query *n_out. */
 p25_status p25_p3_proof_from_json(const char* json, size_t len, uint64_t* inputs_out, size_t cap, size_t* n_out,
                                   p25_p3_config* cfg_out);
+/* Native plonky3 prover for the Fibonacci AIR of src/p3/mod.rs:160-221 (host code):
+ * produces the hot path's per-proof input for any trace height 2^log_n (the reference ships exactly
+ * one such proof, artifacts/proof_fibonacci.json = log_n 6, 100 queries, 16 PoW bits, which this
+ * prover reproduces bit for bit).  pow_start: first proof-of-work witness tried (any valid witness is
+ * a legitimate proof; different witnesses give different query indices).  inputs_out may be NULL to
+ * query *n_out.  The shape (p25_p3_config) for p25_circuit_build_p3_verifier is returned in cfg_out. */
+p25_status p25_p3_prove_fibonacci(int32_t log_n, int32_t num_queries, int32_t pow_bits, uint64_t pow_start,
+                                  int32_t threads, uint64_t* inputs_out, size_t cap, size_t* n_out,
+                                  p25_p3_config* cfg_out);
+/* Input vector -> plonky3 proof JSON in the reference's serde format (src/p3/serde/proof.rs:16-355). */
+p25_status p25_p3_inputs_to_json(const uint64_t* inputs, size_t n, const p25_p3_config* cfg, char* buf,
+                                 size_t cap, size_t* len_out);
 /* Flat proof -> JSON shaped like serde_json::to_string(&ProofWithPublicInputs) (src/p3/mod.rs:261).
  * buf may be NULL to query *len_out. */
 p25_status p25_proof_to_json(p25_circuit* c, const uint64_t* proof, char* buf, size_t cap, size_t* len_out);

@@ -6,7 +6,7 @@ import numpy as np
 
 __all__ = ["P25Error", "lib", "lib_path", "device_init", "poseidon_permute", "poseidon2_permute",
            "merkle_commit", "merkle_tree_words", "lde_commit", "EXPORTED_SYMBOLS", "P",
-           "P3Config", "Circuit", "p3_proof_from_json", "Timings"]
+           "P3Config", "Circuit", "p3_proof_from_json", "Timings", "p3_prove_fibonacci", "p3_inputs_to_json"]
 
 P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -79,6 +79,8 @@ EXPORTED_SYMBOLS = {
     "p25_witness": (i32, [vp, vp, C.c_uint64, vp, C.POINTER(i32)]),
     "p25_p3_proof_from_json": (i32, [C.c_char_p, sz, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
     "p25_proof_to_json": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+    "p25_p3_prove_fibonacci": (i32, [i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
+    "p25_p3_inputs_to_json": (i32, [vp, sz, C.POINTER(P3Config), vp, sz, C.POINTER(sz)]),
 }
 
 
@@ -164,6 +166,28 @@ def p3_proof_from_json(text):
     out = np.zeros(n.value, dtype=np.uint64)
     _check(lib().p25_p3_proof_from_json(text, len(text), _ptr(out), out.size, C.byref(n), C.byref(cfg)))
     return out, cfg
+
+
+def p3_prove_fibonacci(log_n=6, num_queries=100, pow_bits=16, pow_start=0, threads=None):
+    """Native plonky3 proof of the Fibonacci AIR with 2^log_n rows -> (inputs uint64[n], P3Config).
+    With the defaults it reproduces the reference's artifacts/proof_fibonacci.json bit for bit."""
+    threads = threads or min(16, os.cpu_count() or 1)
+    n = sz(0)
+    cfg = P3Config()
+    _check(lib().p25_p3_prove_fibonacci(log_n, num_queries, pow_bits, pow_start, threads, None, 0, C.byref(n), C.byref(cfg)))
+    out = np.zeros(n.value, dtype=np.uint64)
+    _check(lib().p25_p3_prove_fibonacci(log_n, num_queries, pow_bits, pow_start, threads, _ptr(out), out.size,
+                                        C.byref(n), C.byref(cfg)))
+    return out, cfg
+
+
+def p3_inputs_to_json(inputs, cfg):
+    a = _u64(inputs)
+    n = sz(0)
+    _check(lib().p25_p3_inputs_to_json(_ptr(a), a.size, C.byref(cfg), None, 0, C.byref(n)))
+    buf = C.create_string_buffer(n.value)
+    _check(lib().p25_p3_inputs_to_json(_ptr(a), a.size, C.byref(cfg), buf, n.value, C.byref(n)))
+    return buf.raw[:n.value].decode()
 
 
 class Circuit:

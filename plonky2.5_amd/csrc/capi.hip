@@ -216,6 +216,7 @@ p25_status p25_lde_commit_dev(const uint64_t* d_polys, unsigned log_n, size_t n_
 #include "circuit_io.h"
 #include "json_io.h"
 #include "p3_circuit.h"
+#include "p3_prover.h"
 #include "prover.h"
 
 struct p25_circuit {
@@ -462,6 +463,78 @@ p25_status p25_p3_proof_from_json(const char* json, size_t len, uint64_t* inputs
   if (s == P25_ERR_INVALID_ARG && p25::g_last_error.rfind("p3 proof JSON", 0) == 0) return P25_ERR_PARSE;
   return s;
 }
+static void cfg_to_c(const p25::P3Config& pc, p25_p3_config* o) {
+  o->log_blowup = pc.fri_config.log_blowup;
+  o->num_queries = pc.fri_config.num_queries;
+  o->proof_of_work_bits = pc.fri_config.proof_of_work_bits;
+  o->log_quotient_degree = pc.log_quotient_degree;
+  o->log_trace_height = pc.log_trace_height;
+  o->trace_width = pc.trace_width;
+  o->opening_matrix_log_max_height = pc.opening_matrix_log_max_height;
+  o->quotient_opened_len = pc.opening_proof_query_openings_opened_values_length;
+  o->degree_bits = pc.degree_bits;
+}
+static p25::P3Config cfg_from_c(const p25_p3_config* c) {
+  p25::P3Config pc;
+  pc.fri_config.log_blowup = c->log_blowup;
+  pc.fri_config.num_queries = c->num_queries;
+  pc.fri_config.proof_of_work_bits = c->proof_of_work_bits;
+  pc.log_quotient_degree = c->log_quotient_degree;
+  pc.log_trace_height = c->log_trace_height;
+  pc.trace_width = c->trace_width;
+  pc.opening_matrix_log_max_height = c->opening_matrix_log_max_height;
+  pc.opening_proof_query_openings_opened_values_length = c->quotient_opened_len;
+  pc.degree_bits = c->degree_bits;
+  return pc;
+}
+
+p25_status p25_p3_prove_fibonacci(int32_t log_n, int32_t num_queries, int32_t pow_bits, uint64_t pow_start,
+                                  int32_t threads, uint64_t* inputs_out, size_t cap, size_t* n_out,
+                                  p25_p3_config* cfg_out) {
+  return host_guarded([&]() -> p25_status {
+    if (!n_out) throw std::invalid_argument("null argument");
+    p25::P3ProveParams prm;
+    prm.log_n = log_n;
+    prm.num_queries = num_queries;
+    prm.pow_bits = pow_bits;
+    prm.pow_start = pow_start;
+    prm.threads = threads < 1 ? 1 : threads;
+    p25::P3Config pc;
+    pc.fri_config.num_queries = num_queries;
+    pc.log_trace_height = log_n;
+    pc.opening_matrix_log_max_height = log_n + 1;
+    pc.degree_bits = log_n;
+    if (!inputs_out) {  // size query only
+      if (log_n < 1 || log_n > 22 || num_queries < 1) throw std::invalid_argument("bad parameters");
+      *n_out = pc.num_inputs();
+      if (cfg_out) {
+        pc.fri_config.proof_of_work_bits = pow_bits;
+        cfg_to_c(pc, cfg_out);
+      }
+      return P25_OK;
+    }
+    std::vector<u64> v = p25::p3_prove_fibonacci(prm, pc);
+    *n_out = v.size();
+    if (cap < v.size()) throw std::invalid_argument("buffer too small");
+    memcpy(inputs_out, v.data(), v.size() * 8);
+    if (cfg_out) cfg_to_c(pc, cfg_out);
+    return P25_OK;
+  });
+}
+p25_status p25_p3_inputs_to_json(const uint64_t* inputs, size_t n, const p25_p3_config* cfg, char* buf,
+                                 size_t cap, size_t* len_out) {
+  return host_guarded([&]() -> p25_status {
+    if (!inputs || !cfg || !len_out) throw std::invalid_argument("null argument");
+    std::string s = p25::p3_inputs_to_json(std::vector<u64>(inputs, inputs + n), cfg_from_c(cfg));
+    *len_out = s.size();
+    if (buf) {
+      if (cap < s.size()) throw std::invalid_argument("buffer too small");
+      memcpy(buf, s.data(), s.size());
+    }
+    return P25_OK;
+  });
+}
+
 p25_status p25_proof_to_json(p25_circuit* c, const uint64_t* proof, char* buf, size_t cap, size_t* len_out) {
   return host_guarded([&]() -> p25_status {
     if (!c || !proof || !len_out) throw std::invalid_argument("null argument");

@@ -169,7 +169,9 @@ static void split(int log_n, int& log_r1, int& log_r2) {
     log_r2 = (log_n + 1) / 2;  // pass-1 sub-transform (over k2)
     log_r1 = log_n - log_r2;   // pass-2 sub-transform (over k1)
   }
-  if (log_r1 > 10 || log_r2 > 10) throw std::runtime_error("NTT size above 2^20 not supported");
+  // sub-transforms of up to 2^11 points (56 KB of LDS with a 2-wide tile): transforms up to 2^22,
+  // i.e. the 8n-point quotient iNTT of a 2^19-row circuit (BASELINE config 5)
+  if (log_r1 > 11 || log_r2 > 11) throw std::runtime_error("NTT size above 2^22 not supported");
 }
 
 void ntt_inverse(NttTables& tb, const u64* d_in, size_t in_stride, bool in_bitrev, u64* d_tmp,

@@ -1,0 +1,453 @@
+// See p3_prover.h.
+#include "p3_prover.h"
+#include <array>
+#include <functional>
+#include <stdexcept>
+#include <thread>
+#include "poseidon2.h"
+
+namespace p25 {
+namespace {
+using gl::E2;
+typedef std::array<u64, 4> Digest;
+
+void parallel_for(int threads, size_t n, const std::function<void(size_t, size_t)>& f) {
+  if (threads <= 1 || n < 1024) {
+    f(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  size_t chunk = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; t++) {
+    size_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b >= e) break;
+    th.emplace_back([=, &f] { f(b, e); });
+  }
+  for (auto& x : th) x.join();
+}
+
+// natural-order radix-2 NTT with the primitive root `w` of order a.size()
+void ntt(std::vector<u64>& a, u64 w) {
+  const size_t n = a.size();
+  unsigned lg = 0;
+  while (((size_t)1 << lg) < n) lg++;
+  for (size_t i = 0; i < n; i++) {
+    size_t j = gl::bitrev((u32)i, lg);
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  std::vector<u64> tw(n / 2 ? n / 2 : 1);
+  tw[0] = 1;
+  for (size_t i = 1; i < n / 2; i++) tw[i] = gl::mul(tw[i - 1], w);
+  for (size_t len = 1; len < n; len <<= 1) {
+    size_t step = n / (2 * len);
+    for (size_t s = 0; s < n; s += 2 * len)
+      for (size_t j = 0; j < len; j++) {
+        u64 u = a[s + j], v = gl::mul(a[s + j + len], tw[j * step]);
+        a[s + j] = gl::add(u, v);
+        a[s + j + len] = gl::sub(u, v);
+      }
+  }
+}
+void intt(std::vector<u64>& a) {
+  unsigned lg = 0;
+  while (((size_t)1 << lg) < a.size()) lg++;
+  ntt(a, gl::inv(gl::root_of_unity(lg)));
+  u64 ni = gl::inv((u64)a.size());
+  for (auto& x : a) x = gl::mul(x, ni);
+}
+// values of the polynomial with coefficients c (len n) on shift*<w_{2n}>, natural order
+std::vector<u64> lde2(const std::vector<u64>& c, u64 shift) {
+  const size_t n = c.size();
+  std::vector<u64> v(2 * n, 0);
+  u64 p = 1;
+  for (size_t k = 0; k < n; k++) {
+    v[k] = gl::mul(c[k], p);
+    p = gl::mul(p, shift);
+  }
+  unsigned lg = 0;
+  while (((size_t)1 << lg) < 2 * n) lg++;
+  ntt(v, gl::root_of_unity(lg));
+  return v;
+}
+E2 eval_ext(const std::vector<u64>& c, E2 x) {
+  E2 acc = gl::e2(0);
+  for (size_t i = c.size(); i-- > 0;) {
+    acc = gl::mul(acc, x);
+    acc.a = gl::add(acc.a, c[i]);
+  }
+  return acc;
+}
+
+// src/p3/challenger.rs:70-169
+struct Challenger {
+  u64 st[12] = {0};
+  std::vector<u64> in, out;
+  void duplex() {
+    for (size_t i = 0; i < in.size(); i++) st[i] = in[i];
+    in.clear();
+    poseidon2::permute(st);
+    out.assign(st, st + 12);
+  }
+  void observe(u64 x) {
+    out.clear();
+    in.push_back(x);
+    if (in.size() == 12) duplex();
+  }
+  void observe_digest(const Digest& d) {
+    for (u64 x : d) observe(x);
+  }
+  u64 sample() {
+    if (!in.empty() || out.empty()) duplex();
+    u64 v = out.back();
+    out.pop_back();
+    return v;
+  }
+  E2 sample_ext() {
+    u64 a = sample();
+    u64 b = sample();
+    return E2{a, b};
+  }
+  u64 sample_bits(int bits) { return sample() & (((u64)1 << bits) - 1); }
+};
+
+// src/p3/commit.rs:23-60
+Digest hash_row(const u64* row, size_t w) {
+  u64 st[12] = {0};
+  for (size_t off = 0; off < w; off += 4) {
+    size_t m = std::min((size_t)4, w - off);
+    for (size_t i = 0; i < m; i++) st[i] = row[off + i];
+    poseidon2::permute(st);
+  }
+  return Digest{st[0], st[1], st[2], st[3]};
+}
+Digest compress(const Digest& l, const Digest& r) {
+  u64 st[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
+  poseidon2::permute(st);
+  return Digest{st[0], st[1], st[2], st[3]};
+}
+struct Tree {
+  std::vector<std::vector<Digest>> levels;  // levels[0] leaves ... back() = root
+  const Digest& root() const { return levels.back()[0]; }
+  std::vector<Digest> prove(size_t index) const {
+    std::vector<Digest> p;
+    for (size_t k = 0; k + 1 < levels.size(); k++) p.push_back(levels[k][(index >> k) ^ 1]);
+    return p;
+  }
+};
+// rows: row-major matrix [height][width]
+Tree commit(const std::vector<u64>& rows, size_t width, int threads) {
+  const size_t h = rows.size() / width;
+  Tree t;
+  t.levels.emplace_back(h);
+  parallel_for(threads, h, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; i++) t.levels[0][i] = hash_row(&rows[i * width], width);
+  });
+  while (t.levels.back().size() > 1) {
+    const auto& cur = t.levels.back();
+    std::vector<Digest> nxt(cur.size() / 2);
+    parallel_for(threads, nxt.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i++) nxt[i] = compress(cur[2 * i], cur[2 * i + 1]);
+    });
+    t.levels.push_back(std::move(nxt));
+  }
+  return t;
+}
+}  // namespace
+
+std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg) {
+  if (prm.log_n < 1 || prm.log_n > 22 || prm.log_blowup != 1 || prm.num_queries < 1 || prm.pow_bits < 0 || prm.pow_bits > 30)
+    throw std::invalid_argument("p3_prove_fibonacci: unsupported parameters");
+  const int k = prm.log_n, L = k + 1, T = prm.threads;
+  const size_t n = (size_t)1 << k, N2 = 2 * n;
+  const u64 w_n = gl::root_of_unity(k), w_2n = gl::root_of_unity(L);
+  const int W = 3;
+
+  // trace (src/p3/mod.rs:160-221): a, b, c = a + b; next a = b, next b = c; first row (1, 1)
+  std::vector<std::vector<u64>> col(W, std::vector<u64>(n));
+  {
+    u64 a = 1, b = 1;
+    for (size_t i = 0; i < n; i++) {
+      u64 c = gl::add(a, b);
+      col[0][i] = a;
+      col[1][i] = b;
+      col[2][i] = c;
+      a = b;
+      b = c;
+    }
+  }
+  std::vector<std::vector<u64>> coef(col);
+  for (auto& c : coef) intt(c);
+  // LDE on 7*H_{2n}: natural order, then the committed matrix in bit-reversed row order
+  std::vector<std::vector<u64>> lde_nat(W);
+  for (int c = 0; c < W; c++) lde_nat[c] = lde2(coef[c], gl::GENERATOR);
+  std::vector<u64> trace_rows(N2 * W);
+  for (size_t i = 0; i < N2; i++) {
+    size_t r = gl::bitrev((u32)i, L);
+    for (int c = 0; c < W; c++) trace_rows[i * W + c] = lde_nat[c][r];
+  }
+  Tree trace_tree = commit(trace_rows, W, T);
+
+  Challenger ch;
+  ch.observe_digest(trace_tree.root());
+  const E2 alpha = ch.sample_ext();
+
+  // quotient on the disjoint coset 7*H_n (points x_j = 7 w_n^j = LDE natural index 2j)
+  std::vector<u64> q0(n), q1(n);
+  {
+    const u64 g_inv = gl::inv(w_n);
+    const u64 zh = gl::sub(gl::pow(gl::GENERATOR, n), 1);  // x^n - 1 is constant on the coset
+    const u64 zh_inv = gl::inv(zh);
+    u64 x = gl::GENERATOR;
+    for (size_t j = 0; j < n; j++, x = gl::mul(x, w_n)) {
+      const size_t i0 = 2 * j, i1 = (2 * j + 2) % N2;
+      u64 la = lde_nat[0][i0], lb = lde_nat[1][i0], lc = lde_nat[2][i0];
+      u64 na = lde_nat[0][i1], nb = lde_nat[1][i1];
+      u64 is_first = gl::mul(zh, gl::inv(gl::sub(x, 1)));
+      u64 is_trans = gl::sub(x, g_inv);
+      u64 cons[5] = {gl::sub(gl::add(la, lb), lc), gl::mul(is_first, gl::sub(1, la)), gl::mul(is_first, gl::sub(1, lb)),
+                     gl::mul(is_trans, gl::sub(na, lb)), gl::mul(is_trans, gl::sub(nb, lc))};
+      E2 acc = gl::e2(0);
+      for (u64 c : cons) {  // VerifierConstraintFolder::assert_zero: acc = acc * alpha + c
+        acc = gl::mul(acc, alpha);
+        acc.a = gl::add(acc.a, c);
+      }
+      E2 q = gl::mul(acc, zh_inv);
+      q0[j] = q.a;
+      q1[j] = q.b;
+    }
+  }
+  // quotient chunk matrix (one chunk, 2 base columns): P'(h) = q(7h); LDE on H_{2n} = q on 7*H_{2n}
+  std::vector<u64> qc0(q0), qc1(q1);
+  intt(qc0);
+  intt(qc1);
+  std::vector<u64> ql0 = lde2(qc0, 1), ql1 = lde2(qc1, 1);
+  std::vector<u64> quot_rows(N2 * 2);
+  for (size_t i = 0; i < N2; i++) {
+    size_t r = gl::bitrev((u32)i, L);
+    quot_rows[2 * i] = ql0[r];
+    quot_rows[2 * i + 1] = ql1[r];
+  }
+  Tree quot_tree = commit(quot_rows, 2, T);
+  ch.observe_digest(quot_tree.root());
+  const E2 zeta = ch.sample_ext();
+  const E2 zeta_next = gl::mul(zeta, w_n);
+
+  // opened values
+  std::vector<E2> t_local(W), t_next(W);
+  for (int c = 0; c < W; c++) {
+    t_local[c] = eval_ext(coef[c], zeta);
+    t_next[c] = eval_ext(coef[c], zeta_next);
+  }
+  const E2 zeta_over_shift = gl::mul(zeta, gl::inv(gl::GENERATOR));
+  const E2 qz[2] = {eval_ext(qc0, zeta_over_shift), eval_ext(qc1, zeta_over_shift)};
+  {  // self-check of the identity the verifier enforces (verifier.rs:199-239)
+    E2 un = zeta;
+    E2 z_h = gl::sub(gl::exp_pow2(un, k), gl::e2(1));
+    E2 is_first = gl::mul(z_h, gl::inv(gl::sub(un, gl::e2(1))));
+    E2 is_trans = gl::sub(un, gl::e2(gl::inv(w_n)));
+    E2 one = gl::e2(1);
+    E2 cons[5] = {gl::sub(gl::add(t_local[0], t_local[1]), t_local[2]), gl::mul(is_first, gl::sub(one, t_local[0])),
+                  gl::mul(is_first, gl::sub(one, t_local[1])), gl::mul(is_trans, gl::sub(t_next[0], t_local[1])),
+                  gl::mul(is_trans, gl::sub(t_next[1], t_local[2]))};
+    E2 acc = gl::e2(0);
+    for (auto& c : cons) acc = gl::add(gl::mul(acc, alpha), c);
+    E2 lhs = gl::mul(acc, gl::inv(z_h));
+    E2 rhs = gl::add(qz[0], gl::mul(qz[1], E2{0, 1}));
+    if (!gl::eq(lhs, rhs)) throw std::logic_error("p3 prover: quotient identity does not hold");
+  }
+
+  // FRI input: reduced openings on the LDE domain, bit-reversed index (verifier.rs:296-338)
+  const E2 fri_alpha = ch.sample_ext();
+  std::vector<E2> folded(N2);
+  {
+    std::vector<E2> apow(8);
+    apow[0] = gl::e2(1);
+    for (int i = 1; i < 8; i++) apow[i] = gl::mul(apow[i - 1], fri_alpha);
+    parallel_for(T, N2, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i++) {
+        size_t r = gl::bitrev((u32)i, L);
+        u64 x = gl::mul(gl::GENERATOR, gl::pow(w_2n, r));
+        E2 inv_z = gl::inv(gl::sub(gl::e2(x), zeta));
+        E2 inv_zn = gl::inv(gl::sub(gl::e2(x), zeta_next));
+        E2 acc = gl::e2(0);
+        int t = 0;
+        for (int c = 0; c < W; c++, t++)
+          acc = gl::add(acc, gl::mul(apow[t], gl::mul(gl::sub(gl::e2(trace_rows[i * W + c]), t_local[c]), inv_z)));
+        for (int c = 0; c < W; c++, t++)
+          acc = gl::add(acc, gl::mul(apow[t], gl::mul(gl::sub(gl::e2(trace_rows[i * W + c]), t_next[c]), inv_zn)));
+        for (int c = 0; c < 2; c++, t++)
+          acc = gl::add(acc, gl::mul(apow[t], gl::mul(gl::sub(gl::e2(quot_rows[2 * i + c]), qz[c]), inv_z)));
+        folded[i] = acc;
+      }
+    });
+  }
+  // commit phase (verifier.rs:357-388 transcript, 441-516 fold)
+  std::vector<Tree> fri_trees;
+  std::vector<std::vector<E2>> fri_layers;
+  {
+    size_t m = N2;
+    int lm = L;
+    for (int round = 0; round < k; round++) {
+      std::vector<u64> rows(m * 2);
+      for (size_t i = 0; i < m; i++) {
+        rows[2 * i] = folded[i].a;
+        rows[2 * i + 1] = folded[i].b;
+      }
+      fri_layers.push_back(folded);
+      fri_trees.push_back(commit(rows, 4, T));
+      ch.observe_digest(fri_trees.back().root());
+      const E2 beta = ch.sample_ext();
+      const u64 w_m = gl::root_of_unity(lm);
+      std::vector<E2> nxt(m / 2);
+      parallel_for(T, m / 2, [&](size_t b, size_t e) {
+        for (size_t j = b; j < e; j++) {
+          u64 x = gl::pow(w_m, gl::bitrev((u32)(2 * j), lm));
+          E2 e0 = folded[2 * j], e1 = folded[2 * j + 1];
+          // evals[0] + (beta - xs[0]) * (evals[1] - evals[0]) / (xs[1] - xs[0]),  xs = (x, -x)
+          E2 num = gl::mul(gl::sub(e1, e0), gl::sub(beta, gl::e2(x)));
+          u64 den_inv = gl::inv(gl::sub(gl::neg(x), x));
+          nxt[j] = gl::add(e0, gl::mul(num, den_inv));
+        }
+      });
+      folded.swap(nxt);
+      m >>= 1;
+      lm--;
+    }
+    if (folded.size() != 2 || !gl::eq(folded[0], folded[1])) throw std::logic_error("p3 prover: FRI did not fold to a constant");
+  }
+  const E2 final_poly = folded[0];
+  // proof of work (challenger.rs:159-168): observe the witness, sample_bits(pow_bits) must be 0
+  u64 pow_witness = prm.pow_start;
+  for (;; pow_witness++) {
+    if (pow_witness >= gl::P) throw std::logic_error("p3 prover: no PoW witness");
+    Challenger c2 = ch;
+    c2.observe(pow_witness);
+    if (c2.sample_bits(prm.pow_bits) == 0) break;
+  }
+  ch.observe(pow_witness);
+  (void)ch.sample_bits(prm.pow_bits);
+  std::vector<size_t> indices(prm.num_queries);
+  for (auto& ix : indices) ix = (size_t)ch.sample_bits(L);
+
+  // flatten in add_virtual_to order (proof.rs:357-373)
+  cfg = P3Config();
+  cfg.fri_config.log_blowup = prm.log_blowup;
+  cfg.fri_config.num_queries = prm.num_queries;
+  cfg.fri_config.proof_of_work_bits = prm.pow_bits;
+  cfg.log_quotient_degree = 0;
+  cfg.log_trace_height = k;
+  cfg.trace_width = W;
+  cfg.opening_matrix_log_max_height = L;
+  cfg.opening_proof_query_openings_opened_values_length = 2;
+  cfg.degree_bits = k;
+  std::vector<u64> out;
+  auto push_d = [&](const Digest& d) { out.insert(out.end(), d.begin(), d.end()); };
+  auto push_e = [&](E2 e) {
+    out.push_back(e.a);
+    out.push_back(e.b);
+  };
+  push_d(trace_tree.root());
+  push_d(quot_tree.root());
+  for (auto& e : t_local) push_e(e);
+  for (auto& e : t_next) push_e(e);
+  push_e(qz[0]);
+  push_e(qz[1]);
+  for (auto& t : fri_trees) push_d(t.root());
+  for (size_t ix : indices) {
+    size_t idx = ix;
+    for (int round = 0; round < k; round++) {
+      size_t sib = idx ^ 1, pair = idx >> 1;
+      push_e(fri_layers[round][sib]);
+      for (auto& d : fri_trees[round].prove(pair)) push_d(d);
+      idx = pair;
+    }
+  }
+  push_e(final_poly);
+  out.push_back(pow_witness);
+  for (size_t ix : indices) {
+    for (int c = 0; c < W; c++) out.push_back(trace_rows[ix * W + c]);
+    for (auto& d : trace_tree.prove(ix)) push_d(d);
+    out.push_back(quot_rows[2 * ix]);
+    out.push_back(quot_rows[2 * ix + 1]);
+    for (auto& d : quot_tree.prove(ix)) push_d(d);
+  }
+  if (out.size() != cfg.num_inputs()) throw std::logic_error("p3 prover: flattened size mismatch");
+  return out;
+}
+
+std::string p3_inputs_to_json(const std::vector<u64>& in, const P3Config& cfg) {
+  if (in.size() != cfg.num_inputs()) throw std::invalid_argument("input vector does not match the shape");
+  size_t pos = 0;
+  std::string s;
+  auto fe = [&]() { s += "{\"value\":" + std::to_string(in[pos++]) + "}"; };
+  auto arr = [&](size_t n) {
+    s += '[';
+    for (size_t i = 0; i < n; i++) {
+      if (i) s += ',';
+      fe();
+    }
+    s += ']';
+  };
+  auto val = [&](size_t n) {
+    s += "{\"value\":";
+    arr(n);
+    s += '}';
+  };
+  auto list = [&](size_t n, const std::function<void()>& f) {
+    s += '[';
+    for (size_t i = 0; i < n; i++) {
+      if (i) s += ',';
+      f();
+    }
+    s += ']';
+  };
+  const int k = cfg.log_trace_height;
+  s += "{\"commitments\":{\"trace\":";
+  val(4);
+  s += ",\"quotient_chunks\":";
+  val(4);
+  s += "},\"opened_values\":{\"trace_local\":";
+  list(cfg.trace_width, [&] { val(2); });
+  s += ",\"trace_next\":";
+  list(cfg.trace_width, [&] { val(2); });
+  s += ",\"quotient_chunks\":[";
+  list(2, [&] { val(2); });
+  s += "]},\"opening_proof\":{\"fri_proof\":{\"commit_phase_commits\":";
+  list(k, [&] { val(4); });
+  s += ",\"query_proofs\":";
+  list(cfg.fri_config.num_queries, [&] {
+    s += "{\"commit_phase_openings\":";
+    int i = 0;
+    list(k, [&] {
+      s += "{\"sibling_value\":";
+      val(2);
+      s += ",\"opening_proof\":";
+      list(k - i, [&] { arr(4); });
+      s += '}';
+      i++;
+    });
+    s += '}';
+  });
+  s += ",\"final_poly\":";
+  val(2);
+  s += ",\"pow_witness\":";
+  fe();
+  s += "},\"query_openings\":";
+  list(cfg.fri_config.num_queries, [&] {
+    int widths[2] = {cfg.trace_width, cfg.opening_proof_query_openings_opened_values_length};
+    int b = 0;
+    list(2, [&] {
+      s += "{\"opened_values\":[";
+      arr(widths[b]);
+      s += "],\"opening_proof\":";
+      list(cfg.opening_matrix_log_max_height, [&] { arr(4); });
+      s += '}';
+      b++;
+    });
+  });
+  s += "},\"degree_bits\":" + std::to_string(cfg.degree_bits) + "}";
+  if (pos != in.size()) throw std::logic_error("p3 json: size mismatch");
+  return s;
+}
+
+}  // namespace p25
