@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="proofs per GPU per step")
+    ap.add_argument("--log-n", type=int, default=6, help="log2 rows of the inner Fibonacci STARK (6 = the artifact)")
+    ap.add_argument("--distinct", type=int, default=8, help="number of distinct plonky3 proofs cycled through the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = all host cores)")
     args = ap.parse_args()
@@ -57,18 +59,30 @@ def main():
     p25 = ge.load_package()
     p25.device_init(local_rank)
     import p3json
-    inputs, _shape = p3json.load(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json"))
+    if args.log_n == 6:
+        inputs, _shape = p3json.load(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json"))
+        p3cfg = p25.P3Config.fib64()
+    else:  # BASELINE config 5 and friends: inner STARK with 2^log_n rows from the native plonky3 prover
+        inputs, p3cfg = p25.p3_prove_fibonacci(args.log_n, 100, 16, threads=os.cpu_count() or 1)
+    # distinct batch items: further valid plonky3 proofs of the same statement (other PoW witnesses ->
+    # other query indices); the reference artifact is item 0 for log_n = 6
+    variants = [inputs]
+    for v in range(1, max(1, min(args.distinct, args.batch))):
+        alt, _ = p25.p3_prove_fibonacci(args.log_n, 100, 16, pow_start=(v << 24) + rank * (1 << 20),
+                                        threads=os.cpu_count() or 1)
+        variants.append(alt)
 
     # circuit: built once per shape by the host code, tables made resident on the GPU
     t0 = time.time()
-    circuit = p25.Circuit.build_p3_verifier(p25.P3Config.fib64())
+    circuit = p25.Circuit.build_p3_verifier(p3cfg)
     info = circuit.info
     digest, cs_cap = circuit.digest()  # forces the device-side tables (constants/sigmas commitment)
     build_s = time.time() - t0
     B = args.batch
     ni, pw = int(info.num_inputs), int(info.proof_words)
     dev = torch.device("cuda", local_rank)
-    d_inputs = torch.from_numpy(np.tile(inputs.view(np.int64), (B, 1))).to(dev)            # [B][ni]
+    host_in = np.stack([variants[i % len(variants)] for i in range(B)]).view(np.int64)
+    d_inputs = torch.from_numpy(host_in).to(dev)                                           # [B][ni]
     d_seeds = (torch.arange(B, dtype=torch.int64) + rank * B).to(dev)                      # distinct filler seeds
     d_proofs = torch.zeros((B, pw), dtype=torch.int64, device=dev)
     d_status = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -140,7 +154,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64 (Goldilocks, p = 2^64 - 2^32 + 1)",
-            "data": "synthetic: artifacts/proof_fibonacci.json (the unique fib-64 plonky3 proof) replicated, distinct filler seeds",
+            "data": f"synthetic: {len(variants)} distinct plonky3 proofs of fibonacci(2^{args.log_n}) "
+                    "(item 0 = the reference's artifacts/proof_fibonacci.json for log_n 6; the others from the native "
+                    "p3 prover with other PoW witnesses) cycled through the batch, distinct filler seeds",
             "config": {"workload": f"batch of {B} independent fib-64 plonky3-verifier proofs per GPU "
                                    f"(n = 2^{int(info.degree_bits)} rows x 135 wires, LDE 2^{int(info.degree_bits) + 3}), "
                                    f"{world} GPU(s), replicas + RCCL gather",
