@@ -169,7 +169,7 @@ def main():
                          "avg_launch_ms": avg_ms, "launches": int(k_launches), "algorithmic_bytes": algo_bytes,
                          "note": "integer-VALU bound (17 Poseidon permutations per leaf), not HBM bound"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0, N = 1 only
             threads = args.cpu_threads or (os.cpu_count() or 1)
             ora.set_threads(threads)
             oc.digest()  # constants/sigmas commitment is per-circuit, excluded like the reference's build()

@@ -13,6 +13,9 @@ extern "C" {
 void p25o_poseidon_permute(u64* states, size_t n) {
   for (size_t i = 0; i < n; i++) ref_poseidon(states + 12 * i);
 }
+void p25o_poseidon_permute_naive(u64* states, size_t n) {
+  for (size_t i = 0; i < n; i++) ref_poseidon_naive(states + 12 * i);
+}
 void p25o_poseidon2_permute(u64* states, size_t n) {
   for (size_t i = 0; i < n; i++) ref_poseidon2(states + 12 * i);
 }

@@ -19,14 +19,16 @@ static const u64 RP = 0xFFFFFFFF00000001ULL;
 
 static inline u64 rf_reduce(u128 x) {
   // 2^64 = 2^32 - 1, 2^96 = -1 (mod p):  x = x0 + x1*2^64 + x2*2^96 with x1 < 2^32, x2 < 2^32
+  // (64-bit carry/borrow form of the identity above -- the shape of upstream's `reduce128` --
+  // so that the timed CPU baseline is not handicapped by 128-bit compare/subtract loops)
   u64 x0 = (u64)x;
   u64 x1 = (u64)(x >> 64) & 0xFFFFFFFFULL;
   u64 x2 = (u64)(x >> 96);
-  u128 pos = (u128)x0 + (u128)x1 * 0xFFFFFFFFULL + (u128)RP;  // + p keeps it positive
-  pos -= x2;
-  // pos < 2^64 + 2^64 + 2^64: at most a few subtractions
-  while (pos >= RP) pos -= RP;
-  return (u64)pos;
+  u64 t0, r;
+  if (__builtin_sub_overflow(x0, x2, &t0)) t0 -= 0xFFFFFFFFULL;   // borrowed 2^64 = 2^32 - 1 (mod p)
+  u64 t1 = x1 * 0xFFFFFFFFULL;
+  if (__builtin_add_overflow(t0, t1, &r)) r += 0xFFFFFFFFULL;     // carried 2^64
+  return r >= RP ? r - RP : r;
 }
 static inline u64 rf_add(u64 a, u64 b) {
   u128 s = (u128)a + b;

@@ -15,17 +15,77 @@ static u64 pow7(u64 x) {
 }
 
 static void poseidon_mds(u64 s[12]) {
-  u64 o[12];
+  // out[r] = sum_i s[(i+r)%12]*CIRC[i] + s[r]*DIAG[r].  The 32-bit halves are accumulated separately
+  // in 64-bit integers (entries <= 41, 13 terms: no overflow) -- same value as the 128-bit sum, but
+  // without 128-bit multiplies, so the CPU baseline is not needlessly slow.
+  u64 lo[24], hi[24], o[12];
+  for (int i = 0; i < 12; i++) {
+    lo[i] = lo[i + 12] = s[i] & 0xFFFFFFFFull;
+    hi[i] = hi[i + 12] = s[i] >> 32;
+  }
   for (int r = 0; r < 12; r++) {
-    u128 acc = 0;
-    for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * MDS_CIRC[i];
-    acc += (u128)s[r] * MDS_DIAG[r];
-    o[r] = rf_reduce(acc);
+    u64 al = lo[r] * MDS_DIAG[r], ah = hi[r] * MDS_DIAG[r];
+    for (int i = 0; i < 12; i++) {
+      al += lo[i + r] * MDS_CIRC[i];
+      ah += hi[i + r] * MDS_CIRC[i];
+    }
+    o[r] = rf_reduce((u128)al + ((u128)ah << 32));
   }
   memcpy(s, o, sizeof(o));
 }
 
+// Same permutation with the 22 partial rounds in the "optimised" form of the Poseidon paper (what
+// upstream's CPU code does: partial_first_constant_layer, mds_partial_layer_init, then per round one
+// S-box, one scalar constant and a sparse matrix).  Constants derived from the naive definition and
+// verified against it by tools/gen_poseidon_fast.py; ref_poseidon_naive below is the definition.
+namespace pf {
+#include "poseidon_fast_constants.inc"
+}
+static inline u64 red_acc(u128 acc, u32 ov) {
+  // acc + ov * 2^128, with 2^128 = -2^32 (mod p)
+  return rf_sub(rf_reduce(acc), rf_mul(ov, (u64)1 << 32));
+}
 void ref_poseidon(u64 s[12]) {
+  int r = 0;
+  for (; r < 4; r++) {
+    for (int i = 0; i < 12; i++) s[i] = pow7(rf_add(s[i], POSEIDON_RC[12 * r + i]));
+    poseidon_mds(s);
+  }
+  for (int i = 0; i < 12; i++) s[i] = rf_add(s[i], pf::PF_FIRST[i]);
+  {
+    u64 t[11];
+    for (int c = 0; c < 11; c++) {
+      u128 acc = 0;
+      u32 ov = 0;
+      for (int k = 0; k < 11; k++) {
+        u128 p = (u128)s[k + 1] * pf::PF_INIT[k * 11 + c];
+        acc += p;
+        ov += acc < p;
+      }
+      t[c] = red_acc(acc, ov);
+    }
+    memcpy(s + 1, t, sizeof(t));
+  }
+  for (int i = 0; i < 22; i++) {
+    u64 s0 = rf_add(pow7(s[0]), pf::PF_SCALAR[i]);
+    u128 acc = (u128)s0 * 25;  // m00 = MDS_CIRC[0] + MDS_DIAG[0]
+    u32 ov = 0;
+    for (int j = 0; j < 11; j++) {
+      u128 p = (u128)s[j + 1] * pf::PF_VHAT[i * 11 + j];
+      acc += p;
+      ov += acc < p;
+    }
+    for (int j = 0; j < 11; j++) s[j + 1] = rf_reduce((u128)s0 * pf::PF_W[i * 11 + j] + s[j + 1]);
+    s[0] = red_acc(acc, ov);
+  }
+  r += 22;
+  for (; r < 30; r++) {
+    for (int i = 0; i < 12; i++) s[i] = pow7(rf_add(s[i], POSEIDON_RC[12 * r + i]));
+    poseidon_mds(s);
+  }
+}
+
+void ref_poseidon_naive(u64 s[12]) {
   for (int r = 0; r < 30; r++) {
     for (int i = 0; i < 12; i++) s[i] = rf_add(s[i], POSEIDON_RC[12 * r + i]);
     if (r < 4 || r >= 26) {

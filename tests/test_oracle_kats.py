@@ -80,3 +80,18 @@ def test_ntt_roundtrip_and_lde(oracle):
             for ck in reversed(c):
                 acc = (acc * x + ck) % P
             assert acc == int(vals[p][i])
+
+
+def test_poseidon_fast_form_equals_definition(oracle):
+    """The oracle's timed permutation (optimised partial rounds, as upstream's CPU code) equals the
+    naive definition on random states; both are pinned by the KATs above."""
+    import ctypes as C
+    oracle.lib.p25o_poseidon_permute_naive.argtypes = [C.c_void_p, C.c_size_t]
+    from conftest import splitmix_field
+    s = splitmix_field(12 * 4000, seed=99).reshape(-1, 12)
+    s[0, :] = 0
+    s[1, :] = P - 1
+    a = oracle.poseidon_permute(s)
+    b = s.copy()
+    oracle.lib.p25o_poseidon_permute_naive(b.ctypes.data, len(b))
+    assert (a == b).all()

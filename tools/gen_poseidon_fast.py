@@ -118,6 +118,8 @@ if __name__ == "__main__":
             arr("PF_INIT", [init[cidx][r] for r in range(T - 1) for cidx in range(T - 1)]) +
             arr("PF_VHAT", [x for i in range(RP) for x in vhat[i]]) +
             arr("PF_W", [x for i in range(RP) for x in wcol[i]]))
-    if "--write" in sys.argv:  # experiment only: the product uses the dense form (measured faster on MI355X)
-        open(os.path.join(root, "plonky2.5_amd/csrc/poseidon_fast_constants.inc"), "w").write(body)
+    # The GPU product uses the dense form (measured faster on MI355X: 128-bit carry chains are costly
+    # there).  The CPU oracle uses this form -- it is what upstream's CPU prover does, and 64x64->128
+    # multiplies are cheap on x86 -- so that the timed CPU baseline is not a strawman.
+    open(os.path.join(root, "oracle/poseidon_fast_constants.inc"), "w").write(body)
     print("ok: fast form == naive on", len(tests), "states incl. 4 KATs; m00 =", m00[0])
