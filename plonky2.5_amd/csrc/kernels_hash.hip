@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include "poseidon.h"
 #include "poseidon2.h"
+#include "coop.h"
 
 namespace p25 {
 
@@ -39,7 +40,10 @@ __global__ __launch_bounds__(256) void k_poseidon2_permute(u64* states, size_t n
 }
 
 // digests[l] = hash_or_noop(leaf l), leaf l = (cols[c*col_stride + l])_{c < width}
-__global__ __launch_bounds__(256) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
+// 64-lane workgroups: the kernel is a pure per-lane VALU loop (~340k instructions per lane), and one
+// wave per workgroup lets the dispatcher back-fill SIMDs as soon as a single wave retires -- measured
+// 6.31 -> 5.77 ms on the 2^19 x 135 matrix (tools/hashbench.hip), the register-only ceiling being 5.74 ms.
+__global__ __launch_bounds__(64) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
                                                      int width, size_t n_leaves,
                                                      u64* __restrict__ digests) {
   size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256) void k_hash_leaves(const u64* __restrict__ col
 }
 
 // parents[m] = two_to_one(children[2m], children[2m+1])
-__global__ __launch_bounds__(256) void k_tree_level(const u64* __restrict__ children,
+__global__ __launch_bounds__(64) void k_tree_level(const u64* __restrict__ children,
                                                     u64* __restrict__ parents, size_t n_parents) {
   size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n_parents) return;
@@ -65,6 +69,29 @@ __global__ __launch_bounds__(256) void k_tree_level(const u64* __restrict__ chil
   poseidon::two_to_one(l, r, o);
 #pragma unroll
   for (int i = 0; i < 4; i++) parents[4 * m + i] = o[i];
+}
+
+// Same, one 16-lane group per parent (coop.h): used for the small top levels of a tree, where a level
+// is a handful of hashes and its latency, not its throughput, is what the proof waits for.
+__global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__ children,
+                                                         u64* __restrict__ parents, size_t n_parents) {
+  __shared__ u64 rc_lds[360];
+  coop::stage_poseidon_rc(rc_lds);
+  size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / coop::GROUP;
+  const int rr = threadIdx.x & (coop::GROUP - 1);
+  const bool valid = g < n_parents;
+  if (!valid) g = n_parents - 1;  // keep every lane in the shuffles
+  u64 s = rr < 8 ? children[8 * g + rr] : 0;
+  s = coop::poseidon_permute(s, threadIdx.x & 63, rc_lds);
+  if (valid && rr < 4) parents[4 * g + rr] = s;
+}
+static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st) {
+  if (m <= 4096) {
+    size_t th = m * coop::GROUP;
+    hipLaunchKernelGGL(k_tree_level_coop, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, cur, nxt, m);
+  } else {
+    hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, cur, nxt, m);
+  }
 }
 
 void launch_poseidon_permute(u64* d_states, size_t n, hipStream_t st) {
@@ -100,7 +127,7 @@ u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t 
                         unsigned cap_height, u64* d_tree, hipStream_t st, hipEvent_t ev_begin,
                         hipEvent_t ev_end) {
   if (ev_begin) (void)hipEventRecord(ev_begin, st);
-  hipLaunchKernelGGL(k_hash_leaves, dim3((unsigned)((n_leaves + 255) / 256)), dim3(256), 0, st, d_cols,
+  hipLaunchKernelGGL(k_hash_leaves, dim3((unsigned)((n_leaves + 63) / 64)), dim3(64), 0, st, d_cols,
                      col_stride, width, n_leaves, d_tree);
   if (ev_end) (void)hipEventRecord(ev_end, st);
   u64* cur = d_tree;
@@ -108,7 +135,7 @@ u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t 
   while (m > ((size_t)1 << cap_height)) {
     u64* nxt = cur + 4 * m;
     m >>= 1;
-    hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, cur, nxt, m);
+    launch_level(cur, nxt, m, st);
     cur = nxt;
   }
   return cur;
@@ -121,7 +148,7 @@ void launch_tree_from_digests(u64* d_tree, size_t n_leaves, unsigned cap_height,
   while (m > ((size_t)1 << cap_height)) {
     u64* nxt = cur + 4 * m;
     m >>= 1;
-    hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, cur, nxt, m);
+    launch_level(cur, nxt, m, st);
     cur = nxt;
   }
 }

@@ -13,55 +13,22 @@
 // reads (ds_bpermute) + multiply-adds per lane.  That cuts a permutation's dependent chain from
 // ~1.5k modular multiplies (one lane doing all 12 state words) to ~30 x (4 + MDS), i.e. a few us.
 #include "kernels.h"
-#include "poseidon.h"
+#include "coop.h"
 #include "prover_kernels.h"
 
 namespace p25 {
 
-__device__ __forceinline__ u64 shfl64(u64 v, int src) {
-  u32 lo = (u32)v, hi = (u32)(v >> 32);
-  lo = __shfl(lo, src);
-  hi = __shfl(hi, src);
-  return ((u64)hi << 32) | lo;
-}
-
-// lane r < 12 holds state word r (canonical); returns the permuted word (canonical)
-__device__ u64 coop_permute(u64 s, int lane) {
-  const int r = lane < 12 ? lane : 0;
-  for (int rd = 0; rd < poseidon::N_ROUNDS; rd++) {
-    u64 t = poseidon::add_rc(s, poseidon::RC[12 * rd + r]);
-    bool full = rd < poseidon::HALF_FULL || rd >= poseidon::HALF_FULL + poseidon::N_PARTIAL;
-    u64 sb = poseidon::sbox(t);
-    s = (full || r == 0) ? sb : t;
-    // MDS: out[r] = sum_i s[(i + r) % 12] * CIRC[i] (+ 8 * s[0] for r == 0)
-    u32 lo = (u32)s, hi = (u32)(s >> 32);
-    u64 al = 0, ah = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-      int src = i + r;
-      src = src >= 12 ? src - 12 : src;
-      al += (u64)__shfl(lo, src) * poseidon::MDS_CIRC[i];
-      ah += (u64)__shfl(hi, src) * poseidon::MDS_CIRC[i];
-    }
-    if (r == 0) {
-      al += (u64)lo * poseidon::MDS_DIAG0;
-      ah += (u64)hi * poseidon::MDS_DIAG0;
-    }
-    u64 l64 = al + (ah << 32);
-    u32 h32 = (u32)(ah >> 32) + (l64 < al ? 1u : 0u);
-    s = gl::reduce96(l64, h32);
-  }
-  return gl::canon(s);
-}
+using coop::shfl64;
 
 struct Sponge {
   u64 state, inb, outb;  // per-lane words (state: lanes 0..11, buffers: lanes 0..7)
   uint32_t n_in, n_out;  // wave-uniform
   int lane;
+  const u64* rc;  // round constants in LDS
   __device__ void duplex() {
     if (lane < (int)n_in) state = inb;
     n_in = 0;
-    state = coop_permute(state, lane);
+    state = coop::poseidon_permute(state, lane, rc);
     outb = state;
     n_out = 8;
   }
@@ -81,9 +48,12 @@ struct Sponge {
 
 __global__ __launch_bounds__(64) void k_transcript(Transcript* tr, int init, const u64* __restrict__ obs,
                                                    uint32_t n_obs, u64* __restrict__ chal_out, uint32_t n_chal) {
+  __shared__ u64 rc_lds[360];
+  coop::stage_poseidon_rc(rc_lds);
   const int lane = threadIdx.x;
   Sponge sp;
   sp.lane = lane;
+  sp.rc = rc_lds;
   if (init) {
     sp.state = 0;
     sp.inb = 0;

@@ -13,6 +13,7 @@
 // LowHighGenerator, ExponentiationGenerator.
 #include "kernels.h"
 #include "poseidon2.h"
+#include "coop.h"
 #include "prover_kernels.h"
 
 namespace p25 {
@@ -50,12 +51,13 @@ __global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__
                                                       const uint32_t* __restrict__ args, uint32_t g_begin,
                                                       uint32_t g_count, u64* __restrict__ vals, size_t B,
                                                       uint32_t n_proofs, const u64* __restrict__ seeds,
-                                                      uint32_t* __restrict__ status) {
+                                                      uint32_t* __restrict__ status, int skip_poseidon2) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)g_count * n_proofs) return;
   const uint32_t gi = g_begin + (uint32_t)(idx / n_proofs);
   const uint32_t p = (uint32_t)(idx % n_proofs);
   const WitGen g = gens[gi];
+  if (skip_poseidon2 && g.kind == GEN_POSEIDON2) return;  // done by k_witgen_p2_coop
   const uint32_t* dep = args + g.arg_off;
   Emitter emit{vals, dep + g.n_deps, B, p, status};
   auto d = [&](int i) -> u64 { return vals[(size_t)dep[i] * B + p]; };
@@ -187,6 +189,37 @@ __global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__
   }
 }
 
+// Poseidon2 generators of one level, one 16-lane group per (generator, proof): used for small batches,
+// where a level's latency is that of a single permutation (poseidon2_gate.rs:447-523, cooperatively).
+__global__ __launch_bounds__(256) void k_witgen_p2_coop(const WitGen* __restrict__ gens,
+                                                        const uint32_t* __restrict__ args, uint32_t g_begin,
+                                                        uint32_t g_count, u64* __restrict__ vals, size_t B,
+                                                        uint32_t n_proofs, uint32_t* __restrict__ status) {
+  __shared__ u64 k_lds[coop::P2_LDS_WORDS];
+  coop::stage_poseidon2_rc(k_lds);
+  size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / coop::GROUP;
+  const size_t n_groups = (size_t)g_count * n_proofs;
+  const bool valid = grp < n_groups;
+  if (!valid) grp = n_groups - 1;  // every lane takes part in the shuffles
+  const int lane = threadIdx.x & 63, rr = threadIdx.x & (coop::GROUP - 1), base = lane & ~(coop::GROUP - 1);
+  const uint32_t gi = g_begin + (uint32_t)(grp / n_proofs);
+  const uint32_t p = (uint32_t)(grp % n_proofs);
+  const WitGen g = gens[gi];
+  const uint32_t* dep = args + g.arg_off;
+  Emitter em{vals, dep + g.n_deps, B, p, status};
+  auto emit = [&](int k, u64 v) {
+    if (valid) em(k, v);
+  };
+  u64 s = rr < 12 ? vals[(size_t)dep[rr] * B + p] : 0;
+  const u64 swap = vals[(size_t)dep[12] * B + p];
+  u64 up = coop::shfl64(s, base + ((rr + 4) & (coop::GROUP - 1)));
+  u64 dn = coop::shfl64(s, base + ((rr + 12) & (coop::GROUP - 1)));
+  if (rr < 4) emit(rr, gl::mul(swap, gl::sub(up, s)));
+  if (swap == 1) s = rr < 4 ? up : (rr < 8 ? dn : s);
+  s = coop::poseidon2_permute(s, lane, k_lds, [&](int i, u64 v) { emit(4 + i, v); });
+  if (rr < 12) emit(4 + 106 + rr, s);
+}
+
 // vals[slot 0] = 0; vals[input_slots[i]] = inputs[p][i]
 __global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, const uint32_t* __restrict__ input_slots,
                                     uint32_t n_inputs, u64* __restrict__ vals, size_t B, uint32_t n_proofs) {
@@ -217,8 +250,17 @@ void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u6
     uint32_t b = wp.level_start[l], cnt = wp.level_start[l + 1] - b;
     if (!cnt) continue;
     size_t th = (size_t)cnt * n_proofs;
-    hipLaunchKernelGGL(k_witgen_level, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, wp.d_gens, wp.d_args,
-                       b, cnt, d_vals, B, n_proofs, d_seeds, d_status);
+    // small batches: the level's Poseidon2 generators run cooperatively (latency), the rest per lane
+    const uint32_t p2c = l < wp.level_p2_count.size() ? wp.level_p2_count[l] : 0;
+    const int coop_p2 = (n_proofs < 16 && p2c > 0) ? 1 : 0;
+    if (!coop_p2 || p2c < cnt)
+      hipLaunchKernelGGL(k_witgen_level, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, wp.d_gens, wp.d_args,
+                         b, cnt, d_vals, B, n_proofs, d_seeds, d_status, coop_p2);
+    if (coop_p2) {
+      size_t th2 = (size_t)p2c * n_proofs * coop::GROUP;
+      hipLaunchKernelGGL(k_witgen_p2_coop, dim3((unsigned)((th2 + 255) / 256)), dim3(256), 0, st, wp.d_gens,
+                         wp.d_args, wp.level_p2_begin[l], p2c, d_vals, B, n_proofs, d_status);
+    }
   }
 }
 void launch_fill_wires(const DeviceWitnessProgram& wp, const u64* d_vals, size_t B, uint32_t p, u64* d_wires,

@@ -12,6 +12,7 @@ struct DeviceWitnessProgram {
   uint32_t* d_input_slots = nullptr;
   uint32_t* d_wire_slot_cm = nullptr;
   std::vector<uint32_t> level_start;
+  std::vector<uint32_t> level_p2_begin, level_p2_count;  // Poseidon2 generators of each level (contiguous)
   uint32_t n_inputs = 0, num_slots = 0;
   size_t n_wire_elems = 0;
 };

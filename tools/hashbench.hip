@@ -1,0 +1,77 @@
+// Variants of the Merkle leaf-sponge kernel on a synthetic 2^19 x 135 column-major matrix.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "poseidon.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int BS>
+__global__ __launch_bounds__(BS) void k_v0(const u64* __restrict__ cols, size_t stride, int width, size_t n, u64* __restrict__ dig) {
+  size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n) return;
+  u64 out[4];
+  poseidon::hash_or_noop_strided(cols + l, stride, width, out);
+  for (int i = 0; i < 4; i++) dig[4 * l + i] = out[i];
+}
+// prefetch the next 8 words while permuting
+template <int BS>
+__global__ __launch_bounds__(BS) void k_prefetch(const u64* __restrict__ cols, size_t stride, int width, size_t n, u64* __restrict__ dig) {
+  size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n) return;
+  const u64* in = cols + l;
+  u64 s[12];
+  for (int i = 0; i < 12; i++) s[i] = 0;
+  u64 nx[8];
+  for (int i = 0; i < 8; i++) nx[i] = i < width ? in[(size_t)i * stride] : 0;
+  for (int off = 0; off < width; off += 8) {
+    int m = width - off < 8 ? width - off : 8;
+    for (int i = 0; i < 8; i++) if (i < m) s[i] = nx[i];
+    int no = off + 8;
+    for (int i = 0; i < 8; i++) nx[i] = (no + i) < width ? in[(size_t)(no + i) * stride] : 0;
+    poseidon::permute(s);
+  }
+  for (int i = 0; i < 4; i++) dig[4 * l + i] = s[i];
+}
+// occupancy capped through dynamic LDS
+template <int BS>
+__global__ __launch_bounds__(BS) void k_lds(const u64* __restrict__ cols, size_t stride, int width, size_t n, u64* __restrict__ dig) {
+  extern __shared__ u64 dummy[];
+  size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n) return;
+  u64 out[4];
+  poseidon::hash_or_noop_strided(cols + l, stride, width, out);
+  if (out[0] == 0x1234567 && dummy[0] == 1) out[1] = 0;
+  for (int i = 0; i < 4; i++) dig[4 * l + i] = out[i];
+}
+// registers only: 17 permutations per lane (ceiling)
+__global__ __launch_bounds__(256) void k_regs(u64* dig, size_t n, int reps) {
+  size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n) return;
+  u64 s[12];
+  for (int i = 0; i < 12; i++) s[i] = l * 12 + i;
+  for (int r = 0; r < reps; r++) { s[0] ^= r; poseidon::permute(s); }
+  for (int i = 0; i < 4; i++) dig[4 * l + i] = s[i];
+}
+template <class F> float timeit(F f) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  f(); (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0); f(); (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); return ms;
+}
+int main() {
+  const size_t n = 1 << 19; const int w = 135;
+  u64 *cols, *dig;
+  CK(hipMalloc(&cols, n * w * 8)); CK(hipMalloc(&dig, n * 32));
+  CK(hipMemset(cols, 0x11, n * w * 8));
+  const double perms = (double)n * 17;
+  auto rep = [&](const char* name, float ms) { printf("%-28s %7.3f ms  %7.1f Mperm/s\n", name, ms, perms / ms / 1e3); };
+  rep("v0 bs256", timeit([&] { hipLaunchKernelGGL(k_v0<256>, dim3(n / 256), dim3(256), 0, 0, cols, n, w, n, dig); }));
+  rep("v0 bs128", timeit([&] { hipLaunchKernelGGL(k_v0<128>, dim3(n / 128), dim3(128), 0, 0, cols, n, w, n, dig); }));
+  rep("v0 bs64", timeit([&] { hipLaunchKernelGGL(k_v0<64>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
+  rep("prefetch bs256", timeit([&] { hipLaunchKernelGGL(k_prefetch<256>, dim3(n / 256), dim3(256), 0, 0, cols, n, w, n, dig); }));
+  rep("prefetch bs64", timeit([&] { hipLaunchKernelGGL(k_prefetch<64>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
+  rep("lds 40KB bs256 (4 w/SIMD)", timeit([&] { hipLaunchKernelGGL(k_lds<256>, dim3(n / 256), dim3(256), 40 * 1024, 0, cols, n, w, n, dig); }));
+  rep("lds 20KB bs256 (8 blk/CU)", timeit([&] { hipLaunchKernelGGL(k_lds<256>, dim3(n / 256), dim3(256), 20 * 1024, 0, cols, n, w, n, dig); }));
+  rep("lds 54KB bs256 (3 blk/CU)", timeit([&] { hipLaunchKernelGGL(k_lds<256>, dim3(n / 256), dim3(256), 54 * 1024, 0, cols, n, w, n, dig); }));
+  rep("regs only, 17 perms", timeit([&] { hipLaunchKernelGGL(k_regs, dim3(n / 256), dim3(256), 0, 0, dig, n, 17); }));
+  return 0;
+}

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Prove the artifact once on the GPU (after one warm-up) -- target for rocprofv3 traces."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as ge
+import p3json
+p25 = ge.load_package(); p25.device_init(0)
+inputs, _ = p3json.load(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json"))
+c = p25.Circuit.build_p3_verifier(p25.P3Config.fib64())
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+c.prove(inputs, seeds=[0])
+proofs, st, tm = c.prove(np.stack([inputs] * n), seeds=list(range(n)), timings=True)
+print(st.tolist(), {k: round(v, 3) for k, v in tm.as_dict().items()})
