@@ -70,8 +70,60 @@ GL_HD u64 reduce96(u64 lo, u32 hi) {
   if (t2 < t1) t2 += EPS;
   return t2;
 }
+#ifndef P25_ASM_MUL
+#define P25_ASM_MUL 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+GL_HD u64 make64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+// Hand-scheduled gfx950 product + reduction: 14 VALU (5 v_mad_u64_u32 + 9 carry ops) against the ~30
+// the compiler emits for reduce128(a * b, mulhi64(a, b)) (it rebuilds the 128-bit product from 32-bit
+// pieces through v_mov'd zero-extended pairs and resolves every wrap with cmp + 2 cndmask).
+//   U + c*2^64 = a0*b1 + a1*b0;  (r3:r2:r1:r0) = a0*b0 + (U << 32) + a1*b1 * 2^64 + c*2^96
+//   V + c1*2^64 = (r1:r0) + r2*(2^32-1);  W - bw*2^64 = V - r3     (2^64 = 2^32-1, 2^96 = -1 mod p)
+//   result = W + (c1 - bw)*(2^32-1); neither correction can wrap (see DESIGN.md "field multiply").
+// gfx940-family hazard: a VALU-written SGPR/VCC needs 2 wait states before a VALU reads it as a carry;
+// inline asm is opaque to the compiler's hazard recogniser, hence the explicit s_nop.
+__device__ __forceinline__ u64 mul_nc_asm(u64 a, u64 b) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 T, U, P0, P3, c, c1, dm, sx, sy, V;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(T), "=s"(dm) : "v"(a0), "v"(b1));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(U), "=s"(c) : "v"(a1), "v"(b0), "v"(T));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(P0), "=s"(dm) : "v"(a0), "v"(b0));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(P3), "=s"(dm) : "v"(a1), "v"(b1));
+  u32 p0l = (u32)P0, p0h = (u32)(P0 >> 32), ul = (u32)U, uh = (u32)(U >> 32), p3l = (u32)P3, p3h = (u32)(P3 >> 32);
+  u32 r2;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %3\n\ts_nop 1\n\t"         // r1 (over P0.hi)
+      "v_addc_co_u32_e32 %1, vcc, %4, %5, vcc\n\ts_nop 1\n\t"   // r2
+      "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc"                   // r3 - c (over P3.hi)
+      : "+v"(p0h), "=&v"(r2), "+v"(p3h)
+      : "v"(ul), "v"(p3l), "v"(uh)
+      : "vcc");
+  u64 lo = make64(p0l, p0h);
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(V), "=s"(c1) : "v"(r2), "v"(lo));
+  u32 v0 = (u32)V, v1 = (u32)(V >> 32);
+  asm("s_nop 1\n\t"
+      "v_subb_co_u32_e64 %0, vcc, %0, %4, %5\n\ts_nop 1\n\t"  // W.lo = V.lo - r3' - c
+      "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"           // W.hi ; vcc = bw
+      "v_subbrev_co_u32_e64 %0, %2, 0, %0, %6\n\t"             // + c1*(2^32-1): lo -= c1 ...
+      "s_andn2_b64 %2, %6, %2\n\t"
+      "v_addc_co_u32_e64 %1, %3, 0, %1, %2\n\t"                // ... hi += c1 & ~borrow
+      "v_addc_co_u32_e64 %0, %2, 0, %0, vcc\n\t"               // - bw*(2^32-1): lo += bw ...
+      "s_andn2_b64 %2, vcc, %2\n\t"
+      "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"                 // ... hi -= bw & ~carry
+      : "+v"(v0), "+v"(v1), "=&s"(sx), "=&s"(sy)
+      : "v"(p3h), "s"(c), "s"(c1)
+      : "vcc", "scc");  // s_andn2 writes SCC
+  return make64(v0, v1);
+}
+#endif
 // any u64 inputs (non-canonical allowed) -> non-canonical product
-GL_HD u64 mul_nc(u64 a, u64 b) { return reduce128(a * b, mulhi64(a, b)); }
+GL_HD u64 mul_nc(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  return mul_nc_asm(a, b);
+#else
+  return reduce128(a * b, mulhi64(a, b));
+#endif
+}
 GL_HD u64 mul(u64 a, u64 b) { return canon(mul_nc(a, b)); }
 GL_HD u64 sqr(u64 a) { return mul(a, a); }
 // a*b + c, all canonical

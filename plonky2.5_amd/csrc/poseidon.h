@@ -66,8 +66,114 @@ GL_HD u64 add_rc(u64 x, u64 c) {
   return s < x ? s + gl::EPS : s;  // on wrap: +2^64 == +EPS; cannot wrap twice since c < p
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 device form -------------------------------------------------------------------------
+// Round constants split into zero-extended 32-bit halves, one (lo, hi) pair per constant, plus a
+// zero row: the constants of round r+1 are folded into round r's MDS accumulators (they ride in as
+// the 64-bit addend of the first v_mad_u64_u32 of each row, read straight from SGPRs), so only
+// round 0 pays for a separate modular addition.
+struct RcSplit {
+  u64 v[(N_ROUNDS + 1) * WIDTH * 2];
+};
+constexpr RcSplit make_rc_split() {
+  RcSplit t{};
+  for (int i = 0; i < N_ROUNDS * WIDTH; i++) {
+    t.v[2 * i] = RC[i] & 0xFFFFFFFFull;
+    t.v[2 * i + 1] = RC[i] >> 32;
+  }
+  return t;
+}
+static constexpr RcSplit RC_SPLIT = make_rc_split();
+
+template <int C>
+__device__ __forceinline__ void mad_k(u64& acc, u32 x) {
+  u64 dm;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dm) : "v"(x), "n"(C));
+}
+// s <- MDS * s + k, k = the (lo, hi) pairs of the next round's constants.  288 v_mad_u64_u32 with inline
+// constants + 5 instructions per row for the reduction (the compiler's version of mds(): shifts for the
+// power-of-two entries through v_mov'd pairs, ~23 non-mad instructions per row).
+__device__ __forceinline__ void mds_rc(u64 s[WIDTH], const u64* __restrict__ k) {
+  u32 lo[WIDTH], hi[WIDTH];
+#pragma unroll
+  for (int i = 0; i < WIDTH; i++) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+#pragma unroll
+  for (int r = 0; r < WIDTH; r++) {
+    u64 al, ah, dm, t;
+    asm("v_mad_u64_u32 %0, %1, %2, 17, %3" : "=v"(al), "=s"(dm) : "v"(lo[r]), "s"(k[2 * r]));
+    asm("v_mad_u64_u32 %0, %1, %2, 17, %3" : "=v"(ah), "=s"(dm) : "v"(hi[r]), "s"(k[2 * r + 1]));
+#define P25_MDS_TERM(i, C)            \
+  mad_k<C>(al, lo[(i + r) % WIDTH]); \
+  mad_k<C>(ah, hi[(i + r) % WIDTH]);
+    P25_MDS_TERM(1, 15)
+    P25_MDS_TERM(2, 41)
+    P25_MDS_TERM(3, 16)
+    P25_MDS_TERM(4, 2)
+    P25_MDS_TERM(5, 28)
+    P25_MDS_TERM(6, 13)
+    P25_MDS_TERM(7, 13)
+    P25_MDS_TERM(8, 39)
+    P25_MDS_TERM(9, 18)
+    P25_MDS_TERM(10, 34)
+    P25_MDS_TERM(11, 20)
+#undef P25_MDS_TERM
+    if (r == 0) {
+      mad_k<8>(al, lo[0]);
+      mad_k<8>(ah, hi[0]);
+    }
+    // value = al + ah * 2^32, al < 2^43, ah < 2^42:  X = al + (ah >> 32) * (2^32 - 1) < 2^44, then
+    // add (ah & 0xffffffff) << 32; a carry out of bit 64 is worth 2^32 - 1 and cannot ripple
+    // (after a wrap the high word is < 2^12).
+    u32 ahl = (u32)ah, ahh = (u32)(ah >> 32);
+    u64 X;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(X), "=s"(dm) : "v"(ahh), "v"(al));
+    u32 x0 = (u32)X, x1 = (u32)(X >> 32);
+    asm("v_add_co_u32_e32 %1, vcc, %1, %3\n\ts_nop 1\n\t"
+        "v_subbrev_co_u32_e64 %0, %2, 0, %0, vcc\n\t"
+        "s_andn2_b64 %2, vcc, %2\n\t"
+        "v_addc_co_u32_e64 %1, %2, 0, %1, %2"
+        : "+v"(x0), "+v"(x1), "=&s"(t)
+        : "v"(ahl)
+        : "vcc", "scc");  // s_andn2 writes SCC
+    s[r] = gl::make64(x0, x1);
+  }
+}
+static_assert(MDS_CIRC[0] == 17 && MDS_CIRC[1] == 15 && MDS_CIRC[2] == 41 && MDS_CIRC[3] == 16 && MDS_CIRC[4] == 2 &&
+                  MDS_CIRC[5] == 28 && MDS_CIRC[6] == 13 && MDS_CIRC[7] == 13 && MDS_CIRC[8] == 39 &&
+                  MDS_CIRC[9] == 18 && MDS_CIRC[10] == 34 && MDS_CIRC[11] == 20 && MDS_DIAG0 == 8,
+              "mds_rc hard-codes the MDS entries as inline constants");
+
+__device__ __forceinline__ void permute_dev(u64 s[WIDTH]) {
+#pragma unroll
+  for (int i = 0; i < WIDTH; i++) s[i] = add_rc(s[i], RC[i]);
+  int r = 1;
+  for (int k = 0; k < HALF_FULL; k++, r++) {
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
+    mds_rc(s, RC_SPLIT.v + 2 * WIDTH * r);
+  }
+  for (int k = 0; k < N_PARTIAL; k++, r++) {
+    s[0] = sbox(s[0]);
+    mds_rc(s, RC_SPLIT.v + 2 * WIDTH * r);
+  }
+  for (int k = 0; k < HALF_FULL; k++, r++) {
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
+    mds_rc(s, RC_SPLIT.v + 2 * WIDTH * r);  // r == N_ROUNDS for the last round: the zero row
+  }
+#pragma unroll
+  for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
+}
+#endif
+
 // Canonical in, canonical out.
 GL_HD void permute(u64 s[WIDTH]) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  permute_dev(s);
+#else
   int r = 0;
   for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
@@ -89,6 +195,7 @@ GL_HD void permute(u64 s[WIDTH]) {
   }
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
+#endif
 }
 
 // compress two 4-word digests (upstream `two_to_one`)

@@ -1,0 +1,127 @@
+// Cross-checks the hand-written gfx950 sequences in gl.h / poseidon.h (mul_nc_asm, mds_rc, permute_dev)
+// against the plain C++ forms of the same functions, on the device, over edge cases and random inputs.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "poseidon.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__global__ void k_mul(const u64* a, const u64* b, u64* out_asm, u64* out_c, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (i >= n) return;
+  out_asm[i] = gl::canon(gl::mul_nc_asm(a[i], b[i]));
+  out_c[i] = gl::canon(gl::reduce128(a[i] * b[i], gl::mulhi64(a[i], b[i])));
+#endif
+}
+__global__ void k_mds(const u64* in, u64* out_asm, u64* out_c, size_t n, int row) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (i >= n) return;
+  u64 s[12], t[12];
+  for (int k = 0; k < 12; k++) s[k] = t[k] = in[i * 12 + k];
+  poseidon::mds_rc(s, poseidon::RC_SPLIT.v + 24 * row);
+  poseidon::mds(t);
+  for (int k = 0; k < 12; k++) {
+    out_asm[i * 12 + k] = gl::canon(s[k]);
+    u64 c = row < 30 ? poseidon::RC[12 * row + k] : 0;
+    out_c[i * 12 + k] = gl::add(gl::canon(t[k]), c);
+  }
+#endif
+}
+__global__ void k_dump(u64* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int i = 0; i < 48; i++) out[i] = poseidon::RC_SPLIT.v[696 + i];
+#endif
+}
+__device__ void permute_c(u64 s[12]) {
+  using namespace poseidon;
+  for (int r = 0; r < 30; r++) {
+    for (int i = 0; i < 12; i++) s[i] = gl::add(gl::canon(s[i]), RC[12 * r + i]);
+    if (r < 4 || r >= 26) {
+      for (int i = 0; i < 12; i++) {
+        u64 x = s[i], x2 = gl::canon(gl::reduce128(x * x, gl::mulhi64(x, x)));
+        u64 x4 = gl::canon(gl::reduce128(x2 * x2, gl::mulhi64(x2, x2)));
+        u64 x3 = gl::canon(gl::reduce128(x * x2, gl::mulhi64(x, x2)));
+        s[i] = gl::canon(gl::reduce128(x3 * x4, gl::mulhi64(x3, x4)));
+      }
+    } else {
+      u64 x = s[0], x2 = gl::canon(gl::reduce128(x * x, gl::mulhi64(x, x)));
+      u64 x4 = gl::canon(gl::reduce128(x2 * x2, gl::mulhi64(x2, x2)));
+      u64 x3 = gl::canon(gl::reduce128(x * x2, gl::mulhi64(x, x2)));
+      s[0] = gl::canon(gl::reduce128(x3 * x4, gl::mulhi64(x3, x4)));
+    }
+    mds(s);
+  }
+  for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+}
+__global__ void k_perm(const u64* in, u64* out_asm, u64* out_c, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12], t[12];
+  for (int k = 0; k < 12; k++) s[k] = t[k] = in[i * 12 + k];
+  poseidon::permute(s);
+  permute_c(t);
+  for (int k = 0; k < 12; k++) {
+    out_asm[i * 12 + k] = s[k];
+    out_c[i * 12 + k] = t[k];
+  }
+}
+
+static u64 rng_state = 88172645463325252ull;
+static u64 rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+int main() {
+  const size_t n = 1 << 20;
+  u64 *a, *b, *o1, *o2;
+  CK(hipMallocManaged(&a, n * 12 * 8)); CK(hipMallocManaged(&b, n * 8));
+  CK(hipMallocManaged(&o1, n * 12 * 8)); CK(hipMallocManaged(&o2, n * 12 * 8));
+  const u64 P = 0xFFFFFFFF00000001ull;
+  const u64 edge[] = {0, 1, 2, 0xFFFFFFFFull, 0x100000000ull, 0xFFFFFFFF00000000ull, P - 1, P, P + 1, ~0ull, ~0ull - 1,
+                      0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFull, 0xFFFFFFFEFFFFFFFFull, 0x00000001FFFFFFFFull, 0xFFFFFFFF00000002ull};
+  const int ne = sizeof(edge) / 8;
+  int bad_total = 0;
+  {
+    size_t k = 0;
+    for (int i = 0; i < ne; i++) for (int j = 0; j < ne; j++) { a[k] = edge[i]; b[k] = edge[j]; k++; }
+    for (; k < n; k++) {
+      a[k] = rnd(); b[k] = rnd();
+      if ((k & 7) == 1) a[k] |= 0xFFFFFFFF00000000ull;
+      if ((k & 7) == 2) b[k] &= 0xFFFFFFFFull;
+      if ((k & 7) == 3) { a[k] |= 0xFFFFFFFF00000000ull; b[k] |= 0xFFFFFFFF00000000ull; }
+      if ((k & 7) == 4) { a[k] = ~0ull - (rnd() & 0xFFFF); b[k] = ~0ull - (rnd() & 0xFFFF); }
+    }
+    hipLaunchKernelGGL(k_mul, dim3(n / 256), dim3(256), 0, 0, a, b, o1, o2, n);
+    CK(hipDeviceSynchronize());
+    int bad = 0;
+    for (size_t i = 0; i < n; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("mul mismatch a=%016llx b=%016llx asm=%016llx c=%016llx\n", (unsigned long long)a[i], (unsigned long long)b[i], (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    printf("mul_nc_asm: %d mismatches of %zu\n", bad, n);
+    bad_total += bad;
+  }
+  const size_t m = 1 << 16;
+  hipLaunchKernelGGL(k_dump, dim3(1), dim3(1), 0, 0, o1);
+  CK(hipDeviceSynchronize());
+  for (int i = 0; i < 48; i++) printf("RC_SPLIT[%d] = %016llx\n", 696 + i, (unsigned long long)o1[i]);
+  for (int row = 0; row <= 30; row += 5) {
+    for (size_t i = 0; i < m * 12; i++) { a[i] = rnd(); if ((i % 5) == 0) a[i] |= 0xFFFFFFFF00000000ull; if ((i % 7) == 0) a[i] |= 0xFFFFFFFFull; }
+    for (int i = 0; i < 24; i++) a[i] = ~0ull;
+    hipLaunchKernelGGL(k_mds, dim3(m / 256), dim3(256), 0, 0, a, o1, o2, m, row);
+    CK(hipDeviceSynchronize());
+    int bad = 0;
+    for (size_t i = 0; i < m * 12; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("mds mismatch at %zu: asm=%016llx c=%016llx\n", i, (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    printf("mds_rc row %d: %d mismatches of %zu\n", row, bad, m * 12);
+    bad_total += bad;
+  }
+  {
+    for (size_t i = 0; i < m * 12; i++) a[i] = rnd() % P;
+    for (int i = 0; i < 12; i++) a[i] = i;
+    hipLaunchKernelGGL(k_perm, dim3(m / 64), dim3(64), 0, 0, a, o1, o2, m);
+    CK(hipDeviceSynchronize());
+    int bad = 0;
+    for (size_t i = 0; i < m * 12; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("perm mismatch at %zu: asm=%016llx c=%016llx\n", i, (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    printf("permute: %d mismatches of %zu ; perm(0..11)[0] = %016llx\n", bad, m * 12, (unsigned long long)o1[0]);
+    bad_total += bad;
+  }
+  printf(bad_total ? "ASMCHECK FAIL\n" : "ASMCHECK OK\n");
+  return bad_total ? 1 : 0;
+}

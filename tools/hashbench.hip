@@ -67,7 +67,21 @@ int main() {
   rep("v0 bs256", timeit([&] { hipLaunchKernelGGL(k_v0<256>, dim3(n / 256), dim3(256), 0, 0, cols, n, w, n, dig); }));
   rep("v0 bs128", timeit([&] { hipLaunchKernelGGL(k_v0<128>, dim3(n / 128), dim3(128), 0, 0, cols, n, w, n, dig); }));
   rep("v0 bs64", timeit([&] { hipLaunchKernelGGL(k_v0<64>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
-  rep("prefetch bs256", timeit([&] { hipLaunchKernelGGL(k_prefetch<256>, dim3(n / 256), dim3(256), 0, 0, cols, n, w, n, dig); }));
+  {
+    // checksum of the digests, to compare builds (-DP25_ASM_MUL=0 vs 1) bit for bit
+    CK(hipMemset(cols, 0, n * w * 8));
+    u64* h = (u64*)malloc(n * w * 8);
+    u64 x = 88172645463325252ull;
+    for (size_t i = 0; i < n * w; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = x % 0xFFFFFFFF00000001ull; }
+    CK(hipMemcpy(cols, h, n * w * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_v0<64>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig);
+    CK(hipMemcpy(h, dig, n * 32, hipMemcpyDeviceToHost));
+    u64 sum = 0, xr = 0;
+    for (size_t i = 0; i < n * 4; i++) { sum += h[i] * (2 * i + 1); xr ^= h[i]; }
+    printf("digest checksum (asm=%d): %016llx %016llx\n", P25_ASM_MUL, (unsigned long long)sum, (unsigned long long)xr);
+    free(h);
+  }
+  rep("prefetch bs256",timeit([&] { hipLaunchKernelGGL(k_prefetch<256>, dim3(n / 256), dim3(256), 0, 0, cols, n, w, n, dig); }));
   rep("prefetch bs64", timeit([&] { hipLaunchKernelGGL(k_prefetch<64>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
   rep("lds 40KB bs256 (4 w/SIMD)", timeit([&] { hipLaunchKernelGGL(k_lds<256>, dim3(n / 256), dim3(256), 40 * 1024, 0, cols, n, w, n, dig); }));
   rep("lds 20KB bs256 (8 blk/CU)", timeit([&] { hipLaunchKernelGGL(k_lds<256>, dim3(n / 256), dim3(256), 20 * 1024, 0, cols, n, w, n, dig); }));
