@@ -93,7 +93,8 @@ __device__ __forceinline__ void mad_k(u64& acc, u32 x) {
 // s <- MDS * s + k, k = the (lo, hi) pairs of the next round's constants.  288 v_mad_u64_u32 with inline
 // constants + 5 instructions per row for the reduction (the compiler's version of mds(): shifts for the
 // power-of-two entries through v_mov'd pairs, ~23 non-mad instructions per row).
-__device__ __forceinline__ void mds_rc(u64 s[WIDTH], const u64* __restrict__ k) {
+typedef const u64 __attribute__((address_space(4))) * rc_ptr;  // constant address space: scalar loads
+__device__ __forceinline__ void mds_rc(u64 s[WIDTH], rc_ptr k) {
   u32 lo[WIDTH], hi[WIDTH];
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) {
@@ -149,20 +150,24 @@ static_assert(MDS_CIRC[0] == 17 && MDS_CIRC[1] == 15 && MDS_CIRC[2] == 41 && MDS
 __device__ __forceinline__ void permute_dev(u64 s[WIDTH]) {
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) s[i] = add_rc(s[i], RC[i]);
+  // Opaque base pointer: otherwise every one of the 24 scalar loads per round recomputes the table's
+  // pc-relative address (s_getpc + 4 scalar adds each).
+  rc_ptr rc = (rc_ptr)RC_SPLIT.v;
+  asm("" : "+s"(rc));
   int r = 1;
   for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
-    mds_rc(s, RC_SPLIT.v + 2 * WIDTH * r);
+    mds_rc(s, rc + 2 * WIDTH * r);
   }
   for (int k = 0; k < N_PARTIAL; k++, r++) {
     s[0] = sbox(s[0]);
-    mds_rc(s, RC_SPLIT.v + 2 * WIDTH * r);
+    mds_rc(s, rc + 2 * WIDTH * r);
   }
   for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
-    mds_rc(s, RC_SPLIT.v + 2 * WIDTH * r);  // r == N_ROUNDS for the last round: the zero row
+    mds_rc(s, rc + 2 * WIDTH * r);  // r == N_ROUNDS for the last round: the zero row
   }
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);

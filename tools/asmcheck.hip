@@ -20,7 +20,7 @@ __global__ void k_mds(const u64* in, u64* out_asm, u64* out_c, size_t n, int row
   if (i >= n) return;
   u64 s[12], t[12];
   for (int k = 0; k < 12; k++) s[k] = t[k] = in[i * 12 + k];
-  poseidon::mds_rc(s, poseidon::RC_SPLIT.v + 24 * row);
+  poseidon::mds_rc(s, (poseidon::rc_ptr)poseidon::RC_SPLIT.v + 24 * row);
   poseidon::mds(t);
   for (int k = 0; k < 12; k++) {
     out_asm[i * 12 + k] = gl::canon(s[k]);
