@@ -21,6 +21,10 @@ import time
 
 import numpy as np
 
+# libp25 sets this itself when it is loaded; torch may initialise HIP first, so set it here too
+# (hardware queues the runtime spreads the prover's streams over -- see capi.hip).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

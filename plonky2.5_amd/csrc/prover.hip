@@ -508,7 +508,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
 
 static size_t streams_in_flight() {
   const char* e = getenv("P25_STREAMS");
-  int k = e ? atoi(e) : 8;
+  int k = e ? atoi(e) : 12;
   return (size_t)(k < 1 ? 1 : (k > 16 ? 16 : k));
 }
 
