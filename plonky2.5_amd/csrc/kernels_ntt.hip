@@ -27,6 +27,34 @@
 
 namespace p25 {
 
+// G consecutive radix-2 DIF stages on the 2^G elements col[k * step], k < 2^G, held in registers.
+// Stage s0+m pairs (k, k + hk), hk = 2^(G-1-m); the pair's position inside its half-block is
+// j = (k mod hk) * stride + l, twiddle w_R^(j << (s0+m)).  With stride == 1 the last stage has j == 0.
+template <int G>
+__device__ __forceinline__ void dif_group(u64* col, const u64* wl, int step, int l, int lstride, int s0) {
+  constexpr int K = 1 << G;
+  u64 x[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) x[k] = col[k * step];
+#pragma unroll
+  for (int m = 0; m < G; m++) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int hk = K >> (m + 1);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (k & hk) continue;
+      const int j = ((k & (hk - 1)) << lstride) + l;
+      u64 u = x[k], v = x[k + hk];
+      x[k] = gl::add(u, v);
+      u64 d = gl::sub(u, v);
+      x[k + hk] = (hk == 1 && lstride == 0) ? d : gl::mul(d, wl[j << (s0 + m)]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) col[k * step] = x[k];
+}
+
 __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
   extern __shared__ u64 lds[];
   const int R = 1 << a.log_r, T = 1 << a.log_t;
@@ -65,18 +93,25 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
   }
   __syncthreads();
 
-  // radix-2 DIF, natural in -> bit-reversed out
-  for (int len = R >> 1, sh = 0; len >= 1; len >>= 1, sh++) {
-    for (int b = tid; b < T * (R >> 1); b += nth) {
-      int t = b & (T - 1);
-      int p = b >> a.log_t;
-      int j = p & (len - 1);
-      int i0 = ((p - j) << 1) + j;
-      u64 u = lds[i0 * TP + t], v = lds[(i0 + len) * TP + t];
-      lds[i0 * TP + t] = gl::add(u, v);
-      lds[(i0 + len) * TP + t] = gl::mul(gl::sub(u, v), wl[j << sh]);
+  // DIF network, natural in -> bit-reversed out, up to 4 stages (radix 16) per LDS round trip:
+  // a work item holds the 2^g elements {base + k*stride} of one sub-transform in registers.
+  for (int s0 = 0; s0 < a.log_r;) {
+    const int g = a.log_r - s0 < 4 ? a.log_r - s0 : 4;
+    const int lstride = a.log_r - s0 - g;
+    const int items = T << (a.log_r - g);
+    for (int b = tid; b < items; b += nth) {
+      const int t = b & (T - 1), q = b >> a.log_t;
+      const int l = q & ((1 << lstride) - 1), h = q >> lstride;
+      u64* col = lds + ((h << (a.log_r - s0)) + l) * TP + t;
+      switch (g) {
+        case 4: dif_group<4>(col, wl, TP << lstride, l, lstride, s0); break;
+        case 3: dif_group<3>(col, wl, TP << lstride, l, lstride, s0); break;
+        case 2: dif_group<2>(col, wl, TP << lstride, l, lstride, s0); break;
+        default: dif_group<1>(col, wl, TP << lstride, l, lstride, s0); break;
+      }
     }
     __syncthreads();
+    s0 += g;
   }
 
   for (int e = tid; e < T * R; e += nth) {

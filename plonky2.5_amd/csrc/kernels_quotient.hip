@@ -16,6 +16,7 @@
 // (upstream's reduce_with_powers_multi), each gate folds its constraints into the two alpha-power
 // sums as they are produced (alpha^j from an LDS table), and the gate's filter multiplies the
 // folded sums once:   sum_j alpha^j sum_g f_g c_{g,j} = sum_g f_g sum_j alpha^j c_{g,j}.
+#include <stdexcept>
 #include "kernels.h"
 #include "poseidon2.h"
 #include "prover_kernels.h"
@@ -24,38 +25,58 @@ namespace p25 {
 
 namespace {
 
+// alpha^j for both challenges as 22/22/20-bit limbs (8 x u32 per j, LDS): a constraint value c (any
+// u64, as two 32-bit halves) is folded into the alpha-sums with 12 carry-free v_mad_u64_u32 --
+// products are < 2^54, so 512 terms fit a 64-bit accumulator -- instead of two 64x64->128 multiplies
+// with 128-bit accumulation and overflow tracking (~40 instructions).  Reduced mod p once per gate.
+struct AlphaLimbs {
+  u32 l[8];  // [challenge 0: l0 l1 l2 pad | challenge 1: l0 l1 l2 pad]
+};
+constexpr int MAX_TERMS_PER_FOLD = 512;
+
 struct Ctx {
   const u64* wires;  // column base for this point: wires[col * big]
   size_t big;
-  const u64* ap0;    // alpha_0^j, alpha_1^j tables (LDS)
-  const u64* ap1;
-  // Lazy reduction: the two alpha-sums are kept as 160-bit integers (128-bit + overflow count) and
-  // reduced mod p once per gate instead of once per constraint (4 multiply-adds + a carry chain per
-  // term instead of a full modular multiply and add).
-  unsigned __int128 s0, s1;
-  u32 ov0, ov1;
+  const AlphaLimbs* apl;  // LDS
+  u64 acc[2][2][3];       // [challenge][half of c][limb of alpha]
   __device__ __forceinline__ u64 w(int col) const { return wires[(size_t)col * big]; }
   __device__ __forceinline__ void reset() {
-    s0 = 0;
-    s1 = 0;
-    ov0 = 0;
-    ov1 = 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[c][h][k] = 0;
   }
+  __device__ __forceinline__ static void mad(u64& a, u32 x, u32 y) {
+    u64 dm;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(a), "=s"(dm) : "v"(x), "v"(y));
+  }
+  // c: any u64 congruent to the constraint value
   __device__ __forceinline__ void at(int j, u64 c) {
-    unsigned __int128 p0 = (unsigned __int128)c * ap0[j];
-    unsigned __int128 p1 = (unsigned __int128)c * ap1[j];
-    s0 += p0;
-    ov0 += s0 < p0 ? 1u : 0u;
-    s1 += p1;
-    ov1 += s1 < p1 ? 1u : 0u;
+    const AlphaLimbs al = apl[j];
+    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        mad(acc[ch][0][k], c0, al.l[4 * ch + k]);
+        mad(acc[ch][1][k], c1, al.l[4 * ch + k]);
+      }
   }
-  // value = s + ov * 2^128, and 2^128 = -2^32 (mod p)
-  __device__ __forceinline__ static u64 fold(unsigned __int128 s, u32 ov) {
-    u64 r = gl::canon(gl::reduce128((u64)s, (u64)(s >> 64)));
-    return gl::sub(r, gl::mul((u64)ov, (u64)1 << 32));
+  // sum_{h,k} acc[h][k] * 2^(32h + 22k) mod p
+  __device__ __forceinline__ u64 fold(int ch) const {
+    u64 r = gl::canon(acc[ch][0][0]);
+    r = gl::add(r, gl::mul(acc[ch][0][1], (u64)1 << 22));
+    r = gl::add(r, gl::mul(acc[ch][0][2], (u64)1 << 44));
+    r = gl::add(r, gl::mul(acc[ch][1][0], (u64)1 << 32));
+    r = gl::add(r, gl::mul(acc[ch][1][1], (u64)1 << 54));
+    // 2^76 = 2^64 * 2^12 = (2^32 - 1) * 2^12 (mod p)
+    r = gl::add(r, gl::mul(acc[ch][1][2], (u64)0xFFFFFFFFull << 12));
+    return r;
   }
-  __device__ __forceinline__ u64 acc0() const { return fold(s0, ov0); }
-  __device__ __forceinline__ u64 acc1() const { return fold(s1, ov1); }
+  __device__ __forceinline__ u64 acc0() const { return fold(0); }
+  __device__ __forceinline__ u64 acc1() const { return fold(1); }
 };
 
 __device__ void gate_constant(Ctx& cx, u64 k0, u64 k1) {
@@ -232,9 +253,23 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
   hipLaunchKernelGGL(k_alpha_pows, dim3(2), dim3(ALPHA_POWS), 0, st, d_chal, d_alpha_pows);
 }
 
-__global__ __launch_bounds__(128) void k_quotient(QuotientArgs a) {
+__global__ __launch_bounds__(128, 2) void k_quotient(QuotientArgs a) {
   __shared__ u64 ap[2 * ALPHA_POWS];
-  for (int i = threadIdx.x; i < 2 * ALPHA_POWS; i += blockDim.x) ap[i] = a.alpha_pows[i];
+  __shared__ AlphaLimbs apl[ALPHA_POWS];
+  for (int i = threadIdx.x; i < 2 * ALPHA_POWS; i += blockDim.x) {
+    const u64 v = a.alpha_pows[i];
+    ap[i] = v;
+    const int ch = i / ALPHA_POWS, j = i - ch * ALPHA_POWS;
+    apl[j].l[4 * ch] = (u32)v & 0x3FFFFFu;
+    apl[j].l[4 * ch + 1] = (u32)(v >> 22) & 0x3FFFFFu;
+    apl[j].l[4 * ch + 2] = (u32)(v >> 44);
+    apl[j].l[4 * ch + 3] = 0;
+  }
+  __shared__ u64 kb[2 * MAX_ROUTED];  // k_j * beta_c
+  for (int i = threadIdx.x; i < 2 * (int)a.num_routed; i += blockDim.x) {
+    const int c = i / (int)a.num_routed, j = i - c * (int)a.num_routed;
+    kb[i] = gl::mul(a.k_is[j], a.chal[CH_BETAS + c]);
+  }
   __syncthreads();
   const uint32_t lde_bits = a.degree_bits + a.rate_bits;
   const size_t big = (size_t)1 << lde_bits;
@@ -258,8 +293,7 @@ __global__ __launch_bounds__(128) void k_quotient(QuotientArgs a) {
   u64 res[2] = {0, 0};
   // --- L_0(x) (Z_c(x) - 1): terms 0..NC
   {
-    u64 n_field = (u64)1 << a.degree_bits;
-    u64 l0 = gl::mul(zhx, gl::inv(gl::mul(n_field, gl::sub(x, 1))));
+    u64 l0 = gl::mul(zhx, a.l0_inv[p]);  // 1 / (n (x - 1)), per circuit (k_l0_inv)
     for (int c = 0; c < NC; c++) {
       u64 t = gl::mul(l0, gl::sub(zs[(size_t)c * big], 1));
       res[0] = gl::add(res[0], gl::mul(t, ap[c]));
@@ -271,13 +305,16 @@ __global__ __launch_bounds__(128) void k_quotient(QuotientArgs a) {
     const u64 beta = a.chal[CH_BETAS + c], gamma = a.chal[CH_GAMMAS + c];
     for (int k = 0; k < nch; k++) {
       u64 np = 1, dp = 1;
+      // beta * k_j * x: k_j * beta comes from a per-proof table (k_alpha_pows fills it)
       for (int j = k * per; j < (k + 1) * per && j < RW; j++) {
         u64 w = wr[(size_t)j * big];
-        u64 s_id = gl::mul(a.k_is[j], x);
         u64 sg = cs[(size_t)(n_consts + 2 + j) * big];
-        np = gl::mul(np, gl::add(gl::add(w, gl::mul(beta, s_id)), gamma));
-        dp = gl::mul(dp, gl::add(gl::add(w, gl::mul(beta, sg)), gamma));
+        u64 wg = gl::add(w, gamma);
+        np = gl::mul_nc(np, gl::add(wg, gl::mul(kb[c * RW + j], x)));
+        dp = gl::mul_nc(dp, gl::add(wg, gl::mul(beta, sg)));
       }
+      np = gl::canon(np);
+      dp = gl::canon(dp);
       u64 prev = k == 0 ? zs[(size_t)c * big] : zs[(size_t)(NC + c * NP + k - 1) * big];
       u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zs[(size_t)(NC + c * NP + k) * big];
       u64 t = gl::sub(gl::mul(prev, np), gl::mul(next, dp));
@@ -291,8 +328,7 @@ __global__ __launch_bounds__(128) void k_quotient(QuotientArgs a) {
     Ctx cx;
     cx.wires = wr;
     cx.big = big;
-    cx.ap0 = ap;
-    cx.ap1 = ap + ALPHA_POWS;
+    cx.apl = apl;
     const u64 k0 = cs[(size_t)n_consts * big], k1 = cs[(size_t)(n_consts + 1) * big];
     u64 g0 = 0, g1 = 0;
     for (uint32_t gi = 0; gi < a.n_gates; gi++) {
@@ -327,7 +363,22 @@ __global__ __launch_bounds__(128) void k_quotient(QuotientArgs a) {
   a.out[big + p] = gl::mul(res[1], zhi);
 }
 
+// out[p] = 1 / (n (x_p - 1)), x_p = g w_big^rev(p): the point-dependent factor of L_0(x) = Z_H(x) / (n (x - 1)).
+__global__ __launch_bounds__(256) void k_l0_inv(const u64* __restrict__ pow_big, uint32_t degree_bits,
+                                                uint32_t lde_bits, u64* __restrict__ out) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >> lde_bits) return;
+  const u64 x = gl::mul(gl::GENERATOR, pow_big[gl::bitrev((u32)p, lde_bits)]);
+  out[p] = gl::inv(gl::mul((u64)1 << degree_bits, gl::sub(x, 1)));
+}
+void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bits, u64* d_out, hipStream_t st) {
+  const size_t big = (size_t)1 << (degree_bits + rate_bits);
+  hipLaunchKernelGGL(k_l0_inv, dim3((unsigned)((big + 255) / 256)), dim3(256), 0, st, d_pow_big, degree_bits,
+                     degree_bits + rate_bits, d_out);
+}
+
 void launch_quotient(const QuotientArgs& a, hipStream_t st) {
+  if (a.num_routed > (uint32_t)MAX_ROUTED) throw std::runtime_error("quotient: more than MAX_ROUTED routed wires");
   const size_t big = (size_t)1 << (a.degree_bits + a.rate_bits);
   hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
 }

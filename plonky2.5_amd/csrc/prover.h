@@ -79,7 +79,7 @@ class DeviceCircuit {
   ProofLayout layout_;
   NttTables tables_;
   DeviceWitnessProgram wp_;
-  DevMem cs_vals_, cs_coeffs_, cs_lde_, cs_tree_, k_is_, preamble_;
+  DevMem cs_vals_, cs_coeffs_, cs_lde_, cs_tree_, k_is_, preamble_, l0_inv_;
   u64 digest_[4];
   std::vector<u64> cs_cap_;
   QuotientArgs qa_proto_;

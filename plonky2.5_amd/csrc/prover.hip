@@ -205,6 +205,10 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
       qa_proto_.zh_inv[k] = gl::inv(qa_proto_.zh[k]);
     }
   }
+  l0_inv_ = DevMem(big());
+  launch_l0_inv(qa_proto_.pow_big, c_.degree_bits, c_.cfg.rate_bits, l0_inv_.p, stream_);
+  P25_HIP(hipStreamSynchronize(stream_));
+  qa_proto_.l0_inv = l0_inv_.p;
 }
 
 DeviceCircuit::~DeviceCircuit() {

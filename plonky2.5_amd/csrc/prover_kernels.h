@@ -56,9 +56,11 @@ struct QuotientArgs {
   GateEntry gates[16];
   uint32_t n_gates, num_selectors, num_wires, num_routed, num_partial_products, degree_bits, rate_bits;
   u64 zh[8], zh_inv[8];  // Z_H on the coset (index = i mod 2^rate_bits), and inverses
-  u64 n_inv_unused;
+  const u64* l0_inv;     // [big] 1 / (n (x - 1)) at bit-reversed positions (per circuit)
 };
 constexpr int ALPHA_POWS = 192;
+constexpr int MAX_ROUTED = 128;
+void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bits, u64* d_out, hipStream_t st);
 void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st);
 void launch_quotient(const QuotientArgs& a, hipStream_t st);
 

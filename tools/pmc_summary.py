@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --pmc ... --kernel-trace CSV pair per kernel (second half of the run = the
+timed prove call of tools/prove_one.py).  usage: pmc_summary.py <dir with *_counter_collection.csv>"""
+import collections, csv, glob, json, os, sys
+d = sys.argv[1]
+cc = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0])))
+kt = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0])))
+ids = sorted(int(r["Dispatch_Id"]) for r in kt)
+half = ids[len(ids) // 2]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in kt:
+    if int(r["Dispatch_Id"]) <= half: continue
+    k = r["Kernel_Name"].split("(")[0]
+    agg[k]["dur_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); agg[k]["calls"] += 1
+for r in cc:
+    if int(r["Dispatch_Id"]) <= half: continue
+    agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
+rows = sorted(agg.items(), key=lambda kv: -kv[1]["dur_ns"])
+names = sorted({c for _, v in rows for c in v if c not in ("dur_ns", "calls")})
+print(f"{'kernel':28s} calls  dur_ms " + " ".join(f"{n[:14]:>14s}" for n in names))
+for k, v in rows:
+    print(f"{k[:28]:28s} {int(v['calls']):5d} {v['dur_ns']/1e6:7.3f} " + " ".join(f"{v[n]/1e6:14.2f}" for n in names))
+tot = {n: sum(v[n] for _, v in rows) for n in names}
+print("TOTAL (millions):", {n: round(t / 1e6, 1) for n, t in tot.items()}, "dur_ms", round(sum(v["dur_ns"] for _, v in rows) / 1e6, 3))
+if len(sys.argv) > 2:
+    json.dump({k: dict(v) for k, v in rows}, open(sys.argv[2], "w"), indent=1)
