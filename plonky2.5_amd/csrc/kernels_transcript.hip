@@ -110,14 +110,17 @@ __global__ void k_pow_init(u64* result) { *result = ~0ull; }
 
 void launch_pow_search(const Transcript* d_tr, int pow_bits, u64* d_result, hipStream_t st) {
   hipLaunchKernelGGL(k_pow_init, dim3(1), dim3(1), 0, st, d_result);
-  // expected number of candidates 2^pow_bits; each window is skipped once a witness is known.
-  // windows of 2^(pow_bits+2) candidates: P(no witness in a window) = e^-4, so ~1.02 windows do work on
-  // average; all 12 windows fail with probability e^-48 (reported as P25_ERR_INTERNAL by k_finish).
-  const u64 window = (u64)1 << (pow_bits + 2 < 12 ? 12 : pow_bits + 2);
-  int n_windows = 12;
-  for (int w = 0; w < n_windows; w++)
-    hipLaunchKernelGGL(k_pow_search, dim3((unsigned)(window / 256)), dim3(256), 0, st, d_tr, pow_bits,
-                       (u64)w * window, d_result);
+  // Expected number of candidates is 2^pow_bits; a window is skipped once a smaller witness is known.
+  // Windows grow geometrically -- 1, 1, 2, 4, ... x 2^pow_bits candidates, 2^(pow_bits+6) in total -- so
+  // the expected work is ~1.7 x 2^pow_bits permutations (a flat 2^(pow_bits+2) window costs 4 x) and all
+  // windows fail with probability e^-64 (reported as P25_ERR_INTERNAL by k_finish).
+  const int wb = pow_bits < 12 ? 12 : pow_bits;
+  u64 base = 0;
+  for (int w = 0; w < 7; w++) {
+    const u64 window = (u64)1 << (w == 0 ? wb : wb + w - 1);
+    hipLaunchKernelGGL(k_pow_search, dim3((unsigned)(window / 256)), dim3(256), 0, st, d_tr, pow_bits, base, d_result);
+    base += window;
+  }
 }
 
 }  // namespace p25
