@@ -147,10 +147,10 @@ def main():
                 traffic = None
         total_proofs = world * B * args.steps
         # Integer-VALU view of the same run (the bound that actually binds): wave-level VALU instructions
-        # per proof from the committed PMC pass (SQ_INSTS_VALU, profiles/r01_c_pmc_valu_per_kernel.json)
+        # per proof from the committed PMC pass (SQ_INSTS_VALU, profiles/r01_d_pmc_SQ_INSTS_VALU.json)
         # x proofs/s per GPU, against one VALU instruction per 4 cycles per SIMD (1024 SIMDs, 2.4 GHz).
         valu = None
-        vp = os.path.join(ROOT, "profiles", "r01_c_pmc_valu_per_kernel.json")
+        vp = os.path.join(ROOT, "profiles", "r01_d_pmc_SQ_INSTS_VALU.json")
         if os.path.exists(vp) and args.log_n == 6:
             try:
                 per_kernel = json.load(open(vp))
@@ -159,11 +159,38 @@ def main():
                 ach = instr_per_proof * (total_proofs / elapsed) / world
                 valu = {"wave_instr_per_proof": instr_per_proof, "achieved_wave_instr_per_s": ach,
                         "peak_wave_instr_per_s": peak, "frac": ach / peak,
-                        "dominant_kernel_share": per_kernel.get("p25::k_hash_leaves", {}).get("SQ_INSTS_VALU", 0.0)
-                        / instr_per_proof,
+                        "leaf_hash_share": sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in per_kernel.items()
+                                               if "k_hash_leaves" in k) / instr_per_proof,
                         "note": "peak at the nominal 2.4 GHz; rocm-smi shows sclk 2.05-2.25 GHz under this load"}
             except Exception:
                 valu = None
+        # HBM view per phase and overall: algorithmic bytes of each phase -- inputs read
+        # once, outputs written once -- over that phase's device time for one proof alone on the GPU, and
+        # all phases x proofs/s for the batch run.
+        n_small, nw = 1 << int(info.degree_bits), int(info.num_wires)
+        nr, ncs = int(info.num_routed_wires), int(info.num_constants_sigmas)
+        npp = -(-nr // 8) - 1          # chunks of 8 routed wires (max quotient degree factor) minus the Z column
+        nz = 2 * (1 + npp)
+        W = 8
+        ntt = lambda cols: cols * (2 * n_small + n_big) * W           # read values, write coeffs, write LDE
+        mrk = lambda cols: n_big * cols * W + 2 * n_big * 32            # read LDE, write digests + inner levels
+        phase_bytes = {
+            "witness_ms": n_small * nw * W,
+            "wires_commit_ms": ntt(nw) + mrk(nw),
+            "partial_products_ms": n_small * 2 * nr * W + n_small * nz * W,
+            "zs_commit_ms": ntt(nz) + mrk(nz),
+            "quotient_ms": n_big * (nw + ncs + nz + 2) * W + n_big * 2 * W,
+            "quotient_commit_ms": 2 * n_big * 2 * W + ntt(16) + mrk(16),
+            "openings_ms": (nw + ncs + nz + 16) * n_small * W,
+            "fri_ms": (nw + ncs + nz + 16) * n_small * W + 30e6,
+        }
+        tmd = tm.as_dict()
+        hbm_phases = {k[:-3]: {"alg_MB": round(b / 1e6, 1), "GBps_single_proof": round(b / (tmd[k] * 1e-3) / 1e9, 1)}
+                      for k, b in phase_bytes.items() if tmd.get(k, 0) > 0}
+        bytes_per_proof = float(sum(phase_bytes.values()))
+        hbm_overall = {"alg_GB_per_proof": round(bytes_per_proof / 1e9, 3),
+                       "achieved_GBps": round(bytes_per_proof * (total_proofs / elapsed) / world / 1e9, 1),
+                       "frac_of_peak": round(bytes_per_proof * (total_proofs / elapsed) / world / 1e9 / HBM_PEAK_GBS, 4)}
         out = {
             "metric": "recursive proofs/sec (fib-64 p3-in-p2 circuit)",
             "value": total_proofs / elapsed,
@@ -185,14 +212,14 @@ def main():
                        "proofs_per_gpu_per_step": B, "all_statuses_ok": ok,
                        "oracle_verifier_accepts": vcode == 0, "circuit_build_s": round(build_s, 2),
                        "phase_ms_single_proof": {k: round(v, 3) for k, v in tm.as_dict().items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_hash_leaves (Poseidon sponge, 2^19 leaves x 135 words)",
+            "roofline": {"bound": "hbm", "kernel": "k_hash_leaves_wide (Poseidon sponge, 2^19 leaves x 135 words)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(k_launches), "algorithmic_bytes": algo_bytes,
                          "note": "integer-VALU bound (17 Poseidon permutations per leaf), not HBM bound; "
                                  "avg_launch_ms is measured with 12 proofs in flight sharing the GPU "
                                  "(4.5 ms when the kernel runs alone)",
-                         "valu": valu},
+                         "valu": valu, "hbm_phases": hbm_phases, "hbm_overall": hbm_overall},
         }
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0, N = 1 only
             threads = args.cpu_threads or (os.cpu_count() or 1)

@@ -80,3 +80,14 @@ def test_full_size_merkle_properties(gpu, oracle):
     off = sum(4 * (n >> k) for k in range(12))
     assert (tree[off:off + 4] == capo[0]).all()
     assert cap.shape == (16, 4)
+
+
+def test_handwritten_field_asm_matches_cpp_forms():
+    """tools/asmcheck: the inline-asm Goldilocks multiply, MDS row and permutation of gl.h / poseidon.h
+    against the plain C++ forms of the same functions, on the device (edge cases + 10^6 random pairs)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "build", "asmcheck")
+    assert os.path.exists(exe), "tools/build/asmcheck missing: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ASMCHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -99,9 +99,6 @@ int main() {
     bad_total += bad;
   }
   const size_t m = 1 << 16;
-  hipLaunchKernelGGL(k_dump, dim3(1), dim3(1), 0, 0, o1);
-  CK(hipDeviceSynchronize());
-  for (int i = 0; i < 48; i++) printf("RC_SPLIT[%d] = %016llx\n", 696 + i, (unsigned long long)o1[i]);
   for (int row = 0; row <= 30; row += 5) {
     for (size_t i = 0; i < m * 12; i++) { a[i] = rnd(); if ((i % 5) == 0) a[i] |= 0xFFFFFFFF00000000ull; if ((i % 7) == 0) a[i] |= 0xFFFFFFFFull; }
     for (int i = 0; i < 24; i++) a[i] = ~0ull;
