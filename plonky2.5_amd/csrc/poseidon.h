@@ -147,6 +147,11 @@ static_assert(MDS_CIRC[0] == 17 && MDS_CIRC[1] == 15 && MDS_CIRC[2] == 41 && MDS
                   MDS_CIRC[9] == 18 && MDS_CIRC[10] == 34 && MDS_CIRC[11] == 20 && MDS_DIAG0 == 8,
               "mds_rc hard-codes the MDS entries as inline constants");
 
+#ifndef P25_PARTIAL3
+#define P25_PARTIAL3 1
+#endif
+#include "poseidon_p3r.h"
+
 __device__ __forceinline__ void permute_dev(u64 s[WIDTH]) {
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) s[i] = add_rc(s[i], RC[i]);
@@ -160,10 +165,22 @@ __device__ __forceinline__ void permute_dev(u64 s[WIDTH]) {
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
     mds_rc(s, rc + 2 * WIDTH * r);
   }
+#if P25_PARTIAL3
+  // 21 partial rounds as 7 blocks of three (poseidon_p3r.h), the 22nd round by round
+  p3r::tbl_ptr tp = (p3r::tbl_ptr)&p3r::TBL;
+  asm("" : "+s"(tp));
+  for (int b = 0; b < p3r::BLOCKS; b++) p3r::three_rounds(s, tp, b);
+  r += 3 * p3r::BLOCKS;
+  for (int k = 3 * p3r::BLOCKS; k < N_PARTIAL; k++, r++) {
+    s[0] = sbox(s[0]);
+    mds_rc(s, rc + 2 * WIDTH * r);
+  }
+#else
   for (int k = 0; k < N_PARTIAL; k++, r++) {
     s[0] = sbox(s[0]);
     mds_rc(s, rc + 2 * WIDTH * r);
   }
+#endif
   for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
