@@ -23,7 +23,7 @@ import numpy as np
 
 # libp25 sets this itself when it is loaded; torch may initialise HIP first, so set it here too
 # (hardware queues the runtime spreads the prover's streams over -- see capi.hip).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -147,10 +147,10 @@ def main():
                 traffic = None
         total_proofs = world * B * args.steps
         # Integer-VALU view of the same run (the bound that actually binds): wave-level VALU instructions
-        # per proof from the committed PMC pass (SQ_INSTS_VALU, profiles/r01_d_pmc_SQ_INSTS_VALU.json)
+        # per proof from the committed PMC pass (SQ_INSTS_VALU, profiles/r01_e_pmc_SQ_INSTS_VALU.json)
         # x proofs/s per GPU, against one VALU instruction per 4 cycles per SIMD (1024 SIMDs, 2.4 GHz).
         valu = None
-        vp = os.path.join(ROOT, "profiles", "r01_d_pmc_SQ_INSTS_VALU.json")
+        vp = os.path.join(ROOT, "profiles", "r01_e_pmc_SQ_INSTS_VALU.json")
         if os.path.exists(vp) and args.log_n == 6:
             try:
                 per_kernel = json.load(open(vp))
@@ -217,8 +217,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(k_launches), "algorithmic_bytes": algo_bytes,
                          "note": "integer-VALU bound (17 Poseidon permutations per leaf), not HBM bound; "
-                                 "avg_launch_ms is measured with 12 proofs in flight sharing the GPU "
-                                 "(4.5 ms when the kernel runs alone)",
+                                 "avg_launch_ms is measured with 16 proofs in flight sharing the GPU "
+                                 "(3.6 ms when the kernel runs alone)",
                          "valu": valu, "hbm_phases": hbm_phases, "hbm_overall": hbm_overall},
         }
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0, N = 1 only

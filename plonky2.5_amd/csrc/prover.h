@@ -72,6 +72,7 @@ class DeviceCircuit {
  private:
   struct Ctx;  // per-proof working set
   void prove_one(Ctx& cx, const u64* d_vals, size_t B, uint32_t p, u64* d_proof, uint32_t* d_status, PhaseTimes* t);
+  size_t ctx_bytes() const;
   void ensure_ctx(size_t count);
   void ensure_vals(size_t batch);
 

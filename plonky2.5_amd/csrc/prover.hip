@@ -512,7 +512,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
 
 static size_t streams_in_flight() {
   const char* e = getenv("P25_STREAMS");
-  int k = e ? atoi(e) : 12;
+  int k = e ? atoi(e) : 16;
   return (size_t)(k < 1 ? 1 : (k > 16 ? 16 : k));
 }
 
@@ -520,9 +520,28 @@ static size_t streams_in_flight() {
 // parallel ACROSS proofs), then each proof's commit/quotient/FRI pipeline on one of K streams so that
 // the latency-bound stretches of one proof (transcript, Merkle-cap levels, FRI tail) overlap with the
 // throughput-bound kernels of the others.
+// Approximate device bytes of one proof context (see ensure_ctx): the LDE matrices dominate.
+size_t DeviceCircuit::ctx_bytes() const {
+  const size_t n = c_.degree(), B = (size_t)1 << (c_.degree_bits + c_.cfg.rate_bits);
+  const size_t W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;
+  const size_t nz = NC * (1 + NP), nq = NC * c_.cfg.max_quotient_degree_factor;
+  const size_t tw = merkle_tree_words(B, c_.cfg.cap_height);
+  return 8 * (3 * W * n + W * B + 2 * nz * n + nz * B + 3 * NC * B + nq * B + 3 * tw + 16 * n + 6 * B);
+}
+
 void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs,
                                     size_t proof_stride, uint32_t* d_status, PhaseTimes* times) {
-  const size_t K = times ? 1 : streams_in_flight();
+  size_t K = times ? 1 : streams_in_flight();
+  if (K > n_proofs) K = n_proofs ? n_proofs : 1;
+  {
+    // keep the in-flight contexts within ~60% of the device memory (matters for 2^19-row circuits: 13 GB each)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
+      size_t fit = (size_t)(0.6 * (double)total_b) / ctx_bytes();
+      if (fit < 1) fit = 1;
+      if (K > fit) K = fit;
+    }
+  }
   ensure_ctx(K);
   const size_t MAXB = 64;
   for (size_t base = 0; base < n_proofs; base += MAXB) {

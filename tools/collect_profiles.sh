@@ -9,12 +9,6 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/${TAG}_pytest_gpu.txt 2>&1
-python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
-# rocprofv3 per-kernel summary of a bench run (the same command, smaller batch)
-rm -rf $OUT/_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_prof -- python3 bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_b64_rocprof.json 2> $OUT/_prof.err
-find $OUT/_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_rocprofv3_kernel_stats_bench_b64.csv
-rm -rf $OUT/_prof
 # PMC passes (each alone with --kernel-trace), one proof
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $C | cut -d' ' -f1)
@@ -23,6 +17,14 @@ for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS" "FETCH_SIZE" "WRITE
   python3 tools/pmc_summary.py $OUT/_pmc $OUT/${TAG}_pmc_${N}.json > $OUT/${TAG}_pmc_${N}.txt
   rm -rf $OUT/_pmc
 done
+cp $OUT/${TAG}_pmc_SQ_INSTS_VALU.json profiles/ 2>/dev/null   # bench.py reads the VALU counts from profiles/
+python3 tools/make_traffic_json.py ${TAG} > /dev/null
+python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+# rocprofv3 per-kernel summary of a bench run (the same command, smaller batch)
+rm -rf $OUT/_prof
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_prof -- python3 bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_b64_rocprof.json 2> $OUT/_prof.err
+find $OUT/_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_rocprofv3_kernel_stats_bench_b64.csv
+rm -rf $OUT/_prof
 python tools/run_config5.py 20 > $OUT/${TAG}_config5.txt 2>&1
 tail -2 $OUT/${TAG}_pytest_gpu.txt
 cut -c1-160 $OUT/${TAG}_bench_default.json
