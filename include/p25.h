@@ -109,6 +109,35 @@ enum { P25_AIR_FIBONACCI = 0 }; /* the test AIR of src/p3/mod.rs:160-221 */
  *           builder.p3_verify_proof::<PoseidonHash>(proof, &air, fri_config);
  *           builder.build::<PoseidonGoldilocksConfig>()          (src/p3/mod.rs:231-250). */
 p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, p25_circuit** out);
+/* An AIR as data.  The reference's plugin interface for the inner STARK is the Rust
+ * trait `Air` (src/p3/air.rs:10-18) whose `eval` body is code; across the C ABI the same information is
+ * an expression DAG.  node.op: 0 LOCAL(column a of the current row)  1 NEXT(column a of the next row)
+ * 2 CONST(value)  3 ADD(a,b)  4 SUB(a,b)  5 MUL(a,b), a/b = indices of EARLIER nodes.  A constraint is a
+ * node that must vanish on the rows `when` selects (0 always, 1 first row, 2 last row, 3 transition),
+ * folded in order like VerifierConstraintFolder (air.rs:69-118).  Degree (selector included) <= 2: the
+ * reference's proof model has one quotient chunk (serde/proof.rs:41-48).  The FibonacciAir of
+ * src/p3/mod.rs:176-221 in this form builds the very same circuit (same digest) as P25_AIR_FIBONACCI. */
+typedef struct {
+  uint32_t op, a, b, reserved;
+  uint64_t value;
+} p25_air_node;
+typedef struct {
+  uint32_t node, when;
+} p25_air_constraint;
+typedef struct {
+  uint32_t width, n_nodes, n_constraints, reserved;
+  const p25_air_node* nodes;
+  const p25_air_constraint* constraints;
+} p25_air;
+/* p3_verify_proof for a user AIR: `builder.p3_verify_proof::<H>(proof, &air, fri_config)` with any `impl Air`
+ * (src/p3/mod.rs:66-94, 239-250).  cfg->trace_width must equal air->width. */
+p25_status p25_circuit_build_p3_verifier_air(const p25_p3_config* cfg, const p25_air* air, p25_circuit** out);
+/* Native plonky3 prover (see p25_p3_prove_fibonacci) for a user AIR and its trace, trace[row * width + col],
+ * 2^log_n rows.  P25_ERR_INVALID_ARG if the trace does not satisfy the AIR. */
+p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t log_n, int32_t num_queries,
+                            int32_t pow_bits, uint64_t pow_start, int32_t threads, uint64_t* inputs_out, size_t cap,
+                            size_t* n_out, p25_p3_config* cfg_out);
+
 /* Small circuits mirroring the reference's gadget tests (src/p3/mod.rs:271-494 test_p3_and / xor / lsh /
  * rsh / reverse, src/p3/commit.rs:173-198 test_compress): kind 0 and(x,y) 1 xor(x,y) 2 lsh(x,param)
  * 3 rsh(x,param) 4 reverse_bits_len(x,param) 5 Poseidon2 compress(l[4],r[4]) 6 7*w_param^e with inverse.

@@ -6,7 +6,8 @@ import numpy as np
 
 __all__ = ["P25Error", "lib", "lib_path", "device_init", "poseidon_permute", "poseidon2_permute",
            "merkle_commit", "merkle_tree_words", "lde_commit", "EXPORTED_SYMBOLS", "P",
-           "P3Config", "Circuit", "p3_proof_from_json", "Timings", "p3_prove_fibonacci", "p3_inputs_to_json"]
+           "P3Config", "Circuit", "p3_proof_from_json", "Timings", "p3_prove_fibonacci", "p3_inputs_to_json",
+           "Air", "p3_prove_air"]
 
 P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,6 +32,68 @@ class P3Config(C.Structure):
     @classmethod
     def fib64(cls):
         return cls(1, 100, 16, 0, 6, 3, 7, 2, 6)
+
+
+class AirNode(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("reserved", C.c_uint32), ("value", C.c_uint64)]
+
+
+class AirConstraint(C.Structure):
+    _fields_ = [("node", C.c_uint32), ("when", C.c_uint32)]
+
+
+class AirC(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("n_nodes", C.c_uint32), ("n_constraints", C.c_uint32), ("reserved", C.c_uint32),
+                ("nodes", C.POINTER(AirNode)), ("constraints", C.POINTER(AirConstraint))]
+
+
+class Air:
+    """An AIR as an expression DAG (p25_air in include/p25.h): the data form of the reference's `Air` trait
+    (src/p3/air.rs:10-18).  Build it like the trait's `eval` body:
+
+        air = Air(3); a, b, c = air.local(0), air.local(1), air.local(2)
+        air.assert_zero(air.sub(air.add(a, b), c)); air.when_first_row(air.sub(air.const(1), a)); ...
+    """
+    ALWAYS, FIRST_ROW, LAST_ROW, TRANSITION = 0, 1, 2, 3
+
+    def __init__(self, width):
+        self.width, self.nodes, self.constraints = width, [], []
+
+    def _n(self, op, a=0, b=0, value=0):
+        self.nodes.append((op, a, b, value))
+        return len(self.nodes) - 1
+
+    def local(self, col): return self._n(0, col)
+    def next(self, col): return self._n(1, col)
+    def const(self, v): return self._n(2, 0, 0, int(v))
+    def add(self, x, y): return self._n(3, x, y)
+    def sub(self, x, y): return self._n(4, x, y)
+    def mul(self, x, y): return self._n(5, x, y)
+    def assert_zero(self, x, when=0): self.constraints.append((x, when))
+    def when_first_row(self, x): self.assert_zero(x, 1)
+    def when_last_row(self, x): self.assert_zero(x, 2)
+    def when_transition(self, x): self.assert_zero(x, 3)
+
+    @classmethod
+    def fibonacci(cls):
+        """src/p3/mod.rs:176-221, constraint for constraint."""
+        air = cls(3)
+        la, lb, lc = air.local(0), air.local(1), air.local(2)
+        na, nb = air.next(0), air.next(1)
+        air.assert_zero(air.sub(air.add(la, lb), lc))
+        one = air.const(1)
+        air.when_first_row(air.sub(one, la))
+        air.when_first_row(air.sub(one, lb))
+        air.when_transition(air.sub(na, lb))
+        air.when_transition(air.sub(nb, lc))
+        return air
+
+    def to_c(self):
+        nodes = (AirNode * len(self.nodes))(*[AirNode(op, a, b, 0, v) for op, a, b, v in self.nodes])
+        cons = (AirConstraint * len(self.constraints))(*[AirConstraint(n, w) for n, w in self.constraints])
+        c = AirC(self.width, len(self.nodes), len(self.constraints), 0, nodes, cons)
+        c._keep = (nodes, cons)
+        return c
 
 
 class CircuitInfo(C.Structure):
@@ -81,6 +144,9 @@ EXPORTED_SYMBOLS = {
     "p25_proof_to_json": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
     "p25_p3_prove_fibonacci": (i32, [i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
     "p25_p3_inputs_to_json": (i32, [vp, sz, C.POINTER(P3Config), vp, sz, C.POINTER(sz)]),
+    "p25_circuit_build_p3_verifier_air": (i32, [C.POINTER(P3Config), C.POINTER(AirC), C.POINTER(vp)]),
+    "p25_p3_prove_air": (i32, [C.POINTER(AirC), vp, i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz),
+                               C.POINTER(P3Config)]),
 }
 
 
@@ -181,6 +247,24 @@ def p3_prove_fibonacci(log_n=6, num_queries=100, pow_bits=16, pow_start=0, threa
     return out, cfg
 
 
+def p3_prove_air(air, trace, num_queries=100, pow_bits=16, pow_start=0, threads=None):
+    """Native plonky3 proof of `air` (binding.Air) on `trace` (uint64[2^log_n][width]) -> (inputs, P3Config)."""
+    threads = threads or min(16, os.cpu_count() or 1)
+    t = np.ascontiguousarray(trace, dtype=np.uint64)
+    if t.ndim != 2 or t.shape[1] != air.width or t.shape[0] & (t.shape[0] - 1) or t.shape[0] < 2:
+        raise ValueError("trace must be [2^log_n][air.width]")
+    log_n = int(t.shape[0]).bit_length() - 1
+    ac = air.to_c()
+    n = sz(0)
+    cfg = P3Config()
+    _check(lib().p25_p3_prove_air(C.byref(ac), None, log_n, num_queries, pow_bits, pow_start, threads, None, 0,
+                                  C.byref(n), C.byref(cfg)))
+    out = np.zeros(n.value, dtype=np.uint64)
+    _check(lib().p25_p3_prove_air(C.byref(ac), _ptr(t), log_n, num_queries, pow_bits, pow_start, threads, _ptr(out),
+                                  out.size, C.byref(n), C.byref(cfg)))
+    return out, cfg
+
+
 def p3_inputs_to_json(inputs, cfg):
     a = _u64(inputs)
     n = sz(0)
@@ -203,6 +287,14 @@ class Circuit:
         cfg = cfg or P3Config.fib64()
         h = vp()
         _check(lib().p25_circuit_build_p3_verifier(C.byref(cfg), air, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def build_p3_verifier_air(cls, cfg, air):
+        """`builder.p3_verify_proof::<H>(proof, &air, fri_config)` for a user AIR (binding.Air)."""
+        h = vp()
+        ac = air.to_c()
+        _check(lib().p25_circuit_build_p3_verifier_air(C.byref(cfg), C.byref(ac), C.byref(h)))
         return cls(h.value)
 
     @classmethod

@@ -261,34 +261,61 @@ static p25_status host_guarded(F&& f) {
 
 extern "C" {
 
+static p25::P3Config checked_p3_config(const p25_p3_config* cfg) {
+  if (cfg->log_quotient_degree != 0) throw std::invalid_argument("only one quotient chunk is supported (proof.rs:41-48)");
+  if (cfg->trace_width < 1 || cfg->trace_width > 64 || cfg->log_trace_height < 1 || cfg->log_trace_height > 24 ||
+      cfg->num_queries < 1 || cfg->num_queries > 1000 || cfg->degree_bits < 1 || cfg->degree_bits > cfg->log_trace_height ||
+      cfg->opening_matrix_log_max_height < 1 || cfg->opening_matrix_log_max_height > 30 || cfg->quotient_opened_len < 1 ||
+      cfg->log_blowup < 1 || cfg->log_blowup > 4 || cfg->proof_of_work_bits < 0 || cfg->proof_of_work_bits > 32)
+    throw std::invalid_argument("p25_p3_config out of range");
+  p25::P3Config pc;
+  pc.fri_config.log_blowup = cfg->log_blowup;
+  pc.fri_config.num_queries = cfg->num_queries;
+  pc.fri_config.proof_of_work_bits = cfg->proof_of_work_bits;
+  pc.log_quotient_degree = cfg->log_quotient_degree;
+  pc.log_trace_height = cfg->log_trace_height;
+  pc.trace_width = cfg->trace_width;
+  pc.opening_matrix_log_max_height = cfg->opening_matrix_log_max_height;
+  pc.opening_proof_query_openings_opened_values_length = cfg->quotient_opened_len;
+  pc.degree_bits = cfg->degree_bits;
+  return pc;
+}
+static p25::AirProgram air_from_c(const p25_air* air) {
+  if (!air || !air->nodes || !air->constraints) throw std::invalid_argument("null AIR");
+  if (air->n_nodes > (1u << 20) || air->n_constraints > (1u << 16)) throw std::invalid_argument("AIR too large");
+  p25::AirProgram p;
+  p.width = (int)air->width;
+  for (uint32_t i = 0; i < air->n_nodes; i++)
+    p.nodes.push_back(p25::AirProgram::Node{air->nodes[i].op, air->nodes[i].a, air->nodes[i].b, air->nodes[i].value});
+  for (uint32_t i = 0; i < air->n_constraints; i++)
+    p.constraints.push_back(p25::AirProgram::Constraint{air->constraints[i].node, air->constraints[i].when});
+  p.validate();
+  return p;
+}
+static p25_status build_verifier(const p25_p3_config* cfg, const p25::Air& air, p25_circuit** out) {
+  p25::P3Config pc = checked_p3_config(cfg);
+  if (pc.trace_width != air.width()) throw std::invalid_argument("Invalid Proof Shape");
+  p25::CircuitBuilder cb;
+  p25::p3_verify_proof(cb, pc, air);
+  auto* h = new p25_circuit();
+  h->circuit = cb.build();
+  *out = h;
+  return P25_OK;
+}
+
 p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, p25_circuit** out) {
   return host_guarded([&]() -> p25_status {
     if (!cfg || !out) throw std::invalid_argument("null argument");
     if (air != P25_AIR_FIBONACCI) throw std::invalid_argument("unknown AIR");
-    if (cfg->log_quotient_degree != 0) throw std::invalid_argument("only one quotient chunk is supported (proof.rs:41-48)");
-    if (cfg->trace_width < 1 || cfg->trace_width > 64 || cfg->log_trace_height < 1 || cfg->log_trace_height > 24 ||
-        cfg->num_queries < 1 || cfg->num_queries > 1000 || cfg->degree_bits < 1 || cfg->degree_bits > cfg->log_trace_height ||
-        cfg->opening_matrix_log_max_height < 1 || cfg->opening_matrix_log_max_height > 30 || cfg->quotient_opened_len < 1 ||
-        cfg->log_blowup < 1 || cfg->log_blowup > 4 || cfg->proof_of_work_bits < 0 || cfg->proof_of_work_bits > 32)
-      throw std::invalid_argument("p25_p3_config out of range");
-    p25::P3Config pc;
-    pc.fri_config.log_blowup = cfg->log_blowup;
-    pc.fri_config.num_queries = cfg->num_queries;
-    pc.fri_config.proof_of_work_bits = cfg->proof_of_work_bits;
-    pc.log_quotient_degree = cfg->log_quotient_degree;
-    pc.log_trace_height = cfg->log_trace_height;
-    pc.trace_width = cfg->trace_width;
-    pc.opening_matrix_log_max_height = cfg->opening_matrix_log_max_height;
-    pc.opening_proof_query_openings_opened_values_length = cfg->quotient_opened_len;
-    pc.degree_bits = cfg->degree_bits;
-    p25::CircuitBuilder cb;
     p25::FibonacciAir fib;
-    if (pc.trace_width != fib.width()) throw std::invalid_argument("Invalid Proof Shape");
-    p25::p3_verify_proof(cb, pc, fib);
-    auto* h = new p25_circuit();
-    h->circuit = cb.build();
-    *out = h;
-    return P25_OK;
+    return build_verifier(cfg, fib, out);
+  });
+}
+p25_status p25_circuit_build_p3_verifier_air(const p25_p3_config* cfg, const p25_air* air, p25_circuit** out) {
+  return host_guarded([&]() -> p25_status {
+    if (!cfg || !air || !out) throw std::invalid_argument("null argument");
+    p25::ProgramAir pa(air_from_c(air));
+    return build_verifier(cfg, pa, out);
   });
 }
 
@@ -523,6 +550,52 @@ p25_status p25_p3_prove_fibonacci(int32_t log_n, int32_t num_queries, int32_t po
       return P25_OK;
     }
     std::vector<u64> v = p25::p3_prove_fibonacci(prm, pc);
+    *n_out = v.size();
+    if (cap < v.size()) throw std::invalid_argument("buffer too small");
+    memcpy(inputs_out, v.data(), v.size() * 8);
+    if (cfg_out) cfg_to_c(pc, cfg_out);
+    return P25_OK;
+  });
+}
+p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t log_n, int32_t num_queries,
+                            int32_t pow_bits, uint64_t pow_start, int32_t threads, uint64_t* inputs_out, size_t cap,
+                            size_t* n_out, p25_p3_config* cfg_out) {
+  return host_guarded([&]() -> p25_status {
+    if (!air || !n_out) throw std::invalid_argument("null argument");
+    p25::AirProgram prog = air_from_c(air);
+    p25::P3ProveParams prm;
+    prm.log_n = log_n;
+    prm.num_queries = num_queries;
+    prm.pow_bits = pow_bits;
+    prm.pow_start = pow_start;
+    prm.threads = threads < 1 ? 1 : threads;
+    p25::P3Config pc;
+    pc.fri_config.num_queries = num_queries;
+    pc.log_trace_height = log_n;
+    pc.trace_width = prog.width;
+    pc.opening_matrix_log_max_height = log_n + 1;
+    pc.degree_bits = log_n;
+    if (!inputs_out) {  // size query only
+      if (log_n < 1 || log_n > 22 || num_queries < 1) throw std::invalid_argument("bad parameters");
+      *n_out = pc.num_inputs();
+      if (cfg_out) {
+        pc.fri_config.proof_of_work_bits = pow_bits;
+        cfg_to_c(pc, cfg_out);
+      }
+      return P25_OK;
+    }
+    if (!trace) throw std::invalid_argument("null trace");
+    if (log_n < 1 || log_n > 22) throw std::invalid_argument("bad parameters");
+    const size_t n = (size_t)1 << log_n;
+    std::vector<std::vector<u64>> col(prog.width, std::vector<u64>(n));
+    for (size_t r = 0; r < n; r++)
+      for (int c = 0; c < prog.width; c++) col[c][r] = trace[r * prog.width + c];
+    std::vector<u64> v;
+    try {
+      v = p25::p3_prove_air(prog, col, prm, pc);
+    } catch (const std::logic_error& e) {  // "quotient identity does not hold": the trace violates the AIR
+      throw std::invalid_argument(e.what());
+    }
     *n_out = v.size();
     if (cap < v.size()) throw std::invalid_argument("buffer too small");
     memcpy(inputs_out, v.data(), v.size() * 8);

@@ -379,6 +379,66 @@ void FibonacciAir::eval(VerifierConstraintFolder& folder, CircuitBuilder& cb) co
   folder.when_assert_eq(cb, folder.is_transition, nb, lc);
 }
 
+// ---------------------------------------------------------------- AIR programs
+int AirProgram::node_degree(uint32_t i) const {
+  std::vector<int> deg(i + 1, 0);
+  for (uint32_t k = 0; k <= i; k++) {
+    const Node& nd = nodes[k];
+    if (nd.op == LOCAL || nd.op == NEXT) deg[k] = 1;
+    else if (nd.op == CONST) deg[k] = 0;
+    else if (nd.op == MUL) deg[k] = deg[nd.a] + deg[nd.b];
+    else deg[k] = std::max(deg[nd.a], deg[nd.b]);
+  }
+  return deg[i];
+}
+void AirProgram::validate() const {
+  if (width < 1 || width > 1024) throw std::invalid_argument("AIR: width out of range");
+  if (nodes.empty() || constraints.empty()) throw std::invalid_argument("AIR: empty program");
+  for (size_t i = 0; i < nodes.size(); i++) {
+    const Node& nd = nodes[i];
+    if (nd.op > MUL) throw std::invalid_argument("AIR: unknown node op");
+    if ((nd.op == LOCAL || nd.op == NEXT) && nd.a >= (uint32_t)width) throw std::invalid_argument("AIR: column out of range");
+    if (nd.op >= ADD && (nd.a >= i || nd.b >= i)) throw std::invalid_argument("AIR: node refers to a later node");
+    if (nd.op == CONST && nd.value >= gl::P) throw std::invalid_argument("AIR: non-canonical constant");
+  }
+  for (const Constraint& c : constraints) {
+    if (c.node >= nodes.size() || c.when > TRANSITION) throw std::invalid_argument("AIR: bad constraint");
+    if (node_degree(c.node) + (c.when == ALWAYS ? 0 : 1) > 2)
+      throw std::invalid_argument("AIR: constraint degree > 2 needs more than one quotient chunk (serde/proof.rs:41-48 has one)");
+  }
+}
+AirProgram AirProgram::fibonacci() {
+  AirProgram p;
+  p.width = 3;
+  auto nd = [&](uint32_t op, uint32_t a, uint32_t b, u64 v) {
+    p.nodes.push_back(Node{op, a, b, v});
+    return (uint32_t)p.nodes.size() - 1;
+  };
+  uint32_t la = nd(LOCAL, 0, 0, 0), lb = nd(LOCAL, 1, 0, 0), lc = nd(LOCAL, 2, 0, 0);
+  uint32_t na = nd(NEXT, 0, 0, 0), nb = nd(NEXT, 1, 0, 0);
+  uint32_t s = nd(ADD, la, lb, 0);
+  uint32_t c0 = nd(SUB, s, lc, 0);
+  uint32_t one = nd(CONST, 0, 0, 1);
+  uint32_t c1 = nd(SUB, one, la, 0), c2 = nd(SUB, one, lb, 0);
+  uint32_t c3 = nd(SUB, na, lb, 0), c4 = nd(SUB, nb, lc, 0);
+  p.constraints = {{c0, ALWAYS}, {c1, FIRST_ROW}, {c2, FIRST_ROW}, {c3, TRANSITION}, {c4, TRANSITION}};
+  return p;
+}
+namespace {
+struct CircuitExtOps {
+  CircuitBuilder& cb;
+  Ext cst(u64 v) { return p3_field_to_arr(cb, p3_constant(cb, v)); }
+  Ext add(const Ext& x, const Ext& y) { return p3_ext_add(cb, x, y); }
+  Ext sub(const Ext& x, const Ext& y) { return p3_ext_sub(cb, x, y); }
+  Ext mul(const Ext& x, const Ext& y) { return p3_ext_mul(cb, x, y); }
+};
+}  // namespace
+void ProgramAir::eval(VerifierConstraintFolder& folder, CircuitBuilder& cb) const {
+  CircuitExtOps ops{cb};
+  const Ext sel[4] = {Ext{}, folder.is_first_row, folder.is_last_row, folder.is_transition};
+  prog.fold<Ext>(folder.trace_local, folder.trace_next, sel, ops, [&](const Ext& c) { folder.assert_zero(cb, c); });
+}
+
 // ---------------------------------------------------------------- src/p3/serde/proof.rs:357-373
 size_t P3Config::num_inputs() const {
   size_t n = 8 + (size_t)trace_width * 4 + 4;

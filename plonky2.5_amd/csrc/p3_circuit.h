@@ -71,6 +71,80 @@ struct FibonacciAir : Air {
   void eval(VerifierConstraintFolder& folder, CircuitBuilder& cb) const override;
 };
 
+// An AIR as data: the reference's plugin interface is a Rust trait whose `eval` is code
+// (air.rs:10-18); across a C ABI the same information travels as an expression DAG.  Nodes refer to
+// earlier nodes; a constraint is a node that must vanish on the rows selected by `when`, folded in
+// order exactly as VerifierConstraintFolder does (air.rs:69-118): `always` -> assert_zero(node),
+// otherwise assert_zero(selector * node).  Used by BOTH sides of the path's input: the in-circuit
+// verifier (ProgramAir below) and the native plonky3 prover (p3_prover.h).
+struct AirProgram {
+  enum Op : uint32_t { LOCAL = 0, NEXT = 1, CONST = 2, ADD = 3, SUB = 4, MUL = 5 };
+  enum When : uint32_t { ALWAYS = 0, FIRST_ROW = 1, LAST_ROW = 2, TRANSITION = 3 };
+  struct Node {
+    uint32_t op, a, b;  // LOCAL/NEXT: a = column; ADD/SUB/MUL: a, b = earlier node indices
+    u64 value;          // CONST
+  };
+  struct Constraint {
+    uint32_t node, when;
+  };
+  int width = 0;
+  std::vector<Node> nodes;
+  std::vector<Constraint> constraints;
+  // throws std::invalid_argument on malformed programs and on constraint degree > 2 (selector included):
+  // the reference's proof model carries exactly one quotient chunk (serde/proof.rs:41-48)
+  void validate() const;
+  int node_degree(uint32_t i) const;
+  // the test AIR of src/p3/mod.rs:176-221 in this form (same constraints, same order)
+  static AirProgram fibonacci();
+
+  // Generic evaluation, nodes computed on demand in constraint order (so that the circuit form emits
+  // its gates in the order the reference's hand-written `eval` does).  ops: cst(u64), add, sub, mul.
+  template <class T, class Ops, class Emit>
+  void fold(const std::vector<T>& local, const std::vector<T>& next, const T sel[4], Ops& ops, Emit&& emit) const {
+    std::vector<T> val(nodes.size());
+    std::vector<char> have(nodes.size(), 0);
+    for (const Constraint& c : constraints) {
+      // iterative post-order evaluation of the sub-DAG under c.node
+      std::vector<uint32_t> stack{c.node};
+      while (!stack.empty()) {
+        uint32_t i = stack.back();
+        if (have[i]) {
+          stack.pop_back();
+          continue;
+        }
+        const Node& nd = nodes[i];
+        if (nd.op == LOCAL) {
+          val[i] = local[nd.a];
+        } else if (nd.op == NEXT) {
+          val[i] = next[nd.a];
+        } else if (nd.op == CONST) {
+          val[i] = ops.cst(nd.value);
+        } else {
+          if (!have[nd.a]) {
+            stack.push_back(nd.a);
+            continue;
+          }
+          if (!have[nd.b]) {
+            stack.push_back(nd.b);
+            continue;
+          }
+          val[i] = nd.op == ADD ? ops.add(val[nd.a], val[nd.b]) : nd.op == SUB ? ops.sub(val[nd.a], val[nd.b]) : ops.mul(val[nd.a], val[nd.b]);
+        }
+        have[i] = 1;
+        stack.pop_back();
+      }
+      emit(c.when == ALWAYS ? val[c.node] : ops.mul(sel[c.when], val[c.node]));
+    }
+  }
+};
+struct ProgramAir : Air {
+  AirProgram prog;
+  explicit ProgramAir(AirProgram p) : prog(std::move(p)) { prog.validate(); }
+  std::string name() const override { return "Program"; }
+  int width() const override { return prog.width; }
+  void eval(VerifierConstraintFolder& folder, CircuitBuilder& cb) const override;
+};
+
 // CircuitBuilderP3Arithmetic::p3_verify_proof (src/p3/mod.rs:66-94).  Registers the proof's virtual
 // targets as the circuit's per-proof inputs (cb.input_targets, `add_virtual_to` order).
 P3ProofTarget p3_verify_proof(CircuitBuilder& cb, const P3Config& config, const Air& air);

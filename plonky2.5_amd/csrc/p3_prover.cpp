@@ -154,26 +154,52 @@ Tree commit(const std::vector<u64>& rows, size_t width, int threads) {
 }
 }  // namespace
 
+namespace {
+struct BaseOps {
+  u64 cst(u64 v) { return v; }
+  u64 add(u64 x, u64 y) { return gl::add(x, y); }
+  u64 sub(u64 x, u64 y) { return gl::sub(x, y); }
+  u64 mul(u64 x, u64 y) { return gl::mul(x, y); }
+};
+struct ExtOps {
+  E2 cst(u64 v) { return gl::e2(v); }
+  E2 add(E2 x, E2 y) { return gl::add(x, y); }
+  E2 sub(E2 x, E2 y) { return gl::sub(x, y); }
+  E2 mul(E2 x, E2 y) { return gl::mul(x, y); }
+};
+}  // namespace
+
 std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg) {
+  if (prm.log_n < 1 || prm.log_n > 22) throw std::invalid_argument("p3_prove_fibonacci: unsupported parameters");
+  // trace (src/p3/mod.rs:160-221): a, b, c = a + b; next a = b, next b = c; first row (1, 1)
+  const size_t n = (size_t)1 << prm.log_n;
+  std::vector<std::vector<u64>> col(3, std::vector<u64>(n));
+  u64 a = 1, b = 1;
+  for (size_t i = 0; i < n; i++) {
+    u64 c = gl::add(a, b);
+    col[0][i] = a;
+    col[1][i] = b;
+    col[2][i] = c;
+    a = b;
+    b = c;
+  }
+  return p3_prove_air(AirProgram::fibonacci(), col, prm, cfg);
+}
+
+std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vector<u64>>& col, const P3ProveParams& prm,
+                              P3Config& cfg) {
   if (prm.log_n < 1 || prm.log_n > 22 || prm.log_blowup != 1 || prm.num_queries < 1 || prm.pow_bits < 0 || prm.pow_bits > 30)
-    throw std::invalid_argument("p3_prove_fibonacci: unsupported parameters");
+    throw std::invalid_argument("p3_prove: unsupported parameters");
+  air.validate();
   const int k = prm.log_n, L = k + 1, T = prm.threads;
   const size_t n = (size_t)1 << k, N2 = 2 * n;
   const u64 w_n = gl::root_of_unity(k), w_2n = gl::root_of_unity(L);
-  const int W = 3;
-
-  // trace (src/p3/mod.rs:160-221): a, b, c = a + b; next a = b, next b = c; first row (1, 1)
-  std::vector<std::vector<u64>> col(W, std::vector<u64>(n));
-  {
-    u64 a = 1, b = 1;
-    for (size_t i = 0; i < n; i++) {
-      u64 c = gl::add(a, b);
-      col[0][i] = a;
-      col[1][i] = b;
-      col[2][i] = c;
-      a = b;
-      b = c;
-    }
+  const int W = air.width;
+  if ((int)col.size() != W) throw std::invalid_argument("p3_prove: trace width does not match the AIR");
+  for (auto& c : col) {
+    if (c.size() != n) throw std::invalid_argument("p3_prove: trace height does not match log_n");
+    for (u64 v : c)
+      if (v >= gl::P) throw std::invalid_argument("p3_prove: non-canonical trace value");
   }
   std::vector<std::vector<u64>> coef(col);
   for (auto& c : coef) intt(c);
@@ -198,19 +224,22 @@ std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg) {
     const u64 zh = gl::sub(gl::pow(gl::GENERATOR, n), 1);  // x^n - 1 is constant on the coset
     const u64 zh_inv = gl::inv(zh);
     u64 x = gl::GENERATOR;
+    BaseOps ops;
+    std::vector<u64> loc(W), nxt(W);
     for (size_t j = 0; j < n; j++, x = gl::mul(x, w_n)) {
       const size_t i0 = 2 * j, i1 = (2 * j + 2) % N2;
-      u64 la = lde_nat[0][i0], lb = lde_nat[1][i0], lc = lde_nat[2][i0];
-      u64 na = lde_nat[0][i1], nb = lde_nat[1][i1];
-      u64 is_first = gl::mul(zh, gl::inv(gl::sub(x, 1)));
-      u64 is_trans = gl::sub(x, g_inv);
-      u64 cons[5] = {gl::sub(gl::add(la, lb), lc), gl::mul(is_first, gl::sub(1, la)), gl::mul(is_first, gl::sub(1, lb)),
-                     gl::mul(is_trans, gl::sub(na, lb)), gl::mul(is_trans, gl::sub(nb, lc))};
+      for (int c = 0; c < W; c++) {
+        loc[c] = lde_nat[c][i0];
+        nxt[c] = lde_nat[c][i1];
+      }
+      // two_adic.rs:100-147: selectors at a point of the quotient coset
+      const u64 is_trans = gl::sub(x, g_inv);
+      const u64 sel[4] = {0, gl::mul(zh, gl::inv(gl::sub(x, 1))), gl::mul(zh, gl::inv(is_trans)), is_trans};
       E2 acc = gl::e2(0);
-      for (u64 c : cons) {  // VerifierConstraintFolder::assert_zero: acc = acc * alpha + c
+      air.fold<u64>(loc, nxt, sel, ops, [&](u64 c) {  // VerifierConstraintFolder::assert_zero: acc = acc * alpha + c
         acc = gl::mul(acc, alpha);
         acc.a = gl::add(acc.a, c);
-      }
+      });
       E2 q = gl::mul(acc, zh_inv);
       q0[j] = q.a;
       q1[j] = q.b;
@@ -243,14 +272,11 @@ std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg) {
   {  // self-check of the identity the verifier enforces (verifier.rs:199-239)
     E2 un = zeta;
     E2 z_h = gl::sub(gl::exp_pow2(un, k), gl::e2(1));
-    E2 is_first = gl::mul(z_h, gl::inv(gl::sub(un, gl::e2(1))));
     E2 is_trans = gl::sub(un, gl::e2(gl::inv(w_n)));
-    E2 one = gl::e2(1);
-    E2 cons[5] = {gl::sub(gl::add(t_local[0], t_local[1]), t_local[2]), gl::mul(is_first, gl::sub(one, t_local[0])),
-                  gl::mul(is_first, gl::sub(one, t_local[1])), gl::mul(is_trans, gl::sub(t_next[0], t_local[1])),
-                  gl::mul(is_trans, gl::sub(t_next[1], t_local[2]))};
+    const E2 sel[4] = {gl::e2(0), gl::mul(z_h, gl::inv(gl::sub(un, gl::e2(1)))), gl::mul(z_h, gl::inv(is_trans)), is_trans};
+    ExtOps ops;
     E2 acc = gl::e2(0);
-    for (auto& c : cons) acc = gl::add(gl::mul(acc, alpha), c);
+    air.fold<E2>(t_local, t_next, sel, ops, [&](E2 c) { acc = gl::add(gl::mul(acc, alpha), c); });
     E2 lhs = gl::mul(acc, gl::inv(z_h));
     E2 rhs = gl::add(qz[0], gl::mul(qz[1], E2{0, 1}));
     if (!gl::eq(lhs, rhs)) throw std::logic_error("p3 prover: quotient identity does not hold");
@@ -260,9 +286,9 @@ std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg) {
   const E2 fri_alpha = ch.sample_ext();
   std::vector<E2> folded(N2);
   {
-    std::vector<E2> apow(8);
+    std::vector<E2> apow(2 * W + 2);
     apow[0] = gl::e2(1);
-    for (int i = 1; i < 8; i++) apow[i] = gl::mul(apow[i - 1], fri_alpha);
+    for (size_t i = 1; i < apow.size(); i++) apow[i] = gl::mul(apow[i - 1], fri_alpha);
     parallel_for(T, N2, [&](size_t b, size_t e) {
       for (size_t i = b; i < e; i++) {
         size_t r = gl::bitrev((u32)i, L);

@@ -32,6 +32,11 @@ struct P3ProveParams {
 };
 // Returns the proof as the flat input vector (add_virtual_to order) and its shape.
 std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg_out);
+// Same prover for any AIR given as a program (p3_circuit.h: AirProgram) and its trace, col[c][row];
+// constraint degree <= 2 (one quotient chunk, as the reference's proof model has).  Throws
+// std::logic_error("quotient identity ...") if the trace does not satisfy the AIR.
+std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vector<u64>>& col, const P3ProveParams& prm,
+                              P3Config& cfg_out);
 // serde-JSON text in the reference's format (proof.rs:16-19: field elements are {"value": u64})
 std::string p3_inputs_to_json(const std::vector<u64>& inputs, const P3Config& cfg);
 

@@ -77,6 +77,55 @@ constexpr Tables make_tables() {
 }
 static constexpr Tables TBL = make_tables();
 
+// Compile-time check of the algebra: three rounds through the tables == three rounds one at a time
+// (plain modular arithmetic, on a fixed non-trivial state, for every block).
+constexpr u64 sbox_ref(u64 x) {
+  u64 x2 = mulmod(x, x), x4 = mulmod(x2, x2), x3 = mulmod(x, x2);
+  return mulmod(x3, x4);
+}
+constexpr bool tables_consistent() {
+  for (int b = 0; b < BLOCKS; b++) {
+    u64 v[WIDTH] = {}, w[WIDTH] = {};
+    for (int i = 0; i < WIDTH; i++) v[i] = w[i] = mulmod(0x9E3779B97F4A7C15ull % gl::P, (u64)(i + 1 + 13 * b)) ^ 0;
+    // reference: round by round, constants of the following round added after the MDS layer
+    const int r0 = HALF_FULL + 3 * b;
+    for (int k = 0; k < 3; k++) {
+      u64 y[WIDTH] = {};
+      for (int i = 0; i < WIDTH; i++) y[i] = w[i];
+      y[0] = sbox_ref(y[0]);
+      for (int r = 0; r < WIDTH; r++) {
+        u64 acc = RC[WIDTH * (r0 + k + 1) + r];
+        for (int j = 0; j < WIDTH; j++)
+          acc = addmod(acc, mulmod(MDS_CIRC[(j - r + WIDTH) % WIDTH] + (r == 0 && j == 0 ? MDS_DIAG0 : 0), y[j]));
+        w[r] = acc;
+      }
+    }
+    // through the tables
+    u64 d[3] = {};
+    u64 x = v[0];
+    d[0] = addmod(sbox_ref(x), gl::P - x);
+    const u64 row0[WIDTH] = {25, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u64 a = (u64)TBL.kc[b][0] | ((u64)TBL.kc[b][1] << 32);
+    for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(row0[j], v[j]));
+    a = addmod(a, mulmod(25, d[0]));
+    x = a;
+    d[1] = addmod(sbox_ref(x), gl::P - x);
+    a = (u64)TBL.kc[b][2] | ((u64)TBL.kc[b][3] << 32);
+    for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.r2.c[j], v[j]));
+    a = addmod(a, addmod(mulmod(TBL.r2.c[12], d[0]), mulmod(TBL.r2.c[13], d[1])));
+    x = a;
+    d[2] = addmod(sbox_ref(x), gl::P - x);
+    for (int r = 0; r < WIDTH; r++) {
+      a = (u64)TBL.kc[b][4 + 2 * r] | ((u64)TBL.kc[b][5 + 2 * r] << 32);
+      for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.t3[r].c[j], v[j]));
+      for (int e = 0; e < 3; e++) a = addmod(a, mulmod(TBL.t3[r].c[12 + e], d[e]));
+      if (a != w[r]) return false;
+    }
+  }
+  return true;
+}
+static_assert(tables_consistent(), "poseidon_p3r.h: three-round tables disagree with the round-by-round definition");
+
 typedef const Tables __attribute__((address_space(4))) * tbl_ptr;
 
 __device__ __forceinline__ void mad_s(u64& acc, u32 x, u32 coef_sgpr) {

@@ -1,0 +1,80 @@
+"""CPU: AIRs as data -- `p25_circuit_build_p3_verifier_air`, `p25_p3_prove_air`.
+
+Pins: the FibonacciAir of src/p3/mod.rs:176-221 written as a program must give (a) the SAME circuit as
+the hand-written restatement (same digest, computed by the oracle) and (b) the SAME proof as the
+Fibonacci prover, i.e. the reference's artifact bit for bit.  Other AIRs are checked through the
+reference's own in-circuit verifier semantics: the verifier circuit built for that AIR accepts the
+native proof (every `connect` of src/p3 holds), rejects tampered proofs, and a trace that violates the
+AIR cannot be proved."""
+import numpy as np
+import pytest
+
+import air_cases
+from conftest import P
+
+
+def test_fibonacci_program_builds_the_same_circuit(p25, oracle, fib_blob):
+    c = p25.Circuit.build_p3_verifier_air(p25.P3Config.fib64(), p25.Air.fibonacci())
+    assert c.to_blob() == fib_blob
+
+
+def test_fibonacci_program_reproduces_the_artifact(p25, fib_inputs):
+    inp, cfg = p25.p3_prove_air(p25.Air.fibonacci(), air_cases.fib_trace(6), 100, 16)
+    assert (inp == fib_inputs).all()
+    assert (cfg.trace_width, cfg.log_trace_height) == (3, 6)
+
+
+@pytest.mark.parametrize("name,log_n", [("tribonacci", 4), ("squares", 3), ("squares", 5)])
+def test_user_air_accepted_by_its_verifier_circuit(p25, oracle, name, log_n):
+    air = getattr(air_cases, name)(p25)
+    trace = getattr(air_cases, name + "_trace")(log_n)
+    inp, cfg = p25.p3_prove_air(air, trace, num_queries=6, pow_bits=6)
+    assert cfg.trace_width == air.width
+    c = p25.Circuit.build_p3_verifier_air(cfg, air)
+    oc = oracle.load_circuit(c.to_blob())
+    wires, st, msg = oc.witness(inp, seed=3)
+    assert st == 0, msg
+    bad, msg = oc.check_constraints(wires)
+    assert bad == 0, msg
+    proof, st, _tm, msg = oc.prove(inp, seed=3)
+    assert st == 0, msg
+    assert oc.verify(proof)[0] == 0
+    # tampering with an opened trace value or the quotient opening breaks a `connect`
+    for pos in (8, 8 + 4 * air.width, len(inp) - 1):
+        t = inp.copy()
+        t[pos] = (int(t[pos]) + 1) % P
+        assert oc.witness(t, seed=3)[1] == 4
+    # the Fibonacci verifier circuit of the same shape does not accept this AIR's proof
+    if air.width == 3:
+        fc = oracle.load_circuit(p25.Circuit.build_p3_verifier(cfg).to_blob())
+        assert fc.witness(inp, seed=3)[1] == 4
+
+
+def test_violating_trace_cannot_be_proved(p25):
+    air = air_cases.tribonacci(p25)
+    trace = air_cases.tribonacci_trace(4)
+    trace[5, 3] = (int(trace[5, 3]) + 1) % P
+    with pytest.raises(p25.P25Error):
+        p25.p3_prove_air(air, trace, num_queries=4, pow_bits=4)
+
+
+def test_malformed_programs_rejected(p25):
+    cfg = p25.P3Config.fib64()
+    air = p25.Air(3)
+    x = air.local(0)
+    air.when_transition(air.sub(air.mul(x, x), air.local(1)))      # degree 3 with the selector
+    with pytest.raises(p25.P25Error):
+        p25.Circuit.build_p3_verifier_air(cfg, air)
+    air = p25.Air(3)
+    air.assert_zero(air.local(7))                                   # column out of range
+    with pytest.raises(p25.P25Error):
+        p25.Circuit.build_p3_verifier_air(cfg, air)
+    air = p25.Air(3)
+    air.nodes.append((3, 5, 6, 0))                                  # forward reference
+    air.assert_zero(0)
+    with pytest.raises(p25.P25Error):
+        p25.Circuit.build_p3_verifier_air(cfg, air)
+    air = p25.Air.fibonacci()
+    cfg4 = p25.P3Config(1, 100, 16, 0, 6, 4, 7, 2, 6)               # width mismatch: "Invalid Proof Shape"
+    with pytest.raises(p25.P25Error):
+        p25.Circuit.build_p3_verifier_air(cfg4, air)

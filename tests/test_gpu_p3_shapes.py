@@ -32,3 +32,25 @@ def test_two_distinct_fib64_proofs_in_one_batch(gpu, fib_circuit, fib_oracle, fi
     dg, capg = fib_circuit.digest()
     for p in proofs:
         assert fib_oracle.verify(p, dg, capg)[0] == 0
+
+
+@pytest.mark.parametrize("name,log_n", [("tribonacci", 4), ("squares", 5)])
+def test_gpu_equals_oracle_on_user_air(gpu, oracle, name, log_n):
+    """verifier circuits for AIRs given as data (p25_air) -- width 4 / a quadratic and a
+    last-row constraint -- proved on the GPU, byte-identical to the oracle; a tampered input fails."""
+    import air_cases
+    air = getattr(air_cases, name)(gpu)
+    inp, cfg = gpu.p3_prove_air(air, getattr(air_cases, name + "_trace")(log_n), num_queries=12, pow_bits=8)
+    c = gpu.Circuit.build_p3_verifier_air(cfg, air)
+    oc = oracle.load_circuit(c.to_blob())
+    dg, capg = c.digest()
+    do, capo = oc.digest()
+    assert (dg == do).all() and (capg == capo).all()
+    bad = inp.copy()
+    bad[9] = (int(bad[9]) + 1) % 0xFFFFFFFF00000001
+    proofs, st = c.prove(np.stack([inp, bad]), seeds=[5, 6])
+    assert st.tolist() == [0, 4]
+    po, sto, _tm, msg = oc.prove(inp, seed=5)
+    assert sto == 0, msg
+    assert (proofs[0] == po).all()
+    assert oc.verify(proofs[0], dg, capg)[0] == 0
