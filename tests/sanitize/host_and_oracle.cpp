@@ -1,0 +1,82 @@
+// Host-side code of the product (circuit builder, plonky3 verifier-circuit restatement, native plonky3
+// prover, AIR programs, circuit blob I/O) and the CPU oracle (witness, prover, verifier) in one
+// executable for AddressSanitizer + UBSan (GPU sanitizers are not available on the pool; the device
+// code is covered by tools/asmcheck and the parity tests).  Built and run by tests/test_sanitizers_cpu.py.
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+#include "builder.h"
+#include "circuit_io.h"
+#include "p3_circuit.h"
+#include "p3_prover.h"
+typedef uint64_t u64;
+extern "C" {
+void* p25o_circuit_load(const unsigned char* blob, size_t len);
+void p25o_circuit_free(void* h);
+int p25o_witness(void* h, const u64* inputs, u64 seed, u64* wires_out, char* msg, size_t msglen);
+long p25o_check_constraints(void* h, const u64* wires, char* msg, size_t msglen);
+void p25o_circuit_digest(void* h, u64* digest4, u64* cs_cap);
+size_t p25o_proof_words(void* h);
+int p25o_prove(void* h, const u64* inputs, u64 seed, u64* proof_out, double* timings_out, char* msg, size_t msglen);
+int p25o_verify(void* h, const u64* digest4, const u64* cs_cap, const u64* proof_words, char* msg, size_t msglen);
+void p25o_set_threads(int n);
+}
+using namespace p25;
+#define CHECK(c) do { if (!(c)) { printf("CHECK FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+
+int main() {
+  // product host code
+  P3ProveParams prm;
+  prm.log_n = 5; prm.num_queries = 6; prm.pow_bits = 6; prm.threads = 2;
+  P3Config cfg;
+  std::vector<u64> inp = p3_prove_fibonacci(prm, cfg);
+  std::string js = p3_inputs_to_json(inp, cfg);
+  CHECK(js.size() > inp.size());
+  CircuitBuilder cb;
+  FibonacciAir fib;
+  p3_verify_proof(cb, cfg, fib);
+  Circuit c = cb.build();
+  std::vector<uint8_t> blob = circuit_to_blob(c);
+  Circuit c2 = circuit_from_blob(blob.data(), blob.size());
+  CHECK(c2.degree() == c.degree());
+  CircuitBuilder cb2;
+  ProgramAir pa(AirProgram::fibonacci());
+  p3_verify_proof(cb2, cfg, pa);
+  CHECK(circuit_to_blob(cb2.build()) == blob);
+  for (int k = 0; k < 7; k++) CHECK(build_gadget_circuit(k, 5).degree() >= 4);
+  // truncated / corrupted blobs must be rejected, not crash
+  for (size_t cut : {(size_t)0, (size_t)7, blob.size() / 2, blob.size() - 1}) {
+    bool threw = false;
+    try { circuit_from_blob(blob.data(), cut); } catch (const std::exception&) { threw = true; }
+    CHECK(threw);
+  }
+  // oracle on a small verifier circuit
+  prm.log_n = 3; prm.num_queries = 3; prm.pow_bits = 4;
+  inp = p3_prove_fibonacci(prm, cfg);
+  CircuitBuilder cb3;
+  p3_verify_proof(cb3, cfg, fib);
+  Circuit c3 = cb3.build();
+  blob = circuit_to_blob(c3);
+  p25o_set_threads(4);
+  void* h = p25o_circuit_load(blob.data(), blob.size());
+  CHECK(h != nullptr);
+  char msg[256] = {0};
+  std::vector<u64> wires((size_t)c3.degree() * 135);
+  CHECK(p25o_witness(h, inp.data(), 1, wires.data(), msg, sizeof msg) == 0);
+  CHECK(p25o_check_constraints(h, wires.data(), msg, sizeof msg) == 0);
+  u64 dg[4];
+  std::vector<u64> cap(16 * 4);
+  p25o_circuit_digest(h, dg, cap.data());
+  std::vector<u64> proof(p25o_proof_words(h));
+  double tm[16];
+  CHECK(p25o_prove(h, inp.data(), 1, proof.data(), tm, msg, sizeof msg) == 0);
+  CHECK(p25o_verify(h, dg, cap.data(), proof.data(), msg, sizeof msg) == 0);
+  proof[100] ^= 1;
+  CHECK(p25o_verify(h, dg, cap.data(), proof.data(), msg, sizeof msg) != 0);
+  std::vector<u64> bad(inp);
+  bad[9] ^= 1;
+  CHECK(p25o_witness(h, bad.data(), 1, wires.data(), msg, sizeof msg) != 0);
+  p25o_circuit_free(h);
+  printf("SANITIZE OK\n");
+  return 0;
+}
