@@ -17,6 +17,7 @@
 // sums as they are produced (alpha^j from an LDS table), and the gate's filter multiplies the
 // folded sums once:   sum_j alpha^j sum_g f_g c_{g,j} = sum_g f_g sum_j alpha^j c_{g,j}.
 #include <stdexcept>
+#include <stdlib.h>
 #include "kernels.h"
 #include "poseidon2.h"
 #include "prover_kernels.h"
@@ -93,7 +94,7 @@ __device__ void gate_base_sum(Ctx& cx) {
     u64 l = cx.w(1 + i);
     sum = gl::add(sum, gl::mul(l, pw));
     pw = gl::add(pw, pw);
-    cx.at(1 + i, gl::mul(l, gl::sub(l, 1)));
+    cx.at(1 + i, gl::mul_nc(l, gl::sub(l, 1)));  // at() takes any representative
   }
   cx.at(0, gl::sub(sum, cx.w(0)));
 }
@@ -133,13 +134,13 @@ __device__ void gate_u32_arithmetic(Ctx& cx) {
     u64 computed = gl::add(gl::mul(m0, m1), ad);
     u64 diff = gl::sub(0xFFFFFFFFull, hi);
     u64 hi_not_max = gl::sub(gl::mul(inv, diff), 1);
-    cx.at(cb, gl::mul(hi_not_max, lo));
+    cx.at(cb, gl::mul_nc(hi_not_max, lo));
     u64 combined = gl::add(gl::mul(hi, (u64)1 << 32), lo);
     cx.at(cb + 1, gl::sub(combined, computed));
     u64 cl = 0, ch = 0;
     for (int j = 31; j >= 0; j--) {
       u64 l = cx.w(18 + 32 * i + j);
-      u64 pr = gl::mul(gl::mul(l, gl::sub(l, 1)), gl::mul(gl::sub(l, 2), gl::sub(l, 3)));
+      u64 pr = gl::mul_nc(gl::mul_nc(l, gl::sub(l, 1)), gl::mul_nc(gl::sub(l, 2), gl::sub(l, 3)));
       cx.at(cb + 2 + (31 - j), pr);
       if (j < 16) {
         cl = gl::add(gl::add(cl, cl), gl::add(cl, cl));
@@ -162,7 +163,7 @@ __device__ void gate_u32_interleave(Ctx& cx) {
       x = gl::add(gl::add(x, x), bit);
       u64 x2 = gl::add(xi, xi);
       xi = gl::add(gl::add(x2, x2), bit);
-      cx.at(cb + 2 + b, gl::mul(bit, gl::sub(bit, 1)));
+      cx.at(cb + 2 + b, gl::mul_nc(bit, gl::sub(bit, 1)));
     }
     cx.at(cb, gl::sub(x, cx.w(2 * i)));
     cx.at(cb + 1, gl::sub(xi, cx.w(2 * i + 1)));
@@ -178,8 +179,8 @@ __device__ void gate_u32_uninterleave(Ctx& cx) {
       x = gl::add(gl::add(gl::add(x2, x2), gl::add(be, be)), bo);
       ev = gl::add(gl::add(ev, ev), be);
       od = gl::add(gl::add(od, od), bo);
-      cx.at(cb + 3 + 2 * j, gl::mul(be, gl::sub(be, 1)));
-      cx.at(cb + 3 + 2 * j + 1, gl::mul(bo, gl::sub(bo, 1)));
+      cx.at(cb + 3 + 2 * j, gl::mul_nc(be, gl::sub(be, 1)));
+      cx.at(cb + 3 + 2 * j + 1, gl::mul_nc(bo, gl::sub(bo, 1)));
     }
     cx.at(cb, gl::sub(x, cx.w(3 * i)));
     cx.at(cb + 1, gl::sub(ev, cx.w(3 * i + 1)));
@@ -191,7 +192,7 @@ __device__ void gate_poseidon2(Ctx& cx) {
   using namespace poseidon2;
   int nc = 0;
   u64 swap = cx.w(24);
-  cx.at(nc++, gl::mul(swap, gl::sub(swap, 1)));
+  cx.at(nc++, gl::mul_nc(swap, gl::sub(swap, 1)));
   u64 st[12];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(128, 2) void k_quotient(QuotientArgs a) {
         if (k != gi) filter = gl::mul(filter, gl::sub((u64)k, s));
       if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
       cx.reset();
+      if (!((a.debug_gate_mask >> ge.kind) & 1u)) continue;  // profiling aid (P25_Q_MASK), all ones in production
       switch (ge.kind) {
         case G_CONSTANT: gate_constant(cx, k0, k1); break;
         case G_PUBLIC_INPUT: gate_public_input(cx); break;
@@ -377,7 +379,13 @@ void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bit
                      degree_bits + rate_bits, d_out);
 }
 
-void launch_quotient(const QuotientArgs& a, hipStream_t st) {
+void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
+  QuotientArgs a = a_in;
+  static const uint32_t mask = [] {
+    const char* e = getenv("P25_Q_MASK");  // profiling only: evaluates a subset of the gates (wrong proofs!)
+    return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
+  }();
+  a.debug_gate_mask = mask;
   if (a.num_routed > (uint32_t)MAX_ROUTED) throw std::runtime_error("quotient: more than MAX_ROUTED routed wires");
   const size_t big = (size_t)1 << (a.degree_bits + a.rate_bits);
   hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);

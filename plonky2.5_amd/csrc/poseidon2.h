@@ -24,10 +24,10 @@ constexpr int ROUND_P = 22;
 //   [58,106) full rounds 4..7, 12 each
 constexpr int TRACE_LEN = 36 + 22 + 48;
 
-GL_HD u64 sbox(u64 x) {
-  u64 x2 = gl::mul(x, x);
-  u64 x4 = gl::mul(x2, x2);
-  u64 x3 = gl::mul(x, x2);
+GL_HD u64 sbox(u64 x) {  // canonical result; the intermediate powers may stay non-canonical
+  u64 x2 = gl::mul_nc(x, x);
+  u64 x4 = gl::mul_nc(x2, x2);
+  u64 x3 = gl::mul_nc(x, x2);
   return gl::mul(x3, x4);
 }
 

@@ -57,6 +57,7 @@ struct QuotientArgs {
   uint32_t n_gates, num_selectors, num_wires, num_routed, num_partial_products, degree_bits, rate_bits;
   u64 zh[8], zh_inv[8];  // Z_H on the coset (index = i mod 2^rate_bits), and inverses
   const u64* l0_inv;     // [big] 1 / (n (x - 1)) at bit-reversed positions (per circuit)
+  uint32_t debug_gate_mask;  // set by launch_quotient
 };
 constexpr int ALPHA_POWS = 192;
 constexpr int MAX_ROUTED = 128;

@@ -1,0 +1,8 @@
+#!/bin/bash
+export TMPDIR=/tmp
+for M in 0xFFFFFFFF 0x0 $*; do
+  rm -rf gpurun_out/_pmc
+  P25_Q_MASK=$M rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/_pmc -- python3 tools/prove_one.py 1 > gpurun_out/_pmc.log 2>&1
+  echo "MASK $M: $(python3 tools/pmc_summary.py gpurun_out/_pmc | grep k_quotient)"
+done
+rm -rf gpurun_out/_pmc
