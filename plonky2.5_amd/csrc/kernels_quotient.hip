@@ -311,8 +311,8 @@ __global__ __launch_bounds__(128, 2) void k_quotient(QuotientArgs a) {
         u64 w = wr[(size_t)j * big];
         u64 sg = cs[(size_t)(n_consts + 2 + j) * big];
         u64 wg = gl::add(w, gamma);
-        np = gl::mul_nc(np, gl::add(wg, gl::mul(kb[c * RW + j], x)));
-        dp = gl::mul_nc(dp, gl::add(wg, gl::mul(beta, sg)));
+        np = gl::mul_nc(np, gl::mad_nc(kb[c * RW + j], x, wg));
+        dp = gl::mul_nc(dp, gl::mad_nc(beta, sg, wg));
       }
       np = gl::canon(np);
       dp = gl::canon(dp);

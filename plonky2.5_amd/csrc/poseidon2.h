@@ -63,7 +63,7 @@ GL_HD void matmul_internal(u64 s[WIDTH]) {
 #pragma unroll
   for (int i = 1; i < WIDTH; i++) sum = gl::add(sum, s[i]);
 #pragma unroll
-  for (int i = 0; i < WIDTH; i++) s[i] = gl::add(gl::mul(s[i], P2_MAT_DIAG_M_1[i] - 1), sum);
+  for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(gl::mad_nc(s[i], P2_MAT_DIAG_M_1[i] - 1, sum));
 }
 
 // Canonical in/out.  `tr(i, v)` receives the S-box inputs the Poseidon2Gate stores as wires

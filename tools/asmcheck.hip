@@ -14,6 +14,16 @@ __global__ void k_mul(const u64* a, const u64* b, u64* out_asm, u64* out_c, size
   out_c[i] = gl::canon(gl::reduce128(a[i] * b[i], gl::mulhi64(a[i], b[i])));
 #endif
 }
+__global__ void k_mad(const u64* a, const u64* b, u64* out_asm, u64* out_c, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (i >= n) return;
+  const u64 c = a[(i * 7 + 3) % n] ^ b[(i * 5 + 1) % n];  // any u64
+  out_asm[i] = gl::canon(gl::mad_nc_asm(a[i], b[i], c));
+  unsigned __int128 t = (unsigned __int128)a[i] * b[i] + c;
+  out_c[i] = gl::canon(gl::reduce128((u64)t, (u64)(t >> 64)));
+#endif
+}
 __global__ void k_mds(const u64* in, u64* out_asm, u64* out_c, size_t n, int row) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -96,6 +106,14 @@ int main() {
     int bad = 0;
     for (size_t i = 0; i < n; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("mul mismatch a=%016llx b=%016llx asm=%016llx c=%016llx\n", (unsigned long long)a[i], (unsigned long long)b[i], (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
     printf("mul_nc_asm: %d mismatches of %zu\n", bad, n);
+    bad_total += bad;
+    // a*b + c on the same operands (the edge-case block makes a, b, c all-ones etc. meet)
+    for (size_t i = 0; i < 64; i++) { a[n - 1 - i] = ~0ull; b[n - 1 - i] = ~0ull - (i & 1); }
+    hipLaunchKernelGGL(k_mad, dim3(n / 256), dim3(256), 0, 0, a, b, o1, o2, n);
+    CK(hipDeviceSynchronize());
+    bad = 0;
+    for (size_t i = 0; i < n; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("mad mismatch a=%016llx b=%016llx asm=%016llx c=%016llx\n", (unsigned long long)a[i], (unsigned long long)b[i], (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    printf("mad_nc_asm: %d mismatches of %zu\n", bad, n);
     bad_total += bad;
   }
   const size_t m = 1 << 16;
