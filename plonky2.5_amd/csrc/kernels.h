@@ -48,8 +48,7 @@ struct NttPass {
   const u64* pow_table;  // w_N^e (forward) or w_N^-e (inverse), e < N = 2^log_n_table
   int log_n_table;
   int use_twiddle;       // multiply output (t, j) by pow_table[t*j] (N = R*NT required)
-  const u64* pre_t;      // optional [n_cosets][NT]
-  const u64* pre_i;      // optional [n_cosets][R]
+  const u64* pre;        // optional [n_cosets][N]: input element at address k is multiplied by pre[coset][k]
   const u64* post_t;     // optional [NT]
   const u64* post_i;     // optional [R]
 };
@@ -63,7 +62,7 @@ class NttTables {
   // device table of base^e for e < len (cached by (base, len))
   const u64* geom_table(u64 first, u64 ratio, size_t len);
   const u64* upload(const std::vector<u64>& host);
-  typedef std::map<std::tuple<int, int, u64>, std::pair<const u64*, const u64*>> CosetCache;
+  typedef std::map<std::tuple<int, int, u64>, const u64*> CosetCache;
   CosetCache& coset_cache() { return coset_; }
 
  private:

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
 
   for (int k = tid; k < R / 2; k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
 
-  const u64* pre_t = a.pre_t ? a.pre_t + (size_t)coset * NT : nullptr;
-  const u64* pre_i = a.pre_i ? a.pre_i + (size_t)coset * R : nullptr;
+  // coset pre-scale: one table entry per input coefficient (shift_c^k at the coefficient's address k)
+  const u64* pre = a.pre ? a.pre + ((size_t)coset << (a.log_r + a.log_nt)) : nullptr;
   for (int e = tid; e < T * R; e += nth) {
     int t, i;
     size_t addr;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
       addr = (size_t)trow * R + off;
     }
     u64 x = in[addr];
-    if (pre_t) x = gl::mul(x, gl::mul(pre_t[tg0 + t], pre_i[i]));
+    if (pre) x = gl::mul(x, pre[addr]);
     lds[i * TP + t] = x;
   }
   __syncthreads();
@@ -262,30 +262,30 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
   const size_t n = (size_t)1 << log_n;
   const u64* pw = tb.pow_table(log_n, false);
   const u64 w_big = gl::root_of_unity(log_n + rate_bits);
-  // per-coset pre-scale tables: coefficient k = t + NT*i (pass 1) gets shift_c^k
-  const size_t NT1 = (size_t)1 << l1, R1 = (size_t)1 << l2;  // pass-1 geometry
-  std::vector<u64> ht(nc * NT1), hi(nc * R1);
-  for (int c = 0; c < nc; c++) {
-    u64 sc = gl::mul(shift, gl::pow(w_big, c));
-    u64 x = 1;
-    for (size_t k = 0; k < NT1; k++) { ht[c * NT1 + k] = x; x = gl::mul(x, sc); }
-    u64 sr = gl::pow(sc, NT1);
-    x = 1;
-    for (size_t k = 0; k < R1; k++) { hi[c * R1 + k] = x; x = gl::mul(x, sr); }
-  }
-  // cache by content is overkill: tables are tiny; cache by (log_n, rate_bits, shift)
-  // (the cache lives in the NttTables object: device pointers die with it)
+  // per-coset pre-scale table: coefficient k gets shift_c^k, shift_c = shift * w_{8n}^c  (n words per coset;
+  // one load + one multiply per element instead of two factor tables and two multiplies)
   auto& cache = tb.coset_cache();
   auto key = std::make_tuple(log_n, rate_bits, shift);
   auto it = cache.find(key);
-  if (it == cache.end()) it = cache.emplace(key, std::make_pair(tb.upload(ht), tb.upload(hi))).first;
+  if (it == cache.end()) {
+    std::vector<u64> h((size_t)nc * n);
+    for (int c = 0; c < nc; c++) {
+      u64 sc = gl::mul(shift, gl::pow(w_big, c));
+      u64 x = 1;
+      for (size_t k = 0; k < n; k++) {
+        h[(size_t)c * n + k] = x;
+        x = gl::mul(x, sc);
+      }
+    }
+    it = cache.emplace(key, tb.upload(h)).first;
+  }
 
   NttPass p{};
   p.pow_table = pw; p.log_n_table = log_n;
   p.in = d_coeffs; p.out = d_lde;
   p.in_poly_stride = coeff_stride; p.out_poly_stride = lde_stride;
   for (int c = 0; c < nc; c++) p.coset_out_off[c] = (size_t)gl::bitrev(c, rate_bits) * n;
-  p.pre_t = it->second.first; p.pre_i = it->second.second;
+  p.pre = it->second;  // indexed by the input address: requires natural-order input (in_br_* = 0)
   if (l1 == 0) {
     p.log_r = l2; p.log_nt = 0; p.log_t = 0;
     p.in_kind = 1; p.out_kind = 1; p.out_br_i = 1;
