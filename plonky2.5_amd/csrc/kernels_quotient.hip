@@ -254,7 +254,14 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
   hipLaunchKernelGGL(k_alpha_pows, dim3(2), dim3(ALPHA_POWS), 0, st, d_chal, d_alpha_pows);
 }
 
-__global__ __launch_bounds__(128, 2) void k_quotient(QuotientArgs a) {
+// Occupancy target: unconstrained the kernel takes 255 VGPRs = 2 waves per SIMD, which fills the register
+// file, leaves the VALU half idle on memory latency and lets no other stream's waves co-reside.  Capped at
+// 96 VGPRs (5 waves per SIMD) the compiler spills ~580 B per lane to scratch, yet the kernel runs 2.49 ->
+// 1.78 ms and the batch 110 -> 119 proofs/s (3, 4, 6 waves: 2.15, 1.85, 1.77 ms).
+#ifndef P25_Q_WAVES
+#define P25_Q_WAVES 5
+#endif
+__global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
   __shared__ u64 ap[2 * ALPHA_POWS];
   __shared__ AlphaLimbs apl[ALPHA_POWS];
   for (int i = threadIdx.x; i < 2 * ALPHA_POWS; i += blockDim.x) {
