@@ -147,11 +147,14 @@ def main():
                 traffic = None
         total_proofs = world * B * args.steps
         # Integer-VALU view of the same run (the bound that actually binds): wave-level VALU instructions
-        # per proof from the committed PMC pass (SQ_INSTS_VALU, profiles/r01_e_pmc_SQ_INSTS_VALU.json)
-        # x proofs/s per GPU, against one VALU instruction per 4 cycles per SIMD (1024 SIMDs, 2.4 GHz).
+        # per proof from the latest committed PMC pass (SQ_INSTS_VALU, profiles/*_pmc_SQ_INSTS_VALU.json,
+        # written by tools/collect_profiles.sh) x proofs/s per GPU, against one VALU instruction per 4 cycles
+        # per SIMD (1024 SIMDs, 2.4 GHz).
         valu = None
-        vp = os.path.join(ROOT, "profiles", "r01_e_pmc_SQ_INSTS_VALU.json")
-        if os.path.exists(vp) and args.log_n == 6:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_SQ_INSTS_VALU.json")))
+        vp = cands[-1] if cands else ""
+        if vp and args.log_n == 6:
             try:
                 per_kernel = json.load(open(vp))
                 instr_per_proof = sum(v.get("SQ_INSTS_VALU", 0.0) for v in per_kernel.values())

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_poseidon2_permute(u64* states, size_t n
 // 64-lane workgroups: the kernel is a pure per-lane VALU loop (~340k instructions per lane), and one
 // wave per workgroup lets the dispatcher back-fill SIMDs as soon as a single wave retires -- measured
 // 6.31 -> 5.77 ms on the 2^19 x 135 matrix (tools/hashbench.hip), the register-only ceiling being 5.74 ms.
-__global__ __launch_bounds__(64) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
+__global__ __launch_bounds__(64, 6) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
                                                      int width, size_t n_leaves,
                                                      u64* __restrict__ digests) {
   size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void k_hash_leaves(const u64* __restrict__ cols
 
 // The same kernel under its own symbol for wide matrices (the 135-column wires LDE: the dominant launch
 // of a proof), so that profiler summaries list it separately from the 20- and 16-column commits.
-__global__ __launch_bounds__(64) void k_hash_leaves_wide(const u64* __restrict__ cols, size_t col_stride,
+__global__ __launch_bounds__(64, 6) void k_hash_leaves_wide(const u64* __restrict__ cols, size_t col_stride,
                                                           int width, size_t n_leaves,
                                                           u64* __restrict__ digests) {
   size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_hash_leaves_wide(const u64* __restrict__
 }
 
 // parents[m] = two_to_one(children[2m], children[2m+1])
-__global__ __launch_bounds__(64) void k_tree_level(const u64* __restrict__ children,
+__global__ __launch_bounds__(64, 6) void k_tree_level(const u64* __restrict__ children,
                                                     u64* __restrict__ parents, size_t n_parents) {
   size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n_parents) return;
