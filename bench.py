@@ -164,7 +164,9 @@ def main():
                         "peak_wave_instr_per_s": peak, "frac": ach / peak,
                         "leaf_hash_share": sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in per_kernel.items()
                                                if "k_hash_leaves" in k) / instr_per_proof,
-                        "note": "peak at the nominal 2.4 GHz; rocm-smi shows sclk 2.05-2.25 GHz under this load"}
+                        "note": "peak = 1 VALU instruction / SIMD / 4 cycles at 2.4 GHz (shader clock measured in-kernel "
+                                "under this load: 2.31-2.40 GHz); v_mad_u64_u32, 60% of the mix, issues every ~4.7 "
+                                "cycles, so the practical ceiling is ~0.88"}
             except Exception:
                 valu = None
         # HBM view per phase and overall: algorithmic bytes of each phase -- inputs read
