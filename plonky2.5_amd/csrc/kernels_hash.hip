@@ -40,12 +40,12 @@ __global__ __launch_bounds__(256) void k_poseidon2_permute(u64* states, size_t n
 }
 
 // digests[l] = hash_or_noop(leaf l), leaf l = (cols[c*col_stride + l])_{c < width}
-// 64-lane workgroups: the kernel is a pure per-lane VALU loop (~340k instructions per lane), and one
-// wave per workgroup lets the dispatcher back-fill SIMDs as soon as a single wave retires -- measured
-// 6.31 -> 5.77 ms on the 2^19 x 135 matrix (tools/hashbench.hip), the register-only ceiling being 5.74 ms.
-__global__ __launch_bounds__(64, 6) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
-                                                     int width, size_t n_leaves,
-                                                     u64* __restrict__ digests) {
+// 64-lane workgroups: the kernel is a pure per-lane VALU loop (~230k instructions per lane for 135
+// columns), and one wave per workgroup lets the dispatcher back-fill SIMDs as soon as a single wave
+// retires (tools/hashbench.hip: 5 % over 256-lane workgroups).  80 VGPRs (6 waves per SIMD) leave room
+// for other streams' waves next to it.
+__device__ __forceinline__ void hash_leaf(const u64* __restrict__ cols, size_t col_stride, int width,
+                                          size_t n_leaves, u64* __restrict__ digests) {
   size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= n_leaves) return;
   u64 out[4];
@@ -54,19 +54,15 @@ __global__ __launch_bounds__(64, 6) void k_hash_leaves(const u64* __restrict__ c
 #pragma unroll
   for (int i = 0; i < 4; i++) d[i] = out[i];
 }
-
+__global__ __launch_bounds__(64, 6) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
+                                                       int width, size_t n_leaves, u64* __restrict__ digests) {
+  hash_leaf(cols, col_stride, width, n_leaves, digests);
+}
 // The same kernel under its own symbol for wide matrices (the 135-column wires LDE: the dominant launch
 // of a proof), so that profiler summaries list it separately from the 20- and 16-column commits.
 __global__ __launch_bounds__(64, 6) void k_hash_leaves_wide(const u64* __restrict__ cols, size_t col_stride,
-                                                          int width, size_t n_leaves,
-                                                          u64* __restrict__ digests) {
-  size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= n_leaves) return;
-  u64 out[4];
-  poseidon::hash_or_noop_strided(cols + l, col_stride, width, out);
-  u64* d = digests + 4 * l;
-#pragma unroll
-  for (int i = 0; i < 4; i++) d[i] = out[i];
+                                                            int width, size_t n_leaves, u64* __restrict__ digests) {
+  hash_leaf(cols, col_stride, width, n_leaves, digests);
 }
 
 // parents[m] = two_to_one(children[2m], children[2m+1])

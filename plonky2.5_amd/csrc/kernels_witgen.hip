@@ -47,17 +47,17 @@ struct P2Tracer {
   __device__ __forceinline__ void operator()(int i, u64 v) const { em(4 + i, v); }
 };
 
-__global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__ gens,
-                                                      const uint32_t* __restrict__ args, uint32_t g_begin,
-                                                      uint32_t g_count, u64* __restrict__ vals, size_t B,
-                                                      uint32_t n_proofs, const u64* __restrict__ seeds,
-                                                      uint32_t* __restrict__ status, int skip_poseidon2) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* __restrict__ gens,
+                                                  const uint32_t* __restrict__ args, uint32_t g_begin,
+                                                  uint32_t g_count, u64* __restrict__ vals, size_t B,
+                                                  uint32_t n_proofs, const u64* __restrict__ seeds,
+                                                  uint32_t* __restrict__ status, int skip_poseidon2) {
+  size_t idx = (size_t)block * blockDim.x + threadIdx.x;
   if (idx >= (size_t)g_count * n_proofs) return;
   const uint32_t gi = g_begin + (uint32_t)(idx / n_proofs);
   const uint32_t p = (uint32_t)(idx % n_proofs);
   const WitGen g = gens[gi];
-  if (skip_poseidon2 && g.kind == GEN_POSEIDON2) return;  // done by k_witgen_p2_coop
+  if (skip_poseidon2 && g.kind == GEN_POSEIDON2) return;  // done cooperatively (k_witgen_level_fused)
   const uint32_t* dep = args + g.arg_off;
   Emitter emit{vals, dep + g.n_deps, B, p, status};
   auto d = [&](int i) -> u64 { return vals[(size_t)dep[i] * B + p]; };
@@ -189,15 +189,21 @@ __global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__
   }
 }
 
+__global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__ gens,
+                                                      const uint32_t* __restrict__ args, uint32_t g_begin,
+                                                      uint32_t g_count, u64* __restrict__ vals, size_t B,
+                                                      uint32_t n_proofs, const u64* __restrict__ seeds,
+                                                      uint32_t* __restrict__ status, int skip_poseidon2) {
+  witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, skip_poseidon2);
+}
+
 // Poseidon2 generators of one level, one 16-lane group per (generator, proof): used for small batches,
 // where a level's latency is that of a single permutation (poseidon2_gate.rs:447-523, cooperatively).
-__global__ __launch_bounds__(256) void k_witgen_p2_coop(const WitGen* __restrict__ gens,
-                                                        const uint32_t* __restrict__ args, uint32_t g_begin,
-                                                        uint32_t g_count, u64* __restrict__ vals, size_t B,
-                                                        uint32_t n_proofs, uint32_t* __restrict__ status) {
-  __shared__ u64 k_lds[coop::P2_LDS_WORDS];
-  coop::stage_poseidon2_rc(k_lds);
-  size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / coop::GROUP;
+__device__ __forceinline__ void witgen_p2_coop_body(uint32_t block, const u64* k_lds, const WitGen* __restrict__ gens,
+                                                    const uint32_t* __restrict__ args, uint32_t g_begin,
+                                                    uint32_t g_count, u64* __restrict__ vals, size_t B,
+                                                    uint32_t n_proofs, uint32_t* __restrict__ status) {
+  size_t grp = ((size_t)block * blockDim.x + threadIdx.x) / coop::GROUP;
   const size_t n_groups = (size_t)g_count * n_proofs;
   const bool valid = grp < n_groups;
   if (!valid) grp = n_groups - 1;  // every lane takes part in the shuffles
@@ -218,6 +224,22 @@ __global__ __launch_bounds__(256) void k_witgen_p2_coop(const WitGen* __restrict
   if (swap == 1) s = rr < 4 ? up : (rr < 8 ? dn : s);
   s = coop::poseidon2_permute(s, lane, k_lds, [&](int i, u64 v) { emit(4 + i, v); });
   if (rr < 12) emit(4 + 106 + rr, s);
+}
+// One launch per level for small batches (every launch costs ~12 us of a single proof's latency): blocks
+// [0, nb_level) run the per-lane generators of the level, the rest its Poseidon2 generators cooperatively.
+__global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __restrict__ gens,
+                                                            const uint32_t* __restrict__ args, uint32_t g_begin,
+                                                            uint32_t g_count, uint32_t p2_begin, uint32_t p2_count,
+                                                            uint32_t nb_level, u64* __restrict__ vals, size_t B,
+                                                            uint32_t n_proofs, const u64* __restrict__ seeds,
+                                                            uint32_t* __restrict__ status) {
+  __shared__ u64 k_lds[coop::P2_LDS_WORDS];
+  if (blockIdx.x < nb_level) {
+    witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, 1);
+  } else {
+    coop::stage_poseidon2_rc(k_lds);
+    witgen_p2_coop_body(blockIdx.x - nb_level, k_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
+  }
 }
 
 // vals[slot 0] = 0; vals[input_slots[i]] = inputs[p][i]
@@ -253,13 +275,14 @@ void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u6
     // small batches: the level's Poseidon2 generators run cooperatively (latency), the rest per lane
     const uint32_t p2c = l < wp.level_p2_count.size() ? wp.level_p2_count[l] : 0;
     const int coop_p2 = (n_proofs < 16 && p2c > 0) ? 1 : 0;
-    if (!coop_p2 || p2c < cnt)
+    if (!coop_p2) {
       hipLaunchKernelGGL(k_witgen_level, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, wp.d_gens, wp.d_args,
-                         b, cnt, d_vals, B, n_proofs, d_seeds, d_status, coop_p2);
-    if (coop_p2) {
-      size_t th2 = (size_t)p2c * n_proofs * coop::GROUP;
-      hipLaunchKernelGGL(k_witgen_p2_coop, dim3((unsigned)((th2 + 255) / 256)), dim3(256), 0, st, wp.d_gens,
-                         wp.d_args, wp.level_p2_begin[l], p2c, d_vals, B, n_proofs, d_status);
+                         b, cnt, d_vals, B, n_proofs, d_seeds, d_status, 0);
+    } else {
+      const unsigned nb1 = p2c < cnt ? (unsigned)((th + 255) / 256) : 0;
+      const size_t th2 = (size_t)p2c * n_proofs * coop::GROUP;
+      hipLaunchKernelGGL(k_witgen_level_fused, dim3(nb1 + (unsigned)((th2 + 255) / 256)), dim3(256), 0, st, wp.d_gens,
+                         wp.d_args, b, cnt, wp.level_p2_begin[l], p2c, nb1, d_vals, B, n_proofs, d_seeds, d_status);
     }
   }
 }
