@@ -24,13 +24,15 @@ __global__ void k_ext_pows(const u64* __restrict__ point, u64 scale, uint32_t co
   out[2 * t + 1] = r.b;
 }
 
-// one block per polynomial: sum_k c_k z^k with lane t taking the coefficients k = t (mod S)
-__global__ __launch_bounds__(256) void k_eval_polys(const u64* __restrict__ coeffs, uint32_t log_n,
-                                                    const u64* __restrict__ pows /*[S+1] ext*/,
-                                                    u64* __restrict__ out) {
-  __shared__ u64 sa[256], sb[256];
+// one block per polynomial: sum_k c_k z^k with lane t taking the coefficients k = t (mod S).  S = 1024
+// lanes: the per-lane Horner chain (n / S dependent extension multiplies) is what a lone proof waits for.
+constexpr uint32_t EVAL_LANES = 1024;
+__global__ __launch_bounds__(1024) void k_eval_polys(const u64* __restrict__ coeffs, uint32_t log_n,
+                                                     const u64* __restrict__ pows /*[S+1] ext*/,
+                                                     u64* __restrict__ out) {
+  __shared__ u64 sa[EVAL_LANES], sb[EVAL_LANES];
   const uint32_t n = 1u << log_n;
-  const uint32_t S = n < 256 ? n : 256;
+  const uint32_t S = n < EVAL_LANES ? n : EVAL_LANES;
   const u64* c = coeffs + (size_t)blockIdx.x * n;
   const uint32_t t = threadIdx.x;
   gl::E2 acc = gl::e2(0);
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void k_eval_polys(const u64* __restrict__ coef
   sa[t] = acc.a;
   sb[t] = acc.b;
   __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
+  for (int off = EVAL_LANES / 2; off >= 1; off >>= 1) {
     if (t < (unsigned)off) {
       sa[t] = gl::add(sa[t], sa[t + off]);
       sb[t] = gl::add(sb[t], sb[t + off]);
@@ -59,10 +61,11 @@ __global__ __launch_bounds__(256) void k_eval_polys(const u64* __restrict__ coef
 }
 
 void launch_eval_polys(const u64* d_coeffs, uint32_t n_polys, uint32_t log_n, const u64* d_point, u64 scale,
-                       u64* d_scratch_pows, u64* d_out, hipStream_t st) {
-  const uint32_t n = 1u << log_n, S = n < 256 ? n : 256;
-  hipLaunchKernelGGL(k_ext_pows, dim3((S + 1 + 255) / 256), dim3(256), 0, st, d_point, scale, S, 0, d_scratch_pows);
-  hipLaunchKernelGGL(k_eval_polys, dim3(n_polys), dim3(256), 0, st, d_coeffs, log_n, d_scratch_pows, d_out);
+                       u64* d_scratch_pows, u64* d_out, hipStream_t st, bool reuse_pows) {
+  const uint32_t n = 1u << log_n, S = n < EVAL_LANES ? n : EVAL_LANES;
+  if (!reuse_pows)  // (scale * point)^t, t <= S; successive calls at the same point share the table
+    hipLaunchKernelGGL(k_ext_pows, dim3((S + 1 + 255) / 256), dim3(256), 0, st, d_point, scale, S, 0, d_scratch_pows);
+  hipLaunchKernelGGL(k_eval_polys, dim3(n_polys), dim3(EVAL_LANES), 0, st, d_coeffs, log_n, d_scratch_pows, d_out);
 }
 
 // ---------------------------------------------------------------- FRI batching

@@ -95,8 +95,14 @@ __global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__
   s = coop::poseidon_permute(s, threadIdx.x & 63, rc_lds);
   if (valid && rr < 4) parents[4 * g + rr] = s;
 }
+// Levels with at most this many parents use the cooperative kernel.  4096 when many proofs are in flight
+// (the per-lane form costs 25 % fewer instructions); a lone proof prefers 32768: at that size the per-lane
+// form leaves most SIMDs with one wave or none, and the level takes a full permutation latency.
+static size_t g_coop_max_parents = 4096;
+void set_merkle_latency_mode(bool single_proof) { g_coop_max_parents = single_proof ? 32768 : 4096; }
+
 static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st) {
-  if (m <= 4096) {
+  if (m <= g_coop_max_parents) {
     size_t th = m * coop::GROUP;
     hipLaunchKernelGGL(k_tree_level_coop, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, cur, nxt, m);
   } else {

@@ -253,7 +253,7 @@ void DeviceCircuit::ensure_ctx(size_t count) {
   x.transcript = DevMem(sizeof(Transcript) / 8 + 1);
   x.chal = DevMem(CH_WORDS);
   x.alpha_pows = DevMem(2 * ALPHA_POWS);
-  x.eval_pows = DevMem(2 * 258);
+  x.eval_pows = DevMem(2 * 1026);  // z^t, t <= 1024 (launch_eval_polys)
   x.fri_comp = DevMem(4 * n);
   size_t total_polys = layout_.oracle_width[0] + layout_.oracle_width[1] + layout_.oracle_width[2] + layout_.oracle_width[3];
   x.fri_scan = DevMem(2 * (total_polys + 1) + 8 * (n + 1) + 4 * ((n + 255) / 256) + 64);
@@ -407,10 +407,10 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   {
     const u64 g = gl::root_of_unity(db);
     launch_eval_polys(cs_coeffs_.p, L.oracle_width[0], db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.constants, st);
-    launch_eval_polys(x.wires_coeffs.p, W, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.wires, st);
-    launch_eval_polys(x.zs_coeffs.p, NC, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.zs, st);
-    launch_eval_polys(x.zs_coeffs.p + (size_t)NC * n, NC * NP, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.pps, st);
-    launch_eval_polys(x.q_coeffs.p, nq, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.quotient, st);
+    launch_eval_polys(x.wires_coeffs.p, W, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.wires, st, true);
+    launch_eval_polys(x.zs_coeffs.p, NC, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.zs, st, true);
+    launch_eval_polys(x.zs_coeffs.p + (size_t)NC * n, NC * NP, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.pps, st, true);
+    launch_eval_polys(x.q_coeffs.p, nq, db, chal + CH_ZETA, 1, x.eval_pows.p, d_proof + L.quotient, st, true);
     launch_eval_polys(x.zs_coeffs.p, NC, db, chal + CH_ZETA, g, x.eval_pows.p, d_proof + L.zs_next, st);
     // observe: constants|sigmas|wires|zs, then pps|quotient, then zs_next; then FRI alpha
     launch_transcript(tr, 0, d_proof + L.constants, (uint32_t)(L.zs_next - L.constants), chal, 0, st);
@@ -543,6 +543,7 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
     }
   }
   ensure_ctx(K);
+  set_merkle_latency_mode(K == 1);
   const size_t MAXB = 64;
   for (size_t base = 0; base < n_proofs; base += MAXB) {
     size_t bsz = n_proofs - base < MAXB ? n_proofs - base : MAXB;
