@@ -7,6 +7,7 @@
 //   fri_prover_query_rounds              -> launch_queries
 // SURVEY.md App. A.7-A.8.  Extension-field vectors are stored as two component arrays (a[], b[]).
 #include "kernels.h"
+#include "coop.h"
 #include "poseidon.h"
 #include "prover_kernels.h"
 
@@ -262,9 +263,38 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64* __restrict__ v
   }
   for (int i = 0; i < 4; i++) digests[4 * (size_t)l + i] = out[i];
 }
+// Same digests, one 16-lane group per leaf (coop.h).  A FRI layer has few leaves (2^15, 2^11, 2^7 for the
+// fib-64 circuit) and each needs 4 chained permutations, so the per-lane kernel is pure latency (~250 us per
+// layer whatever its size); cooperatively the chain is ~4 x 12 us.  Used for every layer: the whole FRI leaf
+// hashing is < 1 % of a proof's instructions.
+__global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64* __restrict__ va, const u64* __restrict__ vb,
+                                                            uint32_t n_leaves, uint32_t arity_bits,
+                                                            u64* __restrict__ digests) {
+  __shared__ u64 rc_lds[360];
+  coop::stage_poseidon_rc(rc_lds);
+  size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / coop::GROUP;
+  const int rr = threadIdx.x & (coop::GROUP - 1);
+  const bool valid = g < n_leaves;
+  if (!valid) g = n_leaves - 1;  // keep every lane in the shuffles
+  const uint32_t arity = 1u << arity_bits, words = 2 * arity;
+  u64 s = 0;
+  for (uint32_t off = 0; off < words; off += 8) {
+    const uint32_t m = words - off < 8 ? words - off : 8;
+    const uint32_t wd = off + (uint32_t)rr;
+    if ((uint32_t)rr < m) s = ((wd & 1) ? vb : va)[g * arity + (wd >> 1)];
+    s = coop::poseidon_permute(s, threadIdx.x & 63, rc_lds);
+  }
+  if (valid && rr < 4) digests[4 * g + rr] = s;
+}
 void launch_fri_leaf_hash(const u64* va, const u64* vb, uint32_t n_leaves, uint32_t arity_bits, u64* d_digests,
                           hipStream_t st) {
-  hipLaunchKernelGGL(k_fri_leaf_hash, dim3((n_leaves + 255) / 256), dim3(256), 0, st, va, vb, n_leaves, arity_bits, d_digests);
+  if ((2u << arity_bits) <= 4) {  // hash_or_noop: no permutation
+    hipLaunchKernelGGL(k_fri_leaf_hash, dim3((n_leaves + 255) / 256), dim3(256), 0, st, va, vb, n_leaves, arity_bits, d_digests);
+    return;
+  }
+  const size_t th = (size_t)n_leaves * coop::GROUP;
+  hipLaunchKernelGGL(k_fri_leaf_hash_coop, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, va, vb, n_leaves,
+                     arity_bits, d_digests);
 }
 
 // ---------------------------------------------------------------- queries
