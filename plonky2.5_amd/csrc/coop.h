@@ -65,6 +65,36 @@ __device__ inline u64 poseidon_permute(u64 s, int lane, const u64* __restrict__ 
   return gl::canon(s);
 }
 
+// Same permutation when the wave carries ONE state (the transcript): state word r lives in lane r of the
+// wave and the MDS layer broadcasts each word through SGPRs (v_readlane) instead of 24 LDS-crossbar
+// shuffles -- the multiply-adds then take the word as their scalar operand and a per-lane coefficient.
+// A single wave issues its instructions serially, so the shorter sequence is what counts:
+// 15.0 -> 12.9 us per permutation (tools/coopbench.hip).
+__device__ inline u64 poseidon_permute_single(u64 s, int lane, const u64* __restrict__ rc) {
+  const int r = lane < 12 ? lane : 0;
+  u32 coef[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++)
+    coef[j] = poseidon::MDS_CIRC[(j - r + 12) % 12] + ((r == 0 && j == 0) ? poseidon::MDS_DIAG0 : 0);
+  for (int rd = 0; rd < poseidon::N_ROUNDS; rd++) {
+    u64 t = poseidon::add_rc(s, rc[12 * rd + r]);
+    bool full = rd < poseidon::HALF_FULL || rd >= poseidon::HALF_FULL + poseidon::N_PARTIAL;
+    u64 sb = poseidon::sbox(t);
+    s = (full || r == 0) ? sb : t;
+    u32 lo = (u32)s, hi = (u32)(s >> 32);
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+      al += (u64)(u32)__builtin_amdgcn_readlane(lo, j) * coef[j];
+      ah += (u64)(u32)__builtin_amdgcn_readlane(hi, j) * coef[j];
+    }
+    u64 l64 = al + (ah << 32);
+    u32 h32 = (u32)(ah >> 32) + (l64 < al ? 1u : 0u);
+    s = gl::reduce96(l64, h32);
+  }
+  return gl::canon(s);
+}
+
 // Poseidon2 linear layers across the group (poseidon2.rs:126-147, 163-182, 184-213).
 __device__ __forceinline__ u64 p2_external(u64 s, int base, int r) {
   const int blk = base + (r & ~3);

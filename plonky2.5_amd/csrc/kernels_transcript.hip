@@ -28,7 +28,7 @@ struct Sponge {
   __device__ void duplex() {
     if (lane < (int)n_in) state = inb;
     n_in = 0;
-    state = coop::poseidon_permute(state, lane, rc);
+    state = coop::poseidon_permute_single(state, lane, rc);
     outb = state;
     n_out = 8;
   }
