@@ -35,18 +35,31 @@ __device__ __forceinline__ void stage_poseidon2_rc(u64* lds /*[P2_LDS_WORDS]*/) 
   __syncthreads();
 }
 
+// al + ah * 2^32 mod p: the 5-instruction device sequence of poseidon_p3r.h (the host compilation pass only
+// parses these functions).
+__device__ __forceinline__ u64 reduce_row(u64 al, u64 ah) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return poseidon::p3r::reduce_row(al, ah);
+#else
+  return al + (ah << 32);
+#endif
+}
+
 // Poseidon (v1).  `s`: this lane's state word (lanes r >= 12 of the group carry garbage); canonical in/out.
+// As in the per-lane form the constants of round rd + 1 enter through the MDS accumulators of round rd,
+// and the row is reduced by the 5-instruction sequence of poseidon_p3r.h.
 __device__ inline u64 poseidon_permute(u64 s, int lane, const u64* __restrict__ rc) {
   const int base = lane & ~(GROUP - 1);
   const int rr = lane & (GROUP - 1);
   const int r = rr < 12 ? rr : 0;
+  s = poseidon::add_rc(s, rc[r]);
   for (int rd = 0; rd < poseidon::N_ROUNDS; rd++) {
-    u64 t = poseidon::add_rc(s, rc[12 * rd + r]);
-    bool full = rd < poseidon::HALF_FULL || rd >= poseidon::HALF_FULL + poseidon::N_PARTIAL;
-    u64 sb = poseidon::sbox(t);
-    s = (full || r == 0) ? sb : t;
+    const bool full = rd < poseidon::HALF_FULL || rd >= poseidon::HALF_FULL + poseidon::N_PARTIAL;
+    const u64 sb = poseidon::sbox(s);
+    s = (full || r == 0) ? sb : s;
+    const u64 c = rd + 1 < poseidon::N_ROUNDS ? rc[12 * (rd + 1) + r] : 0;
     u32 lo = (u32)s, hi = (u32)(s >> 32);
-    u64 al = 0, ah = 0;
+    u64 al = (u32)c, ah = c >> 32;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
       int src = i + r;
@@ -58,9 +71,7 @@ __device__ inline u64 poseidon_permute(u64 s, int lane, const u64* __restrict__ 
       al += (u64)lo * poseidon::MDS_DIAG0;
       ah += (u64)hi * poseidon::MDS_DIAG0;
     }
-    u64 l64 = al + (ah << 32);
-    u32 h32 = (u32)(ah >> 32) + (l64 < al ? 1u : 0u);
-    s = gl::reduce96(l64, h32);
+    s = reduce_row(al, ah);
   }
   return gl::canon(s);
 }
@@ -76,21 +87,20 @@ __device__ inline u64 poseidon_permute_single(u64 s, int lane, const u64* __rest
 #pragma unroll
   for (int j = 0; j < 12; j++)
     coef[j] = poseidon::MDS_CIRC[(j - r + 12) % 12] + ((r == 0 && j == 0) ? poseidon::MDS_DIAG0 : 0);
+  s = poseidon::add_rc(s, rc[r]);
   for (int rd = 0; rd < poseidon::N_ROUNDS; rd++) {
-    u64 t = poseidon::add_rc(s, rc[12 * rd + r]);
-    bool full = rd < poseidon::HALF_FULL || rd >= poseidon::HALF_FULL + poseidon::N_PARTIAL;
-    u64 sb = poseidon::sbox(t);
-    s = (full || r == 0) ? sb : t;
+    const bool full = rd < poseidon::HALF_FULL || rd >= poseidon::HALF_FULL + poseidon::N_PARTIAL;
+    const u64 sb = poseidon::sbox(s);
+    s = (full || r == 0) ? sb : s;
+    const u64 c = rd + 1 < poseidon::N_ROUNDS ? rc[12 * (rd + 1) + r] : 0;
     u32 lo = (u32)s, hi = (u32)(s >> 32);
-    u64 al = 0, ah = 0;
+    u64 al = (u32)c, ah = c >> 32;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
       al += (u64)(u32)__builtin_amdgcn_readlane(lo, j) * coef[j];
       ah += (u64)(u32)__builtin_amdgcn_readlane(hi, j) * coef[j];
     }
-    u64 l64 = al + (ah << 32);
-    u32 h32 = (u32)(ah >> 32) + (l64 < al ? 1u : 0u);
-    s = gl::reduce96(l64, h32);
+    s = reduce_row(al, ah);
   }
   return gl::canon(s);
 }

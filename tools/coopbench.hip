@@ -87,6 +87,15 @@ __global__ __launch_bounds__(64) void k_v1(u64* io, int reps) {
   for (int r = 0; r < reps; r++) s = perm_v1(s, lane, rc);
   if (lane < 12) io[lane] = s;
 }
+// the product's single-state form (coop.h)
+__global__ __launch_bounds__(64) void k_single(u64* io, int reps) {
+  __shared__ u64 rc[360];
+  coop::stage_poseidon_rc(rc);
+  int lane = threadIdx.x;
+  u64 s = lane < 12 ? io[lane] : 0;
+  for (int r = 0; r < reps; r++) s = coop::poseidon_permute_single(s, lane, rc);
+  if (lane < 12) io[lane] = s;
+}
 template <class K> void run(const char* name, K k) {
   u64* d; (void)hipMallocManaged(&d, 128);
   for (int i = 0; i < 12; i++) d[i] = i;
@@ -99,4 +108,4 @@ template <class K> void run(const char* name, K k) {
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   printf("%-28s %8.2f us per permutation   out[0]=%016llx\n", name, ms * 1e3 / 1001, (unsigned long long)d[0]);
 }
-int main() { run("v0 coop (shfl)", k_v0); run("v1 2 accumulator pairs", k_v1); run("v3 readlane/SGPR broadcast", k_v3); return 0; }
+int main() { run("v0 coop (shfl)", k_v0); run("v1 2 accumulator pairs", k_v1); run("v3 readlane/SGPR broadcast", k_v3); run("coop.h single-state form", k_single); return 0; }
