@@ -28,13 +28,16 @@ __global__ void k_ext_pows(const u64* __restrict__ point, u64 scale, uint32_t co
 // one block per polynomial: sum_k c_k z^k with lane t taking the coefficients k = t (mod S).  S = 1024
 // lanes: the per-lane Horner chain (n / S dependent extension multiplies) is what a lone proof waits for.
 constexpr uint32_t EVAL_LANES = 1024;
-__global__ __launch_bounds__(1024) void k_eval_polys(const u64* __restrict__ coeffs, uint32_t log_n,
+constexpr uint32_t EVAL_CHUNK_LOG = 16;  // polynomials longer than 2^16 are split into chunks, one block each
+// out[(poly, chunk)] = sum_{k in chunk} c_k z^(k - chunk_start): lane t takes k = t (mod S) within the chunk
+__global__ __launch_bounds__(1024) void k_eval_polys(const u64* __restrict__ coeffs, uint32_t log_n, uint32_t log_chunk,
                                                      const u64* __restrict__ pows /*[S+1] ext*/,
                                                      u64* __restrict__ out) {
   __shared__ u64 sa[EVAL_LANES], sb[EVAL_LANES];
-  const uint32_t n = 1u << log_n;
+  const uint32_t n = 1u << log_chunk;
   const uint32_t S = n < EVAL_LANES ? n : EVAL_LANES;
-  const u64* c = coeffs + (size_t)blockIdx.x * n;
+  const uint32_t chunks = 1u << (log_n - log_chunk);
+  const u64* c = coeffs + ((size_t)(blockIdx.x / chunks) << log_n) + ((size_t)(blockIdx.x % chunks) << log_chunk);
   const uint32_t t = threadIdx.x;
   gl::E2 acc = gl::e2(0);
   if (t < S) {
@@ -60,13 +63,35 @@ __global__ __launch_bounds__(1024) void k_eval_polys(const u64* __restrict__ coe
     out[2 * blockIdx.x + 1] = sb[0];
   }
 }
+// out[p] = sum_b part[p][b] (z^chunk)^b  (Horner over the chunks of polynomial p)
+__global__ void k_eval_combine(const u64* __restrict__ part, uint32_t n_polys, uint32_t chunks, uint32_t log_chunk,
+                               const u64* __restrict__ point, u64 scale, u64* __restrict__ out) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_polys) return;
+  gl::E2 y = gl::exp_pow2(gl::mul(gl::E2{point[0], point[1]}, scale), log_chunk);
+  gl::E2 acc = gl::e2(0);
+  for (int b = (int)chunks - 1; b >= 0; b--) {
+    acc = gl::mul(acc, y);
+    acc = gl::add(acc, gl::E2{part[2 * ((size_t)p * chunks + b)], part[2 * ((size_t)p * chunks + b) + 1]});
+  }
+  out[2 * p] = acc.a;
+  out[2 * p + 1] = acc.b;
+}
 
 void launch_eval_polys(const u64* d_coeffs, uint32_t n_polys, uint32_t log_n, const u64* d_point, u64 scale,
                        u64* d_scratch_pows, u64* d_out, hipStream_t st, bool reuse_pows) {
-  const uint32_t n = 1u << log_n, S = n < EVAL_LANES ? n : EVAL_LANES;
+  const uint32_t log_chunk = log_n < EVAL_CHUNK_LOG ? log_n : EVAL_CHUNK_LOG;
+  const uint32_t n = 1u << log_chunk, S = n < EVAL_LANES ? n : EVAL_LANES, chunks = 1u << (log_n - log_chunk);
   if (!reuse_pows)  // (scale * point)^t, t <= S; successive calls at the same point share the table
     hipLaunchKernelGGL(k_ext_pows, dim3((S + 1 + 255) / 256), dim3(256), 0, st, d_point, scale, S, 0, d_scratch_pows);
-  hipLaunchKernelGGL(k_eval_polys, dim3(n_polys), dim3(EVAL_LANES), 0, st, d_coeffs, log_n, d_scratch_pows, d_out);
+  if (chunks == 1) {
+    hipLaunchKernelGGL(k_eval_polys, dim3(n_polys), dim3(EVAL_LANES), 0, st, d_coeffs, log_n, log_chunk, d_scratch_pows, d_out);
+    return;
+  }
+  // partial sums behind the power table: [n_polys][chunks] extension values
+  u64* part = d_scratch_pows + 2 * (EVAL_LANES + 2);
+  hipLaunchKernelGGL(k_eval_polys, dim3(n_polys * chunks), dim3(EVAL_LANES), 0, st, d_coeffs, log_n, log_chunk, d_scratch_pows, part);
+  hipLaunchKernelGGL(k_eval_combine, dim3((n_polys + 63) / 64), dim3(64), 0, st, part, n_polys, chunks, log_chunk, d_point, scale, d_out);
 }
 
 // ---------------------------------------------------------------- FRI batching

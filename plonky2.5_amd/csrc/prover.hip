@@ -1,5 +1,6 @@
 // See prover.h.
 #include "prover.h"
+#include <algorithm>
 #include <string.h>
 #include "poseidon.h"
 
@@ -253,7 +254,12 @@ void DeviceCircuit::ensure_ctx(size_t count) {
   x.transcript = DevMem(sizeof(Transcript) / 8 + 1);
   x.chal = DevMem(CH_WORDS);
   x.alpha_pows = DevMem(2 * ALPHA_POWS);
-  x.eval_pows = DevMem(2 * 1026);  // z^t, t <= 1024 (launch_eval_polys)
+  {
+    // z^t, t <= 1024, followed by the per-chunk partial sums of the widest oracle (launch_eval_polys)
+    const size_t chunks = c_.degree_bits > 16 ? ((size_t)1 << (c_.degree_bits - 16)) : 1;
+    size_t widest = std::max<size_t>({(size_t)layout_.oracle_width[0], (size_t)W, (size_t)nz, (size_t)nq});
+    x.eval_pows = DevMem(2 * 1026 + 2 * widest * chunks);
+  }
   x.fri_comp = DevMem(4 * n);
   size_t total_polys = layout_.oracle_width[0] + layout_.oracle_width[1] + layout_.oracle_width[2] + layout_.oracle_width[3];
   x.fri_scan = DevMem(2 * (total_polys + 1) + 8 * (n + 1) + 4 * ((n + 255) / 256) + 64);

@@ -83,7 +83,7 @@ void launch_zpp(const ZppArgs& a, hipStream_t st);
 // openings: evaluates n_polys coefficient vectors (length n, stride n) at the extension point read
 // from d_point[0..2) (optionally multiplied by `scale`), writing (a, b) pairs to out[2*n_polys].
 void launch_eval_polys(const u64* d_coeffs, uint32_t n_polys, uint32_t log_n, const u64* d_point, u64 scale,
-                       u64* d_scratch_pows /*[2*1026]*/, u64* d_out, hipStream_t st, bool reuse_pows = false);
+                       u64* d_scratch_pows /*[2*1026 + 2*n_polys*chunks]*/, u64* d_out, hipStream_t st, bool reuse_pows = false);
 
 // FRI
 struct FriCombineArgs {
