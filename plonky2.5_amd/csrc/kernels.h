@@ -32,6 +32,7 @@ size_t merkle_level_offset(size_t n_leaves, unsigned level);
 // so bench.py can report its measured duration (roofline line).
 // single_proof: only one proof is in flight (latency matters more than instruction count)
 void set_merkle_latency_mode(bool single_proof);
+bool merkle_latency_mode();
 u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t n_leaves,
                         unsigned cap_height, u64* d_tree, hipStream_t st, hipEvent_t ev_begin = nullptr,
                         hipEvent_t ev_end = nullptr);

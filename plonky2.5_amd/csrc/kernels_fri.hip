@@ -290,8 +290,7 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64* __restrict__ v
 }
 // Same digests, one 16-lane group per leaf (coop.h).  A FRI layer has few leaves (2^15, 2^11, 2^7 for the
 // fib-64 circuit) and each needs 4 chained permutations, so the per-lane kernel is pure latency (~250 us per
-// layer whatever its size); cooperatively the chain is ~4 x 12 us.  Used for every layer: the whole FRI leaf
-// hashing is < 1 % of a proof's instructions.
+// layer whatever its size); cooperatively the chain is ~4 x 12 us.  Used when a single proof is in flight.
 __global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64* __restrict__ va, const u64* __restrict__ vb,
                                                             uint32_t n_leaves, uint32_t arity_bits,
                                                             u64* __restrict__ digests) {
@@ -313,7 +312,8 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64* __restric
 }
 void launch_fri_leaf_hash(const u64* va, const u64* vb, uint32_t n_leaves, uint32_t arity_bits, u64* d_digests,
                           hipStream_t st) {
-  if ((2u << arity_bits) <= 4) {  // hash_or_noop: no permutation
+  // cooperative form only when a lone proof is in flight: it costs 4x the instructions of the per-lane form
+  if ((2u << arity_bits) <= 4 || !merkle_latency_mode()) {
     hipLaunchKernelGGL(k_fri_leaf_hash, dim3((n_leaves + 255) / 256), dim3(256), 0, st, va, vb, n_leaves, arity_bits, d_digests);
     return;
   }

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__
 // form leaves most SIMDs with one wave or none, and the level takes a full permutation latency.
 static size_t g_coop_max_parents = 4096;
 void set_merkle_latency_mode(bool single_proof) { g_coop_max_parents = single_proof ? 32768 : 4096; }
+bool merkle_latency_mode() { return g_coop_max_parents > 4096; }
 
 static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st) {
   if (m <= g_coop_max_parents) {

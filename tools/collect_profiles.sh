@@ -9,12 +9,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/${TAG}_pytest_gpu.txt 2>&1
-# PMC passes (each alone with --kernel-trace), one proof
+# PMC passes (each alone with --kernel-trace)
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $C | cut -d' ' -f1)
   rm -rf $OUT/_pmc
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/_pmc -- python3 tools/prove_one.py 1 > $OUT/_pmc.log 2>&1
-  python3 tools/pmc_summary.py $OUT/_pmc $OUT/${TAG}_pmc_${N}.json > $OUT/${TAG}_pmc_${N}.txt
+  # a batch of 4: the kernels of the throughput path (a lone proof switches some stages to latency-oriented forms)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/_pmc -- python3 tools/prove_one.py 4 > $OUT/_pmc.log 2>&1
+  python3 tools/pmc_summary.py $OUT/_pmc $OUT/${TAG}_pmc_${N}.json 4 > $OUT/${TAG}_pmc_${N}.txt
   rm -rf $OUT/_pmc
 done
 cp $OUT/${TAG}_pmc_SQ_INSTS_VALU.json profiles/ 2>/dev/null   # bench.py reads the VALU counts from profiles/

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --pmc ... --kernel-trace CSV pair per kernel (second half of the run = the
-timed prove call of tools/prove_one.py).  usage: pmc_summary.py <dir with *_counter_collection.csv>"""
+timed prove call of tools/prove_one.py).  usage: pmc_summary.py <dir with *_counter_collection.csv> [out.json] [proofs in the timed call]
+All figures are per proof."""
 import collections, csv, glob, json, os, sys
 d = sys.argv[1]
 cc = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0])))
 kt = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0])))
-ids = sorted(int(r["Dispatch_Id"]) for r in kt)
-half = ids[len(ids) // 2]
+# the timed prove call starts at the LAST k_witgen_set_inputs dispatch; counts are divided by its batch size
+n_proofs = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+starts = [int(r["Dispatch_Id"]) for r in kt if "k_witgen_set_inputs" in r["Kernel_Name"]]
+half = max(starts) - 1 if starts else sorted(int(r["Dispatch_Id"]) for r in kt)[len(kt) // 2]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in kt:
     if int(r["Dispatch_Id"]) <= half: continue
@@ -15,6 +18,9 @@ for r in kt:
 for r in cc:
     if int(r["Dispatch_Id"]) <= half: continue
     agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
+for v in agg.values():
+    for k in list(v):
+        v[k] /= n_proofs
 rows = sorted(agg.items(), key=lambda kv: -kv[1]["dur_ns"])
 names = sorted({c for _, v in rows for c in v if c not in ("dur_ns", "calls")})
 print(f"{'kernel':28s} calls  dur_ms " + " ".join(f"{n[:14]:>14s}" for n in names))
