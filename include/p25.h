@@ -189,6 +189,10 @@ typedef struct {
   float witness_ms, wires_commit_ms, partial_products_ms, zs_commit_ms, quotient_ms, quotient_commit_ms,
       openings_ms, fri_ms, total_ms;
 } p25_timings;
+/* Threading: a p25_circuit owns its streams and per-proof contexts, so calls on ONE circuit must not overlap
+ * (upstream's `prove(&self)` is re-entrant; here use one p25_circuit per host thread, or serialise).  Different
+ * circuits may be used from different threads.  With `timings` != NULL, or a batch of one, the proofs run one
+ * at a time with latency-oriented kernel forms; otherwise up to P25_STREAMS (16) proofs are in flight. */
 p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* seeds,
                            uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status,
                            p25_timings* timings);
