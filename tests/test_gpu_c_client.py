@@ -1,0 +1,25 @@
+"""GPU: a plain-C program (tests/c_abi/example.c) drives the whole path through include/p25.h --
+header usable from C, symbols link, statuses and determinism as documented."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c_client(tmp_path):
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    libdir = os.path.join(ROOT, "plonky2.5_amd")
+    exe = str(tmp_path / "c_client")
+    r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c_abi", "example.c"), "-L" + libdir, "-lp25",
+                        "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "C CLIENT OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
