@@ -160,22 +160,28 @@ __device__ __forceinline__ void permute_dev(u64 s[WIDTH]) {
   rc_ptr rc = (rc_ptr)RC_SPLIT.v;
   asm("" : "+s"(rc));
   int r = 1;
+#if P25_PARTIAL3
+  // full rounds 0..2 with their MDS layers; round 3's S-boxes only -- its MDS is the first layer of the head block
+  for (int k = 0; k < HALF_FULL - 1; k++, r++) {
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
+    mds_rc(s, rc + 2 * WIDTH * r);
+  }
+#pragma unroll
+  for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
+  // the 22 partial rounds: head block (MDS of round 3 + rounds 4, 5), six blocks of three, tail block of two
+  p3r::tbl_ptr tp = (p3r::tbl_ptr)&p3r::TBL;
+  asm("" : "+s"(tp));
+  p3r::three_rounds<true>(s, tp, tp->kh);
+  for (int b = 0; b < p3r::BLOCKS; b++) p3r::three_rounds<false>(s, tp, tp->kc[b]);
+  p3r::two_rounds(s, tp);
+  r = HALF_FULL + N_PARTIAL + 1;
+#else
   for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
     mds_rc(s, rc + 2 * WIDTH * r);
   }
-#if P25_PARTIAL3
-  // 21 partial rounds as 7 blocks of three (poseidon_p3r.h), the 22nd round by round
-  p3r::tbl_ptr tp = (p3r::tbl_ptr)&p3r::TBL;
-  asm("" : "+s"(tp));
-  for (int b = 0; b < p3r::BLOCKS; b++) p3r::three_rounds(s, tp, b);
-  r += 3 * p3r::BLOCKS;
-  for (int k = 3 * p3r::BLOCKS; k < N_PARTIAL; k++, r++) {
-    s[0] = sbox(s[0]);
-    mds_rc(s, rc + 2 * WIDTH * r);
-  }
-#else
   for (int k = 0; k < N_PARTIAL; k++, r++) {
     s[0] = sbox(s[0]);
     mds_rc(s, rc + 2 * WIDTH * r);

@@ -13,30 +13,67 @@
 // THREE rounds, plus two single rows: 442 multiply-adds instead of 3 x 288.  (Four rounds would
 // overflow the accumulators; upstream's sparse "fast partial rounds" need 64-bit constants, i.e. full
 // modular multiplies, and come out no cheaper than the dense layer on this ISA.)
+//
+// The 22 partial rounds (4..25) are scheduled as
+//   * a HEAD block that starts from the S-box outputs y of full round 3: its first "round" is just that
+//     round's MDS layer (the same formulas with d0 = 0), followed by partial rounds 4 and 5;
+//   * six regular blocks for rounds 6..23;
+//   * a TAIL block of two rounds (24, 25) built on M^2.
+// so the MDS layer of full round 3 costs nothing extra and no single round is left over.
 // The arithmetic is exact integer arithmetic mod p: results are bit-identical to the round-by-round form.
 #pragma once
 
 namespace p3r {
 
-constexpr int BLOCKS = 7;  // 21 of the 22 partial rounds; the last one runs through mds_rc
+constexpr int BLOCKS = 6;         // regular three-round blocks: rounds 6 + 3 b .. 8 + 3 b
+constexpr int HEAD_ROUND = 3;     // the head block replaces MDS(round 3) + partial rounds 4, 5
+constexpr int FIRST_BLOCK = 6;    // first round of regular block 0
+constexpr int TAIL_ROUND = 24;    // the tail block covers partial rounds 24, 25
+static_assert(HEAD_ROUND == HALF_FULL - 1 && FIRST_BLOCK + 3 * BLOCKS == TAIL_ROUND &&
+                  TAIL_ROUND + 2 == HALF_FULL + N_PARTIAL,
+              "partial-round schedule");
 
 struct Row16 {
   u32 c[16];
 };
 struct Tables {
   Row16 t3[WIDTH];        // M^3 row r | (M^2 m0)[r], (M m0)[r], m0[r], 0
+  Row16 t2[WIDTH];        // M^2 row r | (M m0)[r], m0[r], 0, 0
   Row16 r2;               // row 0 of M^2 | (M m0)[0], m0[0], 0, 0
   u32 kc[BLOCKS][64];     // per block: k1.lo, k1.hi, k2.lo, k2.hi, then K3[r].lo, K3[r].hi (r < 12), padding
+  u32 kh[64];             // head block, same layout
+  u32 kt[64];             // tail block: k1.lo, k1.hi, 0, 0, then K2[r].lo, K2[r].hi
 };
 
 constexpr u64 mulmod(u64 a, u64 b) { return (u64)((unsigned __int128)a * b % gl::P); }
 constexpr u64 addmod(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % gl::P); }
+constexpr u64 mds_entry(int r, int j) { return MDS_CIRC[(j - r + WIDTH) % WIDTH] + (r == 0 && j == 0 ? MDS_DIAG0 : 0); }
+
+// constants of a block whose three linear layers are followed by the constants of rounds r0+1, r0+2, r0+3
+constexpr void block_constants(u32* out, int r0, const u64 (&M)[WIDTH][WIDTH], const u64 (&M2)[WIDTH][WIDTH]) {
+  const u64* c1 = RC + WIDTH * (r0 + 1);
+  const u64* c2 = RC + WIDTH * (r0 + 2);
+  const u64* c3 = RC + WIDTH * (r0 + 3);
+  u64 k1 = c1[0];
+  u64 k2 = c2[0];
+  for (int j = 0; j < WIDTH; j++) k2 = addmod(k2, mulmod(M[0][j], c1[j]));
+  out[0] = (u32)k1;
+  out[1] = (u32)(k1 >> 32);
+  out[2] = (u32)k2;
+  out[3] = (u32)(k2 >> 32);
+  for (int r = 0; r < WIDTH; r++) {
+    u64 k3 = c3[r];
+    for (int j = 0; j < WIDTH; j++) k3 = addmod(k3, addmod(mulmod(M2[r][j], c1[j]), mulmod(M[r][j], c2[j])));
+    out[4 + 2 * r] = (u32)k3;
+    out[5 + 2 * r] = (u32)(k3 >> 32);
+  }
+}
 
 constexpr Tables make_tables() {
   Tables t{};
   u64 M[WIDTH][WIDTH] = {}, M2[WIDTH][WIDTH] = {}, M3[WIDTH][WIDTH] = {};
   for (int r = 0; r < WIDTH; r++)
-    for (int j = 0; j < WIDTH; j++) M[r][j] = MDS_CIRC[(j - r + WIDTH) % WIDTH] + (r == 0 && j == 0 ? MDS_DIAG0 : 0);
+    for (int j = 0; j < WIDTH; j++) M[r][j] = mds_entry(r, j);
   for (int r = 0; r < WIDTH; r++)
     for (int j = 0; j < WIDTH; j++)
       for (int k = 0; k < WIDTH; k++) M2[r][j] += M[r][k] * M[k][j];
@@ -45,88 +82,111 @@ constexpr Tables make_tables() {
       for (int k = 0; k < WIDTH; k++) M3[r][j] += M2[r][k] * M[k][j];
   // v' = M (v + d e0) + c' = M v + d (M e0): m0 = column 0 of M, M m0 = column 0 of M^2, M^2 m0 = column 0 of M^3
   for (int r = 0; r < WIDTH; r++) {
-    for (int j = 0; j < WIDTH; j++) t.t3[r].c[j] = (u32)M3[r][j];
+    for (int j = 0; j < WIDTH; j++) {
+      t.t3[r].c[j] = (u32)M3[r][j];
+      t.t2[r].c[j] = (u32)M2[r][j];
+    }
     t.t3[r].c[12] = (u32)M3[r][0];
     t.t3[r].c[13] = (u32)M2[r][0];
     t.t3[r].c[14] = (u32)M[r][0];
-    t.t3[r].c[15] = 0;
+    t.t2[r].c[12] = (u32)M2[r][0];
+    t.t2[r].c[13] = (u32)M[r][0];
   }
   for (int j = 0; j < WIDTH; j++) t.r2.c[j] = (u32)M2[0][j];
   t.r2.c[12] = (u32)M2[0][0];
   t.r2.c[13] = (u32)M[0][0];
-  for (int b = 0; b < BLOCKS; b++) {
-    const int r0 = HALF_FULL + 3 * b;
-    const u64* c1 = RC + WIDTH * (r0 + 1);
-    const u64* c2 = RC + WIDTH * (r0 + 2);
-    const u64* c3 = RC + WIDTH * (r0 + 3);
-    u64 k1 = c1[0];
-    u64 k2 = c2[0];
-    for (int j = 0; j < WIDTH; j++) k2 = addmod(k2, mulmod(M[0][j], c1[j]));
-    t.kc[b][0] = (u32)k1;
-    t.kc[b][1] = (u32)(k1 >> 32);
-    t.kc[b][2] = (u32)k2;
-    t.kc[b][3] = (u32)(k2 >> 32);
+  for (int b = 0; b < BLOCKS; b++) block_constants(t.kc[b], FIRST_BLOCK + 3 * b, M, M2);
+  block_constants(t.kh, HEAD_ROUND, M, M2);
+  {  // tail: v2 = M^2 v + d0 (M m0) + d1 m0 + (M c1 + c2), c1 = RC[25], c2 = RC[26]
+    const u64* c1 = RC + WIDTH * (TAIL_ROUND + 1);
+    const u64* c2 = RC + WIDTH * (TAIL_ROUND + 2);
+    t.kt[0] = (u32)c1[0];
+    t.kt[1] = (u32)(c1[0] >> 32);
     for (int r = 0; r < WIDTH; r++) {
-      u64 k3 = c3[r];
-      for (int j = 0; j < WIDTH; j++) k3 = addmod(k3, addmod(mulmod(M2[r][j], c1[j]), mulmod(M[r][j], c2[j])));
-      t.kc[b][4 + 2 * r] = (u32)k3;
-      t.kc[b][5 + 2 * r] = (u32)(k3 >> 32);
+      u64 k = c2[r];
+      for (int j = 0; j < WIDTH; j++) k = addmod(k, mulmod(M[r][j], c1[j]));
+      t.kt[4 + 2 * r] = (u32)k;
+      t.kt[5 + 2 * r] = (u32)(k >> 32);
     }
   }
   return t;
 }
 static constexpr Tables TBL = make_tables();
 
-// Compile-time check of the algebra: three rounds through the tables == three rounds one at a time
-// (plain modular arithmetic, on a fixed non-trivial state, for every block).
+// ---- compile-time check of the algebra: every block through the tables == the same rounds one at a time
+// (plain modular arithmetic, on a fixed non-trivial state)
 constexpr u64 sbox_ref(u64 x) {
   u64 x2 = mulmod(x, x), x4 = mulmod(x2, x2), x3 = mulmod(x, x2);
   return mulmod(x3, x4);
 }
-constexpr bool tables_consistent() {
-  for (int b = 0; b < BLOCKS; b++) {
-    u64 v[WIDTH] = {}, w[WIDTH] = {};
-    for (int i = 0; i < WIDTH; i++) v[i] = w[i] = mulmod(0x9E3779B97F4A7C15ull % gl::P, (u64)(i + 1 + 13 * b)) ^ 0;
-    // reference: round by round, constants of the following round added after the MDS layer
-    const int r0 = HALF_FULL + 3 * b;
-    for (int k = 0; k < 3; k++) {
-      u64 y[WIDTH] = {};
-      for (int i = 0; i < WIDTH; i++) y[i] = w[i];
-      y[0] = sbox_ref(y[0]);
-      for (int r = 0; r < WIDTH; r++) {
-        u64 acc = RC[WIDTH * (r0 + k + 1) + r];
-        for (int j = 0; j < WIDTH; j++)
-          acc = addmod(acc, mulmod(MDS_CIRC[(j - r + WIDTH) % WIDTH] + (r == 0 && j == 0 ? MDS_DIAG0 : 0), y[j]));
-        w[r] = acc;
-      }
-    }
-    // through the tables
-    u64 d[3] = {};
-    u64 x = v[0];
-    d[0] = addmod(sbox_ref(x), gl::P - x);
-    const u64 row0[WIDTH] = {25, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    u64 a = (u64)TBL.kc[b][0] | ((u64)TBL.kc[b][1] << 32);
-    for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(row0[j], v[j]));
-    a = addmod(a, mulmod(25, d[0]));
-    x = a;
-    d[1] = addmod(sbox_ref(x), gl::P - x);
-    a = (u64)TBL.kc[b][2] | ((u64)TBL.kc[b][3] << 32);
-    for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.r2.c[j], v[j]));
-    a = addmod(a, addmod(mulmod(TBL.r2.c[12], d[0]), mulmod(TBL.r2.c[13], d[1])));
-    x = a;
-    d[2] = addmod(sbox_ref(x), gl::P - x);
+constexpr u64 kpair(const u32* k, int i) { return (u64)k[i] | ((u64)k[i + 1] << 32); }
+// reference: `n` rounds starting at round r0 (state has RC[r0] added); skip_first: the first round has no S-box
+constexpr void rounds_ref(u64 (&w)[WIDTH], int r0, int n, bool skip_first) {
+  for (int k = 0; k < n; k++) {
+    u64 y[WIDTH] = {};
+    for (int i = 0; i < WIDTH; i++) y[i] = w[i];
+    if (!(skip_first && k == 0)) y[0] = sbox_ref(y[0]);
     for (int r = 0; r < WIDTH; r++) {
-      a = (u64)TBL.kc[b][4 + 2 * r] | ((u64)TBL.kc[b][5 + 2 * r] << 32);
-      for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.t3[r].c[j], v[j]));
-      for (int e = 0; e < 3; e++) a = addmod(a, mulmod(TBL.t3[r].c[12 + e], d[e]));
-      if (a != w[r]) return false;
+      u64 acc = RC[WIDTH * (r0 + k + 1) + r];
+      for (int j = 0; j < WIDTH; j++) acc = addmod(acc, mulmod(mds_entry(r, j), y[j]));
+      w[r] = acc;
     }
+  }
+}
+constexpr bool block_consistent(const u32* kc, int r0, bool skip_first, int salt) {
+  u64 v[WIDTH] = {}, w[WIDTH] = {};
+  for (int i = 0; i < WIDTH; i++) v[i] = w[i] = mulmod(0x9E3779B97F4A7C15ull % gl::P, (u64)(i + 1 + 13 * salt));
+  rounds_ref(w, r0, 3, skip_first);
+  u64 d[3] = {};
+  u64 x = v[0];
+  d[0] = skip_first ? 0 : addmod(sbox_ref(x), gl::P - x);
+  u64 a = kpair(kc, 0);
+  for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(mds_entry(0, j), v[j]));
+  a = addmod(a, mulmod(mds_entry(0, 0), d[0]));
+  x = a;
+  d[1] = addmod(sbox_ref(x), gl::P - x);
+  a = kpair(kc, 2);
+  for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.r2.c[j], v[j]));
+  a = addmod(a, addmod(mulmod(TBL.r2.c[12], d[0]), mulmod(TBL.r2.c[13], d[1])));
+  x = a;
+  d[2] = addmod(sbox_ref(x), gl::P - x);
+  for (int r = 0; r < WIDTH; r++) {
+    a = kpair(kc, 4 + 2 * r);
+    for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.t3[r].c[j], v[j]));
+    for (int e = 0; e < 3; e++) a = addmod(a, mulmod(TBL.t3[r].c[12 + e], d[e]));
+    if (a != w[r]) return false;
   }
   return true;
 }
-static_assert(tables_consistent(), "poseidon_p3r.h: three-round tables disagree with the round-by-round definition");
+constexpr bool tail_consistent() {
+  u64 v[WIDTH] = {}, w[WIDTH] = {};
+  for (int i = 0; i < WIDTH; i++) v[i] = w[i] = mulmod(0x9E3779B97F4A7C15ull % gl::P, (u64)(i + 977));
+  rounds_ref(w, TAIL_ROUND, 2, false);
+  u64 d[2] = {};
+  u64 x = v[0];
+  d[0] = addmod(sbox_ref(x), gl::P - x);
+  u64 a = kpair(TBL.kt, 0);
+  for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(mds_entry(0, j), v[j]));
+  a = addmod(a, mulmod(mds_entry(0, 0), d[0]));
+  x = a;
+  d[1] = addmod(sbox_ref(x), gl::P - x);
+  for (int r = 0; r < WIDTH; r++) {
+    a = kpair(TBL.kt, 4 + 2 * r);
+    for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.t2[r].c[j], v[j]));
+    for (int e = 0; e < 2; e++) a = addmod(a, mulmod(TBL.t2[r].c[12 + e], d[e]));
+    if (a != w[r]) return false;
+  }
+  return true;
+}
+constexpr bool tables_consistent() {
+  for (int b = 0; b < BLOCKS; b++)
+    if (!block_consistent(TBL.kc[b], FIRST_BLOCK + 3 * b, false, b)) return false;
+  return block_consistent(TBL.kh, HEAD_ROUND, true, 101) && tail_consistent();
+}
+static_assert(tables_consistent(), "poseidon_p3r.h: block tables disagree with the round-by-round definition");
 
 typedef const Tables __attribute__((address_space(4))) * tbl_ptr;
+typedef const u32 __attribute__((address_space(4))) * k_ptr;
 
 __device__ __forceinline__ void mad_s(u64& acc, u32 x, u32 coef_sgpr) {
   u64 dm;
@@ -157,8 +217,8 @@ __device__ __forceinline__ u64 reduce_row(u64 al, u64 ah) {
   return gl::make64(x0, x1);
 }
 
-// One row: sum_j coef[j] v_j + sum_e coef[12 + e] d_e + k, on 32-bit halves.
-template <int NEXTRA>
+// One row: sum_j coef[j] v_j + sum_{e in [E0, E0 + NEXTRA)} coef[12 + e] d_e + k, on 32-bit halves.
+template <int E0, int NEXTRA>
 __device__ __forceinline__ u64 row(const u32* lo, const u32* hi, const Row16& cf, const u32* dlo, const u32* dhi,
                                    u32 klo, u32 khi) {
   u64 al = mul_s(lo[0], cf.c[0]), ah = mul_s(hi[0], cf.c[0]);
@@ -168,7 +228,7 @@ __device__ __forceinline__ u64 row(const u32* lo, const u32* hi, const Row16& cf
     mad_s(ah, hi[j], cf.c[j]);
   }
 #pragma unroll
-  for (int e = 0; e < NEXTRA; e++) {
+  for (int e = E0; e < E0 + NEXTRA; e++) {
     mad_s(al, dlo[e], cf.c[12 + e]);
     mad_s(ah, dhi[e], cf.c[12 + e]);
   }
@@ -176,61 +236,86 @@ __device__ __forceinline__ u64 row(const u32* lo, const u32* hi, const Row16& cf
   add_s(ah, khi);
   return reduce_row(al, ah);
 }
+// Row 0 of M (inline-constant entries 25, 15, 41, ..., 20) applied to the state, + 25 d (if WITH_D) + k
+template <bool WITH_D>
+__device__ __forceinline__ u64 row0_m(const u32* lo, const u32* hi, u32 dlo, u32 dhi, u32 klo, u32 khi) {
+  u64 al = 0, ah = 0;
+  mad_k<25>(al, lo[0]);  mad_k<25>(ah, hi[0]);
+  mad_k<15>(al, lo[1]);  mad_k<15>(ah, hi[1]);
+  mad_k<41>(al, lo[2]);  mad_k<41>(ah, hi[2]);
+  mad_k<16>(al, lo[3]);  mad_k<16>(ah, hi[3]);
+  mad_k<2>(al, lo[4]);   mad_k<2>(ah, hi[4]);
+  mad_k<28>(al, lo[5]);  mad_k<28>(ah, hi[5]);
+  mad_k<13>(al, lo[6]);  mad_k<13>(ah, hi[6]);
+  mad_k<13>(al, lo[7]);  mad_k<13>(ah, hi[7]);
+  mad_k<39>(al, lo[8]);  mad_k<39>(ah, hi[8]);
+  mad_k<18>(al, lo[9]);  mad_k<18>(ah, hi[9]);
+  mad_k<34>(al, lo[10]); mad_k<34>(ah, hi[10]);
+  mad_k<20>(al, lo[11]); mad_k<20>(ah, hi[11]);
+  if (WITH_D) {
+    mad_k<25>(al, dlo);
+    mad_k<25>(ah, dhi);
+  }
+  add_s(al, klo);
+  add_s(ah, khi);
+  return reduce_row(al, ah);
+}
+__device__ __forceinline__ void load_row(Row16& cf, const Row16 __attribute__((address_space(4))) * src) {
+#pragma unroll
+  for (int j = 0; j < 16; j++) cf.c[j] = src->c[j];
+}
+__device__ __forceinline__ void delta(u64 x_canonical, u32& dlo, u32& dhi) {
+  const u64 d = gl::sub(sbox(x_canonical), x_canonical);  // sbox(x) - x: any u64 minus a canonical value
+  dlo = (u32)d;
+  dhi = (u32)(d >> 32);
+}
 
-// s: state entering partial round HALF_FULL + 3 b (constants added, any u64 representatives);
-// on return: state entering round HALF_FULL + 3 b + 3.
-__device__ __forceinline__ void three_rounds(u64 s[WIDTH], tbl_ptr tp, int b) {
+// Three linear layers with the S-boxes of lane 0 in between.
+//   HEAD = false: s = state entering a partial round (constants added); on return the state three rounds later.
+//   HEAD = true : s = S-box outputs of the last leading full round; the first layer is that round's MDS.
+template <bool HEAD>
+__device__ __forceinline__ void three_rounds(u64 s[WIDTH], tbl_ptr tp, k_ptr kc) {
   u32 lo[WIDTH], hi[WIDTH];
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) {
     lo[i] = (u32)s[i];
     hi[i] = (u32)(s[i] >> 32);
   }
-  const auto* kc = tp->kc[b];
-  u32 dlo[3], dhi[3];
-  u64 x = gl::canon(s[0]);
-  u64 d = gl::sub(sbox(x), x);  // sbox(x) - x: any u64 minus a canonical value
-  dlo[0] = (u32)d;
-  dhi[0] = (u32)(d >> 32);
-  {
-    // row 0 of M has inline-constant entries, but one code path for all rows keeps this short: M row 0 =
-    // (25, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20), m0[0] = 25
-    u64 al = 0, ah = 0;
-    mad_k<25>(al, lo[0]);  mad_k<25>(ah, hi[0]);
-    mad_k<15>(al, lo[1]);  mad_k<15>(ah, hi[1]);
-    mad_k<41>(al, lo[2]);  mad_k<41>(ah, hi[2]);
-    mad_k<16>(al, lo[3]);  mad_k<16>(ah, hi[3]);
-    mad_k<2>(al, lo[4]);   mad_k<2>(ah, hi[4]);
-    mad_k<28>(al, lo[5]);  mad_k<28>(ah, hi[5]);
-    mad_k<13>(al, lo[6]);  mad_k<13>(ah, hi[6]);
-    mad_k<13>(al, lo[7]);  mad_k<13>(ah, hi[7]);
-    mad_k<39>(al, lo[8]);  mad_k<39>(ah, hi[8]);
-    mad_k<18>(al, lo[9]);  mad_k<18>(ah, hi[9]);
-    mad_k<34>(al, lo[10]); mad_k<34>(ah, hi[10]);
-    mad_k<20>(al, lo[11]); mad_k<20>(ah, hi[11]);
-    mad_k<25>(al, dlo[0]); mad_k<25>(ah, dhi[0]);
-    add_s(al, kc[0]);
-    add_s(ah, kc[1]);
-    x = gl::canon(reduce_row(al, ah));
-  }
-  d = gl::sub(sbox(x), x);
-  dlo[1] = (u32)d;
-  dhi[1] = (u32)(d >> 32);
+  u32 dlo[3] = {0, 0, 0}, dhi[3] = {0, 0, 0};
+  if (!HEAD) delta(gl::canon(s[0]), dlo[0], dhi[0]);
+  u64 x = gl::canon(row0_m<!HEAD>(lo, hi, dlo[0], dhi[0], kc[0], kc[1]));
+  delta(x, dlo[1], dhi[1]);
   {
     Row16 cf;
-#pragma unroll
-    for (int j = 0; j < 16; j++) cf.c[j] = tp->r2.c[j];
-    x = gl::canon(row<2>(lo, hi, cf, dlo, dhi, kc[2], kc[3]));
+    load_row(cf, &tp->r2);
+    x = gl::canon(row<HEAD ? 1 : 0, HEAD ? 1 : 2>(lo, hi, cf, dlo, dhi, kc[2], kc[3]));
   }
-  d = gl::sub(sbox(x), x);
-  dlo[2] = (u32)d;
-  dhi[2] = (u32)(d >> 32);
+  delta(x, dlo[2], dhi[2]);
 #pragma unroll
   for (int r = 0; r < WIDTH; r++) {
     Row16 cf;
+    load_row(cf, &tp->t3[r]);
+    s[r] = row<HEAD ? 1 : 0, HEAD ? 2 : 3>(lo, hi, cf, dlo, dhi, kc[4 + 2 * r], kc[5 + 2 * r]);
+  }
+}
+// The last two partial rounds.
+__device__ __forceinline__ void two_rounds(u64 s[WIDTH], tbl_ptr tp) {
+  u32 lo[WIDTH], hi[WIDTH];
 #pragma unroll
-    for (int j = 0; j < 16; j++) cf.c[j] = tp->t3[r].c[j];
-    s[r] = row<3>(lo, hi, cf, dlo, dhi, kc[4 + 2 * r], kc[5 + 2 * r]);
+  for (int i = 0; i < WIDTH; i++) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+  const k_ptr kc = tp->kt;
+  u32 dlo[2], dhi[2];
+  delta(gl::canon(s[0]), dlo[0], dhi[0]);
+  const u64 x = gl::canon(row0_m<true>(lo, hi, dlo[0], dhi[0], kc[0], kc[1]));
+  delta(x, dlo[1], dhi[1]);
+#pragma unroll
+  for (int r = 0; r < WIDTH; r++) {
+    Row16 cf;
+    load_row(cf, &tp->t2[r]);
+    s[r] = row<0, 2>(lo, hi, cf, dlo, dhi, kc[4 + 2 * r], kc[5 + 2 * r]);
   }
 }
 
