@@ -94,7 +94,9 @@ __device__ __forceinline__ void mad_k(u64& acc, u32 x) {
 // constants + 5 instructions per row for the reduction (the compiler's version of mds(): shifts for the
 // power-of-two entries through v_mov'd pairs, ~23 non-mad instructions per row).
 typedef const u64 __attribute__((address_space(4))) * rc_ptr;  // constant address space: scalar loads
-__device__ __forceinline__ void mds_rc(u64 s[WIDTH], rc_ptr k) {
+// `rows`: bit r set = output word r is wanted (wave-uniform; the last layer of a sponge permutation only
+// needs the capacity words, or the digest words -- see permute_rows).
+__device__ __forceinline__ void mds_rc(u64 s[WIDTH], rc_ptr k, u32 rows = 0xFFF) {
   u32 lo[WIDTH], hi[WIDTH];
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) {
@@ -103,6 +105,7 @@ __device__ __forceinline__ void mds_rc(u64 s[WIDTH], rc_ptr k) {
   }
 #pragma unroll
   for (int r = 0; r < WIDTH; r++) {
+    if (!((rows >> r) & 1u)) continue;
     u64 al, ah, dm, t;
     asm("v_mad_u64_u32 %0, %1, %2, 17, %3" : "=v"(al), "=s"(dm) : "v"(lo[r]), "s"(k[2 * r]));
     asm("v_mad_u64_u32 %0, %1, %2, 17, %3" : "=v"(ah), "=s"(dm) : "v"(hi[r]), "s"(k[2 * r + 1]));
@@ -152,7 +155,7 @@ static_assert(MDS_CIRC[0] == 17 && MDS_CIRC[1] == 15 && MDS_CIRC[2] == 41 && MDS
 #endif
 #include "poseidon_p3r.h"
 
-__device__ __forceinline__ void permute_dev(u64 s[WIDTH]) {
+__device__ __forceinline__ void permute_dev(u64 s[WIDTH], u32 rows) {
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) s[i] = add_rc(s[i], RC[i]);
   // Opaque base pointer: otherwise every one of the 24 scalar loads per round recomputes the table's
@@ -187,21 +190,29 @@ __device__ __forceinline__ void permute_dev(u64 s[WIDTH]) {
     mds_rc(s, rc + 2 * WIDTH * r);
   }
 #endif
-  for (int k = 0; k < HALF_FULL; k++, r++) {
+  for (int k = 0; k < HALF_FULL - 1; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
-    mds_rc(s, rc + 2 * WIDTH * r);  // r == N_ROUNDS for the last round: the zero row
+    mds_rc(s, rc + 2 * WIDTH * r);
   }
+  // last round: the zero constant row, and only the output words the caller will read
+#pragma unroll
+  for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
+  mds_rc(s, rc + 2 * WIDTH * N_ROUNDS, rows);
 #pragma unroll
   for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
 }
 #endif
 
-// Canonical in, canonical out.
-GL_HD void permute(u64 s[WIDTH]) {
+// Canonical in, canonical out.  permute_rows: only the output words whose bit is set in `rows` are
+// defined afterwards (the others hold unspecified canonical values).  In an overwrite-mode sponge every
+// absorbing permutation is followed by 8 fresh inputs, so only its capacity words 8..11 matter, and the
+// last one only yields the 4 digest words: 8 of the 12 rows of the final MDS layer are never computed.
+GL_HD void permute_rows(u64 s[WIDTH], u32 rows) {
 #if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
-  permute_dev(s);
+  permute_dev(s, rows);
 #else
+  (void)rows;
   int r = 0;
   for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
@@ -226,6 +237,9 @@ GL_HD void permute(u64 s[WIDTH]) {
 #endif
 }
 
+GL_HD void permute(u64 s[WIDTH]) { permute_rows(s, 0xFFF); }
+constexpr u32 ROWS_DIGEST = 0x00F, ROWS_CAPACITY = 0xF00, ROWS_ALL = 0xFFF;
+
 // compress two 4-word digests (upstream `two_to_one`)
 GL_HD void two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
   u64 s[WIDTH];
@@ -235,7 +249,7 @@ GL_HD void two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
     s[4 + i] = r[i];
     s[8 + i] = 0;
   }
-  permute(s);
+  permute_rows(s, ROWS_DIGEST);
 #pragma unroll
   for (int i = 0; i < 4; i++) out[i] = s[i];
 }
@@ -248,7 +262,8 @@ GL_HD void hash_no_pad_strided(const u64* in, size_t stride, int n, u64 out[4]) 
   for (int off = 0; off < n; off += RATE) {
     int m = n - off < RATE ? n - off : RATE;
     for (int i = 0; i < m; i++) s[i] = in[(size_t)(off + i) * stride];
-    permute(s);
+    const int next = n - (off + RATE);  // inputs still to absorb after this permutation
+    permute_rows(s, next <= 0 ? ROWS_DIGEST : (next >= RATE ? ROWS_CAPACITY : ROWS_ALL));
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) out[i] = s[i];
