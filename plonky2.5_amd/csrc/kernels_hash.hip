@@ -95,12 +95,16 @@ __global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__
   s = coop::poseidon_permute(s, threadIdx.x & 63, rc_lds);
   if (valid && rr < 4) parents[4 * g + rr] = s;
 }
-// Levels with at most this many parents use the cooperative kernel.  4096 when many proofs are in flight
-// (the per-lane form costs 25 % fewer instructions); a lone proof prefers 32768: at that size the per-lane
+// Levels with at most this many parents use the cooperative kernel.  512 when many proofs are in flight
+// (the per-lane form costs several times fewer instructions and other streams hide its latency; measured
+// 4096 / 512 / 0: 122.3 / 123.0 / 122.8 proofs/s); a lone proof prefers 32768: at that size the per-lane
 // form leaves most SIMDs with one wave or none, and the level takes a full permutation latency.
-static size_t g_coop_max_parents = 4096;
-void set_merkle_latency_mode(bool single_proof) { g_coop_max_parents = single_proof ? 32768 : 4096; }
-bool merkle_latency_mode() { return g_coop_max_parents > 4096; }
+constexpr size_t COOP_PARENTS_BATCH = 512, COOP_PARENTS_SINGLE = 32768;
+static size_t g_coop_max_parents = COOP_PARENTS_BATCH;
+void set_merkle_latency_mode(bool single_proof) {
+  g_coop_max_parents = single_proof ? COOP_PARENTS_SINGLE : COOP_PARENTS_BATCH;
+}
+bool merkle_latency_mode() { return g_coop_max_parents == COOP_PARENTS_SINGLE; }
 
 static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st) {
   if (m <= g_coop_max_parents) {
