@@ -299,7 +299,7 @@ class Circuit:
 
     @classmethod
     def build_gadget(cls, kind, param=0):
-        """kind: 0 and, 1 xor, 2 lsh, 3 rsh, 4 reverse_bits_len, 5 compress, 6 exp (include/p25.h)."""
+        """kind: 0 and, 1 xor, 2 lsh, 3 rsh, 4 reverse_bits_len, 5 compress, 6 exp, 7 hash_iter_slices (include/p25.h)."""
         h = vp()
         _check(lib().p25_circuit_build_gadget(kind, param, C.byref(h)))
         return cls(h.value)

@@ -790,6 +790,17 @@ Circuit build_gadget_circuit(int kind, int param) {
       cb.connect(x, expected);
       break;
     }
+    case GADGET_HASH_SLICES: {  // MerkleTreeMmcs::hash_iter_slices (commit.rs:23-46; test_hash_iter_slice :143-171)
+      if (param < 1 || param > 16) throw std::invalid_argument("hash_iter_slices gadget: 1..16 slices of 4 words");
+      std::vector<std::vector<Target>> slices(param, std::vector<Target>(4));
+      for (auto& sl : slices)
+        for (auto& t : sl) t = in();
+      std::vector<const std::vector<Target>*> ptrs;
+      for (auto& sl : slices) ptrs.push_back(&sl);
+      auto out = hash_iter_slices(cb, ptrs);
+      for (int i = 0; i < 4; i++) cb.connect(out[i], in());
+      break;
+    }
     default:
       throw std::invalid_argument("unknown gadget kind");
   }

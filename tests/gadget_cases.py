@@ -36,4 +36,14 @@ def cases(oracle=None):
         r = [r64() for _ in range(4)]
         st = oracle.poseidon2_permute(np.array(l + r + [0] * 4, dtype=np.uint64))[0]
         out.append(("compress", 5, 0, l + r + [int(v) for v in st[:4]]))
+        # hash_iter_slices: Poseidon2 overwrite-mode sponge, RATE = 4 (src/p3/constants.rs:3), over the
+        # concatenated slices
+        for n_slices in (2, 3, 5):   # 2 = the reference's test_hash_iter_slice shape
+            words = [r64() for _ in range(4 * n_slices)]
+            state = np.zeros(12, dtype=np.uint64)
+            for off in range(0, len(words), 4):
+                chunk = words[off:off + 4]
+                state[:len(chunk)] = chunk
+                state = oracle.poseidon2_permute(state)[0].copy()
+            out.append((f"hash_slices{n_slices}", 7, n_slices, words + [int(v) for v in state[:4]]))
     return out
