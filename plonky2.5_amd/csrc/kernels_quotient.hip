@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include "kernels.h"
 #include "poseidon2.h"
+#include "coop.h"
 #include "prover_kernels.h"
 
 namespace p25 {
@@ -89,12 +90,21 @@ __device__ void gate_public_input(Ctx& cx) {
   for (int i = 0; i < 4; i++) cx.at(i, cx.w(i));
 }
 __device__ void gate_base_sum(Ctx& cx) {
-  u64 sum = 0, pw = 1;
-  for (int i = 0; i < BASE_SUM_LIMBS; i++) {
-    u64 l = cx.w(1 + i);
-    sum = gl::add(sum, gl::mul(l, pw));
-    pw = gl::add(pw, pw);
-    cx.at(1 + i, gl::mul_nc(l, gl::sub(l, 1)));  // at() takes any representative
+  // sum_i limb_i 2^i, i < 63: carry-free groups of eight limbs (cf. SmallLin below), most significant group
+  // first, joined by sum = sum * 2^8 + group
+  u64 sum = 0;
+  for (int q = (BASE_SUM_LIMBS + 7) / 8 - 1; q >= 0; q--) {
+    u64 al = 0, ah = 0, dm;
+    const int n = BASE_SUM_LIMBS - 8 * q < 8 ? BASE_SUM_LIMBS - 8 * q : 8;
+    for (int t = 0; t < n; t++) {
+      const int i = 8 * q + t;
+      u64 l = cx.w(1 + i);
+      const u32 c = 1u << t;
+      asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(al), "=s"(dm) : "v"((u32)l), "s"(c));
+      asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(ah), "=s"(dm) : "v"((u32)(l >> 32)), "s"(c));
+      cx.at(1 + i, gl::mul_nc(l, gl::sub(l, 1)));
+    }
+    sum = gl::mad_nc(sum, (u64)1 << 8, coop::reduce_row(al, ah));
   }
   cx.at(0, gl::sub(sum, cx.w(0)));
 }
@@ -126,6 +136,25 @@ __device__ void gate_exponentiation(Ctx& cx) {
   }
   cx.at(EXP_POWER_BITS, gl::sub(cx.w(1 + EXP_POWER_BITS), prev_inter));
 }
+// sum_i v_i * c_i for small constants c_i (wave-uniform, < 2^15) and 64-bit field values v_i: two carry-free
+// multiply-adds per term on the 32-bit halves, one 5-instruction reduction at the end -- instead of the
+// Horner chains x = 2x + b (two modular additions, 12 instructions, per step).  At most 16 terms per group:
+// products < 2^47, sums < 2^51.
+struct SmallLin {
+  u64 al = 0, ah = 0;
+  __device__ __forceinline__ void add(u64 v, u32 c_uniform) {
+    u64 dm;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(al), "=s"(dm) : "v"((u32)v), "s"(c_uniform));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(ah), "=s"(dm) : "v"((u32)(v >> 32)), "s"(c_uniform));
+  }
+  __device__ __forceinline__ u64 value() const { return coop::reduce_row(al, ah); }  // any u64 representative
+};
+// ((g[0] * 2^s + g[1]) * 2^s + g[2]) * 2^s + g[3]
+__device__ __forceinline__ u64 join4(const u64 g[4], u32 shift) {
+  const u64 m = (u64)1 << shift;
+  return gl::mad_nc(gl::mad_nc(gl::mad_nc(g[0], m, g[1]), m, g[2]), m, g[3]);
+}
+
 __device__ void gate_u32_arithmetic(Ctx& cx) {
   for (int i = 0; i < 3; i++) {
     const int cb = 36 * i;
@@ -137,19 +166,21 @@ __device__ void gate_u32_arithmetic(Ctx& cx) {
     cx.at(cb, gl::mul_nc(hi_not_max, lo));
     u64 combined = gl::add(gl::mul(hi, (u64)1 << 32), lo);
     cx.at(cb + 1, gl::sub(combined, computed));
-    u64 cl = 0, ch = 0;
-    for (int j = 31; j >= 0; j--) {
-      u64 l = cx.w(18 + 32 * i + j);
-      u64 pr = gl::mul_nc(gl::mul_nc(l, gl::sub(l, 1)), gl::mul_nc(gl::sub(l, 2), gl::sub(l, 3)));
-      cx.at(cb + 2 + (31 - j), pr);
-      if (j < 16) {
-        cl = gl::add(gl::add(cl, cl), gl::add(cl, cl));
-        cl = gl::add(cl, l);
-      } else {
-        ch = gl::add(gl::add(ch, ch), gl::add(ch, ch));
-        ch = gl::add(ch, l);
+    // 32 base-4 limbs, most significant first: limbs 31..16 make the high word, 15..0 the low word
+    u64 part[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // limbs 31-8q .. 24-8q
+      SmallLin acc;
+      for (int t = 0; t < 8; t++) {
+        const int j = 31 - 8 * q - t;
+        u64 l = cx.w(18 + 32 * i + j);
+        u64 pr = gl::mul_nc(gl::mul_nc(l, gl::sub(l, 1)), gl::mul_nc(gl::sub(l, 2), gl::sub(l, 3)));
+        cx.at(cb + 2 + (31 - j), pr);
+        acc.add(l, 1u << (2 * (7 - t)));
       }
+      part[q] = acc.value();
     }
+    const u64 ch = gl::mad_nc(part[0], (u64)1 << 16, part[1]), cl = gl::mad_nc(part[2], (u64)1 << 16, part[3]);
     cx.at(cb + 34, gl::sub(cl, lo));
     cx.at(cb + 35, gl::sub(ch, hi));
   }
@@ -157,34 +188,48 @@ __device__ void gate_u32_arithmetic(Ctx& cx) {
 __device__ void gate_u32_interleave(Ctx& cx) {
   for (int i = 0; i < 3; i++) {
     const int cb = 34 * i;
-    u64 x = 0, xi = 0;
-    for (int b = 0; b < 32; b++) {
-      u64 bit = cx.w(6 + 32 * i + b);
-      x = gl::add(gl::add(x, x), bit);
-      u64 x2 = gl::add(xi, xi);
-      xi = gl::add(gl::add(x2, x2), bit);
-      cx.at(cb + 2 + b, gl::mul_nc(bit, gl::sub(bit, 1)));
+    u64 xq[4], xiq[4];  // bits 8q .. 8q+7, most significant first
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      SmallLin ax, axi;
+      for (int t = 0; t < 8; t++) {
+        const int b = 8 * q + t;
+        u64 bit = cx.w(6 + 32 * i + b);
+        ax.add(bit, 1u << (7 - t));
+        axi.add(bit, 1u << (2 * (7 - t)));
+        cx.at(cb + 2 + b, gl::mul_nc(bit, gl::sub(bit, 1)));
+      }
+      xq[q] = ax.value();
+      xiq[q] = axi.value();
     }
-    cx.at(cb, gl::sub(x, cx.w(2 * i)));
-    cx.at(cb + 1, gl::sub(xi, cx.w(2 * i + 1)));
+    cx.at(cb, gl::sub(join4(xq, 8), cx.w(2 * i)));
+    cx.at(cb + 1, gl::sub(join4(xiq, 16), cx.w(2 * i + 1)));
   }
 }
 __device__ void gate_u32_uninterleave(Ctx& cx) {
   for (int i = 0; i < 2; i++) {
     const int cb = 67 * i;
-    u64 x = 0, ev = 0, od = 0;
-    for (int j = 0; j < 32; j++) {
-      u64 be = cx.w(6 + 64 * i + 2 * j), bo = cx.w(6 + 64 * i + 2 * j + 1);
-      u64 x2 = gl::add(x, x);
-      x = gl::add(gl::add(gl::add(x2, x2), gl::add(be, be)), bo);
-      ev = gl::add(gl::add(ev, ev), be);
-      od = gl::add(gl::add(od, od), bo);
-      cx.at(cb + 3 + 2 * j, gl::mul_nc(be, gl::sub(be, 1)));
-      cx.at(cb + 3 + 2 * j + 1, gl::mul_nc(bo, gl::sub(bo, 1)));
+    u64 xq[4], evq[4], odq[4];  // bit pairs 8q .. 8q+7, most significant first
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      SmallLin ax, aev, aod;
+      for (int t = 0; t < 8; t++) {
+        const int j = 8 * q + t;
+        u64 be = cx.w(6 + 64 * i + 2 * j), bo = cx.w(6 + 64 * i + 2 * j + 1);
+        ax.add(be, 2u << (2 * (7 - t)));
+        ax.add(bo, 1u << (2 * (7 - t)));
+        aev.add(be, 1u << (7 - t));
+        aod.add(bo, 1u << (7 - t));
+        cx.at(cb + 3 + 2 * j, gl::mul_nc(be, gl::sub(be, 1)));
+        cx.at(cb + 3 + 2 * j + 1, gl::mul_nc(bo, gl::sub(bo, 1)));
+      }
+      xq[q] = ax.value();
+      evq[q] = aev.value();
+      odq[q] = aod.value();
     }
-    cx.at(cb, gl::sub(x, cx.w(3 * i)));
-    cx.at(cb + 1, gl::sub(ev, cx.w(3 * i + 1)));
-    cx.at(cb + 2, gl::sub(od, cx.w(3 * i + 2)));
+    cx.at(cb, gl::sub(join4(xq, 16), cx.w(3 * i)));
+    cx.at(cb + 1, gl::sub(join4(evq, 8), cx.w(3 * i + 1)));
+    cx.at(cb + 2, gl::sub(join4(odq, 8), cx.w(3 * i + 2)));
   }
 }
 // poseidon2_gate.rs:233-310
