@@ -127,11 +127,11 @@ __device__ void gate_exponentiation(Ctx& cx) {
   const u64 base = cx.w(0);
   u64 prev_inter = 1;
   for (int i = 0; i < EXP_POWER_BITS; i++) {
-    u64 prev = i == 0 ? 1 : gl::mul(prev_inter, prev_inter);
+    u64 prev = i == 0 ? 1 : gl::mul_nc(prev_inter, prev_inter);  // intermediate values may stay non-canonical
     u64 bit = cx.w(1 + (EXP_POWER_BITS - 1 - i));
-    u64 sel = gl::add(gl::mul(bit, base), gl::sub(1, bit));
+    u64 sel = gl::mad_nc(bit, base, gl::sub(1, bit));              // bit * base + (1 - bit)
     u64 inter = cx.w(2 + EXP_POWER_BITS + i);
-    cx.at(i, gl::sub(gl::mul(prev, sel), inter));
+    cx.at(i, gl::sub(gl::mul_nc(prev, sel), inter));
     prev_inter = inter;
   }
   cx.at(EXP_POWER_BITS, gl::sub(cx.w(1 + EXP_POWER_BITS), prev_inter));
