@@ -243,15 +243,24 @@ __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __rest
 }
 
 // vals[slot 0] = 0; vals[input_slots[i]] = inputs[p][i]
+// A non-canonical input word (>= p) is reduced and the proof flagged P25_ERR_INVALID_ARG: the host-buffer
+// entry point rejects such inputs up front, the device-resident one can only find out here.
 __global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, const uint32_t* __restrict__ input_slots,
-                                    uint32_t n_inputs, u64* __restrict__ vals, size_t B, uint32_t n_proofs) {
+                                    uint32_t n_inputs, u64* __restrict__ vals, size_t B, uint32_t n_proofs,
+                                    uint32_t* __restrict__ status) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)(n_inputs + 1) * n_proofs) return;
   uint32_t i = (uint32_t)(idx / n_proofs), p = (uint32_t)(idx % n_proofs);
-  if (i == n_inputs)
+  if (i == n_inputs) {
     vals[p] = 0;
-  else
-    vals[(size_t)input_slots[i] * B + p] = inputs[(size_t)p * n_inputs + i];
+  } else {
+    u64 v = inputs[(size_t)p * n_inputs + i];
+    if (v >= gl::P) {
+      v -= gl::P;
+      status[p] = 1;  // P25_ERR_INVALID_ARG
+    }
+    vals[(size_t)input_slots[i] * B + p] = v;
+  }
 }
 
 // wires[col][row] (column-major, natural row order) for one proof of the batch
@@ -267,7 +276,7 @@ void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u6
                    size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st) {
   size_t tot = (size_t)(wp.n_inputs + 1) * n_proofs;
   hipLaunchKernelGGL(k_witgen_set_inputs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_inputs,
-                     wp.d_input_slots, wp.n_inputs, d_vals, B, n_proofs);
+                     wp.d_input_slots, wp.n_inputs, d_vals, B, n_proofs, d_status);
   for (size_t l = 0; l + 1 < wp.level_start.size(); l++) {
     uint32_t b = wp.level_start[l], cnt = wp.level_start[l + 1] - b;
     if (!cnt) continue;

@@ -64,3 +64,20 @@ def test_non_canonical_input_rejected(gpu, fib_circuit, fib_inputs, p25):
     with pytest.raises(p25.P25Error) as e:
         fib_circuit.prove(bad)
     assert e.value.status == 1
+
+
+def test_non_canonical_device_resident_input_flagged(gpu, fib_circuit, fib_inputs):
+    """p25_prove_batch_dev cannot validate HBM-resident inputs on the host: the input kernel flags them."""
+    import torch
+    bad = fib_inputs.copy()
+    bad[3] = np.uint64(P)                       # == 0 mod p, but not canonical
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(np.stack([fib_inputs, bad]).view(np.int64)).to(dev)
+    pw = int(fib_circuit.info.proof_words)
+    d_seeds = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_proofs = torch.zeros((2, pw), dtype=torch.int64, device=dev)
+    d_status = torch.full((2,), 99, dtype=torch.int32, device=dev)
+    fib_circuit.prove_dev(d_in.data_ptr(), 2, d_seeds.data_ptr(), d_proofs.data_ptr(), pw, d_status.data_ptr())
+    fib_circuit.sync()
+    assert d_status.cpu().tolist()[0] == 0
+    assert d_status.cpu().tolist()[1] != 0
