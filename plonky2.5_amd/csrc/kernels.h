@@ -30,12 +30,11 @@ size_t merkle_tree_words(size_t n_leaves, unsigned cap_height);
 size_t merkle_level_offset(size_t n_leaves, unsigned level);
 // ev_begin/ev_end (optional) bracket the leaf-sponge kernel -- the dominant kernel of the prover --
 // so bench.py can report its measured duration (roofline line).
-// single_proof: only one proof is in flight (latency matters more than instruction count)
-void set_merkle_latency_mode(bool single_proof);
-bool merkle_latency_mode();
+// single_proof: only one proof is in flight (latency matters more than instruction count): cooperative
+// kernels for larger levels.
 u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t n_leaves,
                         unsigned cap_height, u64* d_tree, hipStream_t st, hipEvent_t ev_begin = nullptr,
-                        hipEvent_t ev_end = nullptr);
+                        hipEvent_t ev_end = nullptr, bool single_proof = false);
 
 // ---------------- NTT (kernels_ntt.hip) ----------------
 // One pass of a two-pass (four-step) NTT: a block transforms a tile of 2^log_t independent

@@ -311,9 +311,9 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64* __restric
   if (valid && rr < 4) digests[4 * g + rr] = s;
 }
 void launch_fri_leaf_hash(const u64* va, const u64* vb, uint32_t n_leaves, uint32_t arity_bits, u64* d_digests,
-                          hipStream_t st) {
+                          hipStream_t st, bool single_proof) {
   // cooperative form only when a lone proof is in flight: it costs 4x the instructions of the per-lane form
-  if ((2u << arity_bits) <= 4 || !merkle_latency_mode()) {
+  if ((2u << arity_bits) <= 4 || !single_proof) {
     hipLaunchKernelGGL(k_fri_leaf_hash, dim3((n_leaves + 255) / 256), dim3(256), 0, st, va, vb, n_leaves, arity_bits, d_digests);
     return;
   }

@@ -100,14 +100,9 @@ __global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__
 // 4096 / 512 / 0: 122.3 / 123.0 / 122.8 proofs/s); a lone proof prefers 32768: at that size the per-lane
 // form leaves most SIMDs with one wave or none, and the level takes a full permutation latency.
 constexpr size_t COOP_PARENTS_BATCH = 512, COOP_PARENTS_SINGLE = 32768;
-static size_t g_coop_max_parents = COOP_PARENTS_BATCH;
-void set_merkle_latency_mode(bool single_proof) {
-  g_coop_max_parents = single_proof ? COOP_PARENTS_SINGLE : COOP_PARENTS_BATCH;
-}
-bool merkle_latency_mode() { return g_coop_max_parents == COOP_PARENTS_SINGLE; }
 
-static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st) {
-  if (m <= g_coop_max_parents) {
+static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st, bool single_proof) {
+  if (m <= (single_proof ? COOP_PARENTS_SINGLE : COOP_PARENTS_BATCH)) {
     size_t th = m * coop::GROUP;
     hipLaunchKernelGGL(k_tree_level_coop, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, cur, nxt, m);
   } else {
@@ -146,7 +141,7 @@ size_t merkle_level_offset(size_t n_leaves, unsigned level) {
 // Builds every level up to the cap in `tree` (layout: merkle_level_offset).  Returns pointer to cap.
 u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t n_leaves,
                         unsigned cap_height, u64* d_tree, hipStream_t st, hipEvent_t ev_begin,
-                        hipEvent_t ev_end) {
+                        hipEvent_t ev_end, bool single_proof) {
   if (ev_begin) (void)hipEventRecord(ev_begin, st);
   if (width >= 128)
     hipLaunchKernelGGL(k_hash_leaves_wide, dim3((unsigned)((n_leaves + 63) / 64)), dim3(64), 0, st, d_cols,
@@ -160,20 +155,20 @@ u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t 
   while (m > ((size_t)1 << cap_height)) {
     u64* nxt = cur + 4 * m;
     m >>= 1;
-    launch_level(cur, nxt, m, st);
+    launch_level(cur, nxt, m, st, single_proof);
     cur = nxt;
   }
   return cur;
 }
 
 // Same as launch_merkle_tree but the leaf digests (level 0) are already in d_tree.
-void launch_tree_from_digests(u64* d_tree, size_t n_leaves, unsigned cap_height, hipStream_t st) {
+void launch_tree_from_digests(u64* d_tree, size_t n_leaves, unsigned cap_height, hipStream_t st, bool single_proof) {
   u64* cur = d_tree;
   size_t m = n_leaves;
   while (m > ((size_t)1 << cap_height)) {
     u64* nxt = cur + 4 * m;
     m >>= 1;
-    launch_level(cur, nxt, m, st);
+    launch_level(cur, nxt, m, st, single_proof);
     cur = nxt;
   }
 }

@@ -87,6 +87,7 @@ class DeviceCircuit {
   hipStream_t stream_ = nullptr;
   std::vector<std::unique_ptr<Ctx>> ctxs_;   // proofs in flight: one working set + HIP stream each
   hipEvent_t ev_witness_ = nullptr;
+  bool single_proof_ = false;  // set per prove call: one proof in flight -> latency-oriented kernel forms
   DevMem vals_;
   size_t vals_batch_ = 0;
   std::vector<DevMem> owned_;

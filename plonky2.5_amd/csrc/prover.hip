@@ -353,7 +353,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
       }
       kstats_pending_.push_back({e0, e1});
     }
-    launch_merkle_tree(x.wires_lde.p, B, W, B, cap_h, x.wires_tree.p, st, e0, e1);
+    launch_merkle_tree(x.wires_lde.p, B, W, B, cap_h, x.wires_tree.p, st, e0, e1, single_proof_);
   }
   const u64* wires_cap = x.wires_tree.p + tw - capw;
   d2d(d_proof + L.wires_cap, wires_cap, capw);
@@ -382,7 +382,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   // "commit to partial products, Z's"
   ntt_inverse(tables_, x.zs_vals.p, n, false, x.tmp.p, n, x.zs_coeffs.p, n, db, nz, 1, st);
   ntt_lde_bitrev(tables_, x.zs_coeffs.p, n, x.zs_lde.p, B, db, rb, nz, gl::GENERATOR, st);
-  launch_merkle_tree(x.zs_lde.p, B, nz, B, cap_h, x.zs_tree.p, st);
+  launch_merkle_tree(x.zs_lde.p, B, nz, B, cap_h, x.zs_tree.p, st, nullptr, nullptr, single_proof_);
   const u64* zs_cap = x.zs_tree.p + tw - capw;
   d2d(d_proof + L.zs_cap, zs_cap, capw);
   launch_transcript(tr, 0, zs_cap, (uint32_t)capw, chal + CH_ALPHAS, NC, st);
@@ -403,7 +403,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   mark();  // 5
   // "split up quotient polys" (chunks of n are contiguous: [NC][8][n] == [16][n]) + "commit to quotient polys"
   ntt_lde_bitrev(tables_, x.q_coeffs.p, n, x.q_lde.p, B, db, rb, nq, gl::GENERATOR, st);
-  launch_merkle_tree(x.q_lde.p, B, nq, B, cap_h, x.q_tree.p, st);
+  launch_merkle_tree(x.q_lde.p, B, nq, B, cap_h, x.q_tree.p, st, nullptr, nullptr, single_proof_);
   const u64* q_cap = x.q_tree.p + tw - capw;
   d2d(d_proof + L.quotient_cap, q_cap, capw);
   launch_transcript(tr, 0, q_cap, (uint32_t)capw, chal + CH_ZETA, 2, st);
@@ -454,8 +454,8 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
       // values of the current polynomial on shift*<w>, bit-reversed positions, components a | b
       ntt_lde_bitrev(tables_, x.fri_coeffs[l].p, m, x.fri_vals[l].p, vals, log_m, rb, 2, shift, st);
       const size_t n_leaves = vals >> ab;
-      launch_fri_leaf_hash(x.fri_vals[l].p, x.fri_vals[l].p + vals, (uint32_t)n_leaves, ab, x.fri_tree[l].p, st);
-      launch_tree_from_digests(x.fri_tree[l].p, n_leaves, cap_h, st);
+      launch_fri_leaf_hash(x.fri_vals[l].p, x.fri_vals[l].p + vals, (uint32_t)n_leaves, ab, x.fri_tree[l].p, st, single_proof_);
+      launch_tree_from_digests(x.fri_tree[l].p, n_leaves, cap_h, st, single_proof_);
       const size_t ltw = merkle_tree_words(n_leaves, cap_h);
       const u64* cap = x.fri_tree[l].p + ltw - capw;
       d2d(d_proof + L.fri_caps + l * capw, cap, capw);
@@ -549,7 +549,7 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
     }
   }
   ensure_ctx(K);
-  set_merkle_latency_mode(K == 1);
+  single_proof_ = K == 1;  // a lone proof in flight: latency-oriented kernel forms
   const size_t MAXB = 64;
   for (size_t base = 0; base < n_proofs; base += MAXB) {
     size_t bsz = n_proofs - base < MAXB ? n_proofs - base : MAXB;

@@ -103,8 +103,9 @@ void launch_fri_fold(const u64* ca, const u64* cb, uint32_t len_out, uint32_t ar
                      u64* oa, u64* ob, hipStream_t st);
 // leaves: 2^arity_bits consecutive extension values (bit-reversed order), flattened (a, b)
 void launch_fri_leaf_hash(const u64* va, const u64* vb, uint32_t n_leaves, uint32_t arity_bits, u64* d_digests,
-                          hipStream_t st);
-void launch_tree_from_digests(u64* d_tree, size_t n_leaves, unsigned cap_height, hipStream_t st);
+                          hipStream_t st, bool single_proof = false);
+void launch_tree_from_digests(u64* d_tree, size_t n_leaves, unsigned cap_height, hipStream_t st,
+                              bool single_proof = false);
 
 // query phase: writes initial-tree openings and FRI steps into the flat proof
 struct QueryArgs {
