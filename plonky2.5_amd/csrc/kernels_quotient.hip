@@ -18,6 +18,7 @@
 // folded sums once:   sum_j alpha^j sum_g f_g c_{g,j} = sum_g f_g sum_j alpha^j c_{g,j}.
 #include <stdexcept>
 #include <stdlib.h>
+#include "builder.h"
 #include "kernels.h"
 #include "poseidon2.h"
 #include "coop.h"
@@ -439,6 +440,10 @@ void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   }();
   a.debug_gate_mask = mask;
   if (a.num_routed > (uint32_t)MAX_ROUTED) throw std::runtime_error("quotient: more than MAX_ROUTED routed wires");
+  for (uint32_t gi = 0; gi < a.n_gates; gi++)  // the carry-free alpha fold holds 512 terms per gate
+    if (gate_info((GateKind)a.gates[gi].kind).num_constraints > MAX_TERMS_PER_FOLD ||
+        gate_info((GateKind)a.gates[gi].kind).num_constraints > ALPHA_POWS)
+      throw std::runtime_error("quotient: gate with too many constraints for the alpha-power table");
   const size_t big = (size_t)1 << (a.degree_bits + a.rate_bits);
   hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
 }
