@@ -5,8 +5,13 @@
 #include "ref_hash.h"
 #include "ref_gates.h"
 #include "ref_prover.h"
+#include <atomic>
+#include <chrono>
 #include <memory>
+#include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
+#include <thread>
 
 extern "C" {
 
@@ -176,6 +181,56 @@ int p25o_prove(void* h, const u64* inputs, u64 seed, u64* proof_out, double* tim
   }
   return 0;
 }
+// CPU-baseline leg "one proof per core": n_proofs independent proofs on n_threads host threads, each
+// proof single-threaded (as the reference build: Cargo.toml:15-18 has no `parallel` feature) and each
+// thread pinned to its own CPU of the process's affinity set.  inputs[n_proofs][num_inputs],
+// proofs_out[n_proofs][proof_words] (nullable), statuses[n_proofs], per_proof_s[n_proofs] (nullable:
+// wall seconds of each proof).  Returns wall seconds of the whole run.
+double p25o_prove_many(void* h, const u64* inputs, const u64* seeds, size_t n_proofs, int n_threads,
+                       u64* proofs_out, int* statuses, double* per_proof_s) {
+  auto* oc = (OracleCircuit*)h;
+  p25o_precompute(h);
+  const size_t ni = oc->c.num_inputs, pw = ref_proof_words(oc->c);
+  if (n_threads < 1) n_threads = 1;
+  std::vector<int> cpus;
+  {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0)
+      for (int i = 0; i < CPU_SETSIZE; i++)
+        if (CPU_ISSET(i, &set)) cpus.push_back(i);
+  }
+  std::atomic<size_t> next{0};
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++)
+    th.emplace_back([&, t] {
+      if (!cpus.empty()) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(cpus[t % cpus.size()], &one);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+      }
+      ref_set_thread_local_threads(1);
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= n_proofs) break;
+        auto a = std::chrono::steady_clock::now();
+        RProof pr;
+        std::string m;
+        int st = ref_prove(oc->c, *oc->pre, inputs + i * ni, seeds ? seeds[i] : (u64)i, pr, nullptr, &m);
+        statuses[i] = st;
+        if (!st && proofs_out) {
+          std::vector<u64> flat = ref_proof_flatten(oc->c, pr);
+          memcpy(proofs_out + i * pw, flat.data(), pw * 8);
+        }
+        if (per_proof_s) per_proof_s[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+      }
+    });
+  for (auto& x : th) x.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // digest4 / cs_cap: the verifier-side circuit data (VerifierOnlyCircuitData); pass the oracle's own
 // (p25o_circuit_digest) or the product's to cross-check.
 int p25o_verify(void* h, const u64* digest4, const u64* cs_cap, const u64* proof_words, char* msg, size_t msglen) {

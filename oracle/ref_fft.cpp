@@ -8,23 +8,57 @@ static unsigned log2_exact(size_t n) {
   return l;
 }
 
+// Twiddles in per-stage contiguous layout, tw[len + j] = root_{2 len}^j (j < len), cached per root so
+// the timed CPU baseline does not rebuild them (or stride through one big table) on every transform.
+#include <map>
+#include <memory>
+#include <mutex>
+static const std::vector<u64>& stage_twiddles(size_t n, u64 root) {
+  static std::mutex m;
+  static std::map<std::pair<size_t, u64>, std::unique_ptr<std::vector<u64>>> cache;
+  std::lock_guard<std::mutex> lk(m);
+  auto& slot = cache[{n, root}];
+  if (!slot) {
+    slot.reset(new std::vector<u64>(n < 2 ? 2 : n));
+    std::vector<u64>& tw = *slot;
+    // top stage: len = n/2, root itself; lower stages take every other entry
+    for (size_t len = n / 2; len >= 1; len >>= 1) {
+      if (len == n / 2) {
+        u64 w = 1;
+        for (size_t j = 0; j < len; j++) {
+          tw[len + j] = w;
+          w = rf_mul(w, root);
+        }
+      } else {
+        for (size_t j = 0; j < len; j++) tw[len + j] = tw[2 * len + 2 * j];
+      }
+    }
+  }
+  return *slot;
+}
+
 static void fft_core(std::vector<u64>& a, u64 root) {
   const size_t n = a.size();
+  if (n < 2) return;
   const unsigned lg = log2_exact(n);
   for (size_t i = 0; i < n; i++) {
     size_t j = rbits(i, lg);
     if (i < j) std::swap(a[i], a[j]);
   }
-  std::vector<u64> tw(n / 2 ? n / 2 : 1);
-  tw[0] = 1;
-  for (size_t i = 1; i < n / 2; i++) tw[i] = rf_mul(tw[i - 1], root);
-  for (size_t len = 1; len < n; len <<= 1) {
-    size_t step = n / (2 * len);
+  const std::vector<u64>& tw = stage_twiddles(n, root);
+  u64* d = a.data();
+  for (size_t s = 0; s < n; s += 2) {  // len = 1: twiddle 1
+    u64 u = d[s], v = d[s + 1];
+    d[s] = rf_add(u, v);
+    d[s + 1] = rf_sub(u, v);
+  }
+  for (size_t len = 2; len < n; len <<= 1) {
+    const u64* w = tw.data() + len;
     for (size_t s = 0; s < n; s += 2 * len)
       for (size_t j = 0; j < len; j++) {
-        u64 u = a[s + j], v = rf_mul(a[s + j + len], tw[j * step]);
-        a[s + j] = rf_add(u, v);
-        a[s + j + len] = rf_sub(u, v);
+        u64 u = d[s + j], v = rf_mul(d[s + j + len], w[j]);
+        d[s + j] = rf_add(u, v);
+        d[s + j + len] = rf_sub(u, v);
       }
   }
 }

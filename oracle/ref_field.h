@@ -24,10 +24,12 @@ static inline u64 rf_reduce(u128 x) {
   u64 x0 = (u64)x;
   u64 x1 = (u64)(x >> 64) & 0xFFFFFFFFULL;
   u64 x2 = (u64)(x >> 96);
-  u64 t0, r;
-  if (__builtin_sub_overflow(x0, x2, &t0)) t0 -= 0xFFFFFFFFULL;   // borrowed 2^64 = 2^32 - 1 (mod p)
-  u64 t1 = x1 * 0xFFFFFFFFULL;
-  if (__builtin_add_overflow(t0, t1, &r)) r += 0xFFFFFFFFULL;     // carried 2^64
+  // branch-free: the borrow/carry conditions are data-dependent coin flips, so masks beat jumps
+  u64 t0 = x0 - x2;
+  t0 -= (0 - (u64)(x0 < x2)) & 0xFFFFFFFFULL;   // borrowed 2^64 = 2^32 - 1 (mod p)
+  u64 t1 = (x1 << 32) - x1;                      // x1 * (2^32 - 1)
+  u64 r = t0 + t1;
+  r += (0 - (u64)(r < t1)) & 0xFFFFFFFFULL;     // carried 2^64
   return r >= RP ? r - RP : r;
 }
 static inline u64 rf_add(u64 a, u64 b) {
@@ -83,7 +85,11 @@ static inline RE2 re_exp_pow2(RE2 b, unsigned k) {
   return b;
 }
 static inline size_t rbits(size_t x, unsigned bits) {
-  size_t r = 0;
-  for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
-  return r;
+  if (!bits) return 0;
+  u64 v = x;
+  v = ((v >> 1) & 0x5555555555555555ULL) | ((v & 0x5555555555555555ULL) << 1);
+  v = ((v >> 2) & 0x3333333333333333ULL) | ((v & 0x3333333333333333ULL) << 2);
+  v = ((v >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((v & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  v = __builtin_bswap64(v);
+  return (size_t)(v >> (64 - bits));
 }

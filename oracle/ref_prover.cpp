@@ -7,23 +7,121 @@
 #include "ref_fft.h"
 #include "ref_gates.h"
 
+// Threading model of the CPU baseline: a persistent worker pool (no thread creation per loop) and a
+// per-calling-thread width, so that N independent proofs can run on N cores, one thread each
+// (ref_set_thread_local_threads(1) in every proving thread), or one proof can be spread over T cores.
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 static int g_threads = 1;
+static thread_local int tl_threads = 0;       // 0 = use the process-wide setting
+static thread_local bool tl_in_worker = false;
 void ref_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void ref_set_thread_local_threads(int n) { tl_threads = n < 0 ? 0 : n; }
+
+namespace {
+struct Job {
+  const std::function<void(size_t, size_t)>* f;
+  size_t n, chunk;
+  std::atomic<size_t> next{0};
+  std::atomic<size_t> done{0};
+  size_t total_chunks;
+  std::mutex m;
+  std::condition_variable cv;
+};
+class Pool {
+ public:
+  void run(int T, size_t n, const std::function<void(size_t, size_t)>& f) {
+    Job job;
+    job.f = &f;
+    job.n = n;
+    job.chunk = (n + T - 1) / T;
+    job.total_chunks = (n + job.chunk - 1) / job.chunk;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      while ((int)workers_.size() < T - 1) workers_.emplace_back([this] { worker(); });
+      for (int i = 0; i < T - 1; i++) q_.push_back(&job);
+    }
+    cv_.notify_all();
+    work(job);
+    std::unique_lock<std::mutex> lk(job.m);
+    job.cv.wait(lk, [&] { return job.done.load() == job.total_chunks; });
+    // drop queue entries that no worker picked up (all chunks were already taken)
+    lk.unlock();
+    {
+      std::lock_guard<std::mutex> lk2(m_);
+      for (auto it = q_.begin(); it != q_.end();) it = (*it == &job) ? q_.erase(it) : it + 1;
+    }
+    // a worker that popped the job but is still inside work()/notify must be waited for (job is on this stack)
+    for (;;) {
+      {
+        std::lock_guard<std::mutex> lk2(m_);
+        if (!job_refs(&job)) break;
+      }
+      std::this_thread::yield();
+    }
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<std::thread> workers_;
+  std::vector<Job*> q_;
+  std::vector<Job*> active_;
+  bool job_refs(Job* j) {
+    for (Job* a : active_)
+      if (a == j) return true;
+    return false;
+  }
+  static void work(Job& job) {
+    for (;;) {
+      size_t c = job.next.fetch_add(1);
+      if (c >= job.total_chunks) return;
+      size_t b = c * job.chunk, e = b + job.chunk < job.n ? b + job.chunk : job.n;
+      (*job.f)(b, e);
+      if (job.done.fetch_add(1) + 1 == job.total_chunks) {
+        std::lock_guard<std::mutex> lk(job.m);
+        job.cv.notify_all();
+      }
+    }
+  }
+  void worker() {
+    tl_in_worker = true;
+    for (;;) {
+      Job* j;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !q_.empty(); });
+        j = q_.back();
+        q_.pop_back();
+        active_.push_back(j);
+      }
+      work(*j);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        for (auto it = active_.begin(); it != active_.end(); ++it)
+          if (*it == j) {
+            active_.erase(it);
+            break;
+          }
+      }
+    }
+  }
+};
+Pool& pool() {
+  static Pool* p = new Pool();  // leaked on purpose: workers are detached-for-life daemon threads
+  return *p;
+}
+}  // namespace
 
 static void parallel_for(size_t n, const std::function<void(size_t, size_t)>& f) {
-  int T = g_threads;
-  if (T <= 1 || n < 2) {
+  int T = tl_threads ? tl_threads : g_threads;
+  if (T <= 1 || n < 2 || tl_in_worker) {
     f(0, n);
     return;
   }
-  std::vector<std::thread> th;
-  size_t chunk = (n + T - 1) / T;
-  for (int t = 0; t < T; t++) {
-    size_t b = t * chunk, e = b + chunk < n ? b + chunk : n;
-    if (b >= e) break;
-    th.emplace_back([=, &f] { f(b, e); });
-  }
-  for (auto& x : th) x.join();
+  if ((size_t)T > n) T = (int)n;
+  pool().run(T, n, f);
 }
 static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -13,7 +13,8 @@
 #include "ref_circuit.h"
 #include "ref_hash.h"
 
-void ref_set_threads(int n);
+void ref_set_threads(int n);               // process-wide width of parallel loops
+void ref_set_thread_local_threads(int n);  // override for the calling thread (0 = none)
 
 struct RPolyBatch {
   size_t n_polys = 0;

@@ -1,5 +1,10 @@
-"""Worker for tests/test_dist_gloo.py: world_size-2 gloo run of the sharding + gather path with a
-stand-in prover (the real one needs a GPU; the sharding / gather logic is identical)."""
+"""Worker for the world_size-2 tests of the N>1 path (block sharding of independent proofs + one gather).
+
+  python -m torch.distributed.run --nproc-per-node 2 tests/_dist_worker.py N          CPU, gloo: sharding and
+        gather logic with a stand-in for the prover (libp25 has no CPU path; tests/test_dist_gloo.py)
+  ... tests/_dist_worker.py N --real      GPU box: every rank runs the REAL prover on GPU 0 for its shard,
+        gloo carries the gather; rank 0 checks all N proofs with the oracle (tests/test_gpu_baseline_configs.py)
+"""
 import os
 import sys
 
@@ -17,11 +22,11 @@ def fake_prove(inputs, words):
     return (inputs[:, :1] * 1000 + torch.arange(words, dtype=torch.int64)[None, :])
 
 
-def main():
-    n_total, words = int(sys.argv[1]), 17
+def main_standin(n_total):
+    words = 17
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    pkg = ge.load_package()
+    ge.load_package()
     from plonky25_amd import dist as pd
     start, stop = pd.shard_range(n_total, rank, world)
     all_inputs = torch.arange(n_total, dtype=torch.int64)[:, None].repeat(1, 5)
@@ -45,5 +50,49 @@ def main():
     dist.destroy_process_group()
 
 
+def main_real(n_total):
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    p25 = ge.load_package()
+    from plonky25_amd import dist as pd
+    p25.device_init(0)                       # both ranks share the box's one GPU
+    with open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")) as f:
+        base, cfg = p25.p3_proof_from_json(f.read())
+    # the same global batch on every rank (deterministic), each rank proves its own block
+    variants = [base] + [p25.p3_prove_fibonacci(6, 100, 16, pow_start=v << 24)[0] for v in (1, 2)]
+    batch = np.stack([variants[i % 3] for i in range(n_total)])
+    bad = n_total - 1                        # the last proof of the last shard carries a corrupted inner proof
+    batch[bad, 9000] = (int(batch[bad, 9000]) + 1) % 0xFFFFFFFF00000001
+    seeds = np.arange(n_total, dtype=np.uint64) + np.uint64(1000)
+    circuit = p25.Circuit.build_p3_verifier(cfg)
+    start, stop = pd.shard_range(n_total, rank, world)
+    proofs, st = circuit.prove(batch[start:stop], seeds=seeds[start:stop])
+    gp, gs = pd.gather_proofs(torch.from_numpy(proofs.view(np.int64)), torch.from_numpy(st), n_total)
+    if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle_binding import Oracle
+        oc = Oracle().load_circuit(circuit.to_blob())
+        dg, cap = circuit.digest()
+        all_p = gp.numpy().view(np.uint64)
+        assert gs.tolist() == [0] * (n_total - 1) + [4], gs.tolist()
+        for i in range(n_total - 1):
+            code, msg = oc.verify(all_p[i], dg, cap)
+            assert code == 0, (i, msg)
+        # byte equality across the shard boundary: last proof of rank 0's block, first of rank 1's
+        s1 = pd.shard_range(n_total, 1, world)[0]
+        idx = [s1 - 1, s1]
+        po, sto, _per, _wall = oc.prove_many(batch[idx], seeds[idx], threads=2)
+        assert (sto == 0).all()
+        for k, i in enumerate(idx):
+            assert (all_p[i] == po[k]).all(), f"gathered proof {i} differs from the oracle's"
+        print("DIST_REAL_OK", n_total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    main()
+    n = int(sys.argv[1])
+    if "--real" in sys.argv:
+        main_real(n)
+    else:
+        main_standin(n)

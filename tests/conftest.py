@@ -31,148 +31,8 @@ def load_p25():
     return mod
 
 
-def _p(a):
-    return a.ctypes.data_as(C.c_void_p) if a is not None else None
-
-
-class OracleCircuit:
-    """A circuit blob loaded into the oracle: CPU witness generator, prover and verifier."""
-
-    def __init__(self, lib, blob):
-        self.lib = lib
-        self.h = C.c_void_p(lib.p25o_circuit_load(blob, len(blob)))
-        assert self.h.value, "oracle could not parse the circuit blob"
-        info = (C.c_uint64 * 8)()
-        lib.p25o_circuit_info(self.h, info)
-        self.degree_bits, self.num_wires, self.num_inputs, self.num_generators = map(int, info[:4])
-        self.proof_words = int(info[4])
-        self.n = 1 << self.degree_bits
-
-    def witness(self, inputs, seed=0):
-        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
-        wires = np.zeros((self.num_wires, self.n), dtype=np.uint64)
-        msg = C.create_string_buffer(512)
-        st = self.lib.p25o_witness(self.h, _p(inp), seed, _p(wires), msg, 512)
-        return wires, st, msg.value.decode()
-
-    def check_constraints(self, wires):
-        msg = C.create_string_buffer(512)
-        bad = self.lib.p25o_check_constraints(self.h, _p(np.ascontiguousarray(wires)), msg, 512)
-        return bad, msg.value.decode()
-
-    def digest(self):
-        d = np.zeros(4, dtype=np.uint64)
-        cap = np.zeros((16, 4), dtype=np.uint64)
-        self.lib.p25o_circuit_digest(self.h, _p(d), _p(cap))
-        return d, cap
-
-    def prove(self, inputs, seed=0):
-        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
-        proof = np.zeros(self.proof_words, dtype=np.uint64)
-        tm = (C.c_double * 9)()
-        msg = C.create_string_buffer(512)
-        st = self.lib.p25o_prove(self.h, _p(inp), seed, _p(proof), tm, msg, 512)
-        names = ["witness", "wires_commit", "zs", "zs_commit", "quotient", "quotient_commit", "openings", "fri", "total"]
-        return proof, st, dict(zip(names, [float(x) for x in tm])), msg.value.decode()
-
-    def verify(self, proof, digest=None, cs_cap=None):
-        if digest is None:
-            digest, cs_cap = self.digest()
-        msg = C.create_string_buffer(512)
-        st = self.lib.p25o_verify(self.h, _p(np.ascontiguousarray(digest, dtype=np.uint64)),
-                                  _p(np.ascontiguousarray(cs_cap, dtype=np.uint64)),
-                                  _p(np.ascontiguousarray(proof, dtype=np.uint64)), msg, 512)
-        return st, msg.value.decode()
-
-
-class Oracle:
-    """ctypes view of oracle/libp25_oracle.so -- the CPU restatement (checker only)."""
-
-    def __init__(self):
-        path = os.path.join(ROOT, "oracle", "libp25_oracle.so")
-        if not os.path.exists(path):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-        self.lib = C.CDLL(path)
-        L = self.lib
-        vp, sz, ui, u64 = C.c_void_p, C.c_size_t, C.c_uint, C.c_uint64
-        L.p25o_poseidon_permute.argtypes = [vp, sz]
-        L.p25o_poseidon2_permute.argtypes = [vp, sz]
-        L.p25o_poseidon2_trace.argtypes = [vp, vp]
-        L.p25o_hash_no_pad.argtypes = [vp, sz, vp]
-        L.p25o_mul.argtypes = [u64, u64]
-        L.p25o_mul.restype = u64
-        L.p25o_inv.argtypes = [u64]
-        L.p25o_inv.restype = u64
-        L.p25o_merkle_commit.argtypes = [vp, sz, sz, ui, vp, vp]
-        L.p25o_lde_commit.argtypes = [vp, ui, sz, C.c_int, ui, ui, vp, vp, vp]
-        L.p25o_set_threads.argtypes = [C.c_int]
-        L.p25o_circuit_load.restype = vp
-        L.p25o_circuit_load.argtypes = [C.c_char_p, sz]
-        L.p25o_circuit_free.argtypes = [vp]
-        L.p25o_circuit_info.argtypes = [vp, vp]
-        L.p25o_witness.argtypes = [vp, vp, u64, vp, C.c_char_p, sz]
-        L.p25o_check_constraints.argtypes = [vp, vp, C.c_char_p, sz]
-        L.p25o_check_constraints.restype = C.c_long
-        L.p25o_precompute.argtypes = [vp]
-        L.p25o_circuit_digest.argtypes = [vp, vp, vp]
-        L.p25o_proof_words.argtypes = [vp]
-        L.p25o_proof_words.restype = sz
-        L.p25o_prove.argtypes = [vp, vp, u64, vp, vp, C.c_char_p, sz]
-        L.p25o_verify.argtypes = [vp, vp, vp, vp, C.c_char_p, sz]
-        L.p25o_set_threads(min(16, os.cpu_count() or 1))
-
-    def set_threads(self, n):
-        self.lib.p25o_set_threads(n)
-
-    def load_circuit(self, blob):
-        return OracleCircuit(self.lib, blob)
-
-    def poseidon_permute(self, states):
-        s = np.ascontiguousarray(states, dtype=np.uint64).copy().reshape(-1, 12)
-        self.lib.p25o_poseidon_permute(_p(s), s.shape[0])
-        return s
-
-    def poseidon2_permute(self, states):
-        s = np.ascontiguousarray(states, dtype=np.uint64).copy().reshape(-1, 12)
-        self.lib.p25o_poseidon2_permute(_p(s), s.shape[0])
-        return s
-
-    def poseidon2_trace(self, state):
-        s = np.ascontiguousarray(state, dtype=np.uint64).copy()
-        tr = np.zeros(106, dtype=np.uint64)
-        self.lib.p25o_poseidon2_trace(_p(s), _p(tr))
-        return s, tr
-
-    def hash_no_pad(self, words):
-        a = np.ascontiguousarray(words, dtype=np.uint64)
-        out = np.zeros(4, dtype=np.uint64)
-        self.lib.p25o_hash_no_pad(_p(a), a.size, _p(out))
-        return out
-
-    def merkle_commit(self, leaves_rm, cap_height, want_tree=False):
-        a = np.ascontiguousarray(leaves_rm, dtype=np.uint64)
-        n, w = a.shape
-        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
-        words, m = 0, n
-        while m >= (1 << cap_height):
-            words += 4 * m
-            if m == 1:
-                break
-            m >>= 1
-        tree = np.zeros(words, dtype=np.uint64) if want_tree else None
-        self.lib.p25o_merkle_commit(_p(a), n, w, cap_height, _p(cap), _p(tree))
-        return (cap, tree) if want_tree else cap
-
-    def lde_commit(self, polys, rate_bits, cap_height, from_coeffs=False):
-        a = np.ascontiguousarray(polys, dtype=np.uint64)
-        npolys, n = a.shape
-        log_n = n.bit_length() - 1
-        coeffs = np.zeros_like(a)
-        lde = np.zeros((npolys, n << rate_bits), dtype=np.uint64)
-        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
-        self.lib.p25o_lde_commit(_p(a), log_n, npolys, int(from_coeffs), rate_bits, cap_height,
-                                 _p(coeffs), _p(lde), _p(cap))
-        return coeffs, lde, cap
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from oracle_binding import Oracle, OracleCircuit, splitmix_field  # noqa: E402,F401  (the checker)
 
 
 @pytest.fixture(scope="session")
@@ -212,17 +72,3 @@ def fib_inputs():
     import p3json
     inp, _shape = p3json.load(ARTIFACT)
     return inp
-
-
-def splitmix_field(n, seed=0x243F6A8885A308D3):
-    """n canonical Goldilocks elements from SplitMix64 (SURVEY.md 8d synthetic-input recipe)."""
-    out = np.empty(n, dtype=np.uint64)
-    x = np.uint64(seed)
-    idx = np.arange(1, n + 1, dtype=np.uint64)
-    with np.errstate(over="ignore"):
-        z = x + idx * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    out[:] = z % np.uint64(P)
-    return out
