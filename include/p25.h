@@ -40,7 +40,10 @@ enum {
 const char* p25_last_error(void);
 /* Library version string. */
 const char* p25_version(void);
-/* Select the HIP device used by this process (one process per GPU).  P25_ERR_NO_DEVICE if none. */
+/* Select the HIP device used by this PROCESS (one process per GPU); call once, before creating circuits.
+ * The index is recorded and re-applied (hipSetDevice is per host thread) at every entry point, so calls from
+ * any host thread run on this device.  Without it the first call adopts the thread's current device.
+ * P25_ERR_NO_DEVICE if none. */
 p25_status p25_device_init(int device_index);
 
 /* ------------------------------------------------------------------------------------------
@@ -141,7 +144,9 @@ p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t l
 /* Small circuits mirroring the reference's gadget tests (src/p3/mod.rs:271-494 test_p3_and / xor / lsh /
  * rsh / reverse, src/p3/commit.rs:173-198 test_compress): kind 0 and(x,y) 1 xor(x,y) 2 lsh(x,param)
  * 3 rsh(x,param) 4 reverse_bits_len(x,param) 5 Poseidon2 compress(l[4],r[4]) 6 7*w_param^e with inverse
- * 7 MerkleTreeMmcs::hash_iter_slices over `param` slices of 4 words (src/p3/commit.rs:23-46, test :143-171).
+ * 7 MerkleTreeMmcs::hash_iter_slices over `param` slices of 4 words (src/p3/commit.rs:23-46, test :143-171)
+ * 8 inputs a, b under one copy constraint (`connect(a, b)`) and a*b: a != b fails with
+ *   P25_ERR_WITNESS_CONFLICT like upstream's "was set twice with different values".
  * Inputs = operands followed by the expected result(s); a wrong expectation fails the proof with
  * P25_ERR_WITNESS_CONFLICT, as the failing `connect` panics upstream. */
 p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** out);

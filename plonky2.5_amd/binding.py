@@ -11,7 +11,8 @@ __all__ = ["P25Error", "lib", "lib_path", "device_init", "poseidon_permute", "po
 
 P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(_HERE, "libp25.so")
+# P25_LIB: load another build of the same library (tools/qmask.sh uses a profiling build); there is no fallback
+lib_path = os.environ.get("P25_LIB") or os.path.join(_HERE, "libp25.so")
 
 STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "NO_DEVICE", 3: "HIP", 4: "WITNESS_CONFLICT",
                 5: "GENERATORS_NOT_RUN", 6: "OPENING_IN_SUBGROUP", 7: "INTERNAL", 8: "PARSE"}
@@ -299,7 +300,8 @@ class Circuit:
 
     @classmethod
     def build_gadget(cls, kind, param=0):
-        """kind: 0 and, 1 xor, 2 lsh, 3 rsh, 4 reverse_bits_len, 5 compress, 6 exp, 7 hash_iter_slices (include/p25.h)."""
+        """kind: 0 and, 1 xor, 2 lsh, 3 rsh, 4 reverse_bits_len, 5 compress, 6 exp, 7 hash_iter_slices,
+        8 two connected inputs (include/p25.h)."""
         h = vp()
         _check(lib().p25_circuit_build_gadget(kind, param, C.byref(h)))
         return cls(h.value)

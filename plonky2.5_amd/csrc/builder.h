@@ -68,6 +68,9 @@ struct GateInfo {
   int degree, num_constants, num_constraints, num_ops;
 };
 const GateInfo& gate_info(GateKind k);
+// limits of the device kernels, enforced when a circuit enters the library (circuit_io.cpp)
+constexpr int ALPHA_POWS = 192;   // alpha-power table of the quotient kernel: max constraints per gate
+constexpr int MAX_ROUTED = 128;   // routed wires the permutation argument kernels hold
 constexpr int BASE_SUM_LIMBS = 63;
 constexpr int EXP_POWER_BITS = 66;
 

@@ -2,29 +2,45 @@
 #include <stdlib.h>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include "../../include/p25.h"
 #include "kernels.h"
 
 namespace p25 {
 thread_local std::string g_last_error;
-static bool g_device_ok = false;
+// Process-wide device selection.  hipSetDevice is per host thread, so the chosen index is recorded and
+// re-applied at every entry point: a worker thread of the host calling into the library lands on the GPU
+// p25_device_init selected, not on device 0.  -1 = not initialised (first use picks the current device).
+static std::atomic<int> g_device{-1};
+static std::once_flag g_tables_once;
 static std::unique_ptr<NttTables> g_tables;
+static std::mutex g_primitives_mutex;  // the primitive entry points share g_tables (NttTables caches are not thread-safe)
 
 NttTables& tables() {
-  if (!g_tables) g_tables.reset(new NttTables());
+  std::call_once(g_tables_once, [] { g_tables.reset(new NttTables()); });
   return *g_tables;
 }
 
 p25_status ensure_device() {
-  if (g_device_ok) return P25_OK;
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0) {
-    g_last_error = "no HIP device available (libp25 has no CPU fallback)";
-    return P25_ERR_NO_DEVICE;
+  int d = g_device.load(std::memory_order_acquire);
+  if (d < 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      g_last_error = "no HIP device available (libp25 has no CPU fallback)";
+      return P25_ERR_NO_DEVICE;
+    }
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+    int expected = -1;
+    g_device.compare_exchange_strong(expected, cur, std::memory_order_acq_rel);
+    d = g_device.load(std::memory_order_acquire);
   }
-  g_device_ok = true;
+  if (hipSetDevice(d) != hipSuccess) {
+    g_last_error = "hipSetDevice failed";
+    return P25_ERR_HIP;
+  }
   return P25_OK;
 }
 
@@ -105,7 +121,7 @@ p25_status p25_device_init(int device_index) {
     g_last_error = "hipSetDevice failed";
     return P25_ERR_HIP;
   }
-  g_device_ok = true;
+  g_device.store(device_index, std::memory_order_release);
   return P25_OK;
 }
 
@@ -184,6 +200,7 @@ p25_status p25_lde_commit(const uint64_t* polys, unsigned log_n, size_t n_polys,
   return guarded([&]() -> p25_status {
     if (!polys || !n_polys || log_n > 20 || rate_bits > 3 || log_n + rate_bits < cap_height)
       throw std::invalid_argument("p25_lde_commit: bad shape");
+    std::lock_guard<std::mutex> lk(g_primitives_mutex);
     const size_t n = (size_t)1 << log_n, big = n << rate_bits;
     DevBuf in(n * n_polys), co(n * n_polys), tmp(n * n_polys), lde(big * n_polys);
     size_t tw = merkle_tree_words(big, cap_height);
@@ -210,6 +227,7 @@ p25_status p25_lde_commit_dev(const uint64_t* d_polys, unsigned log_n, size_t n_
     if (!d_polys || !n_polys || log_n > 20 || rate_bits > 3 || !d_lde ||
         (!from_coeffs && (!d_coeffs || !d_tmp)))
       throw std::invalid_argument("p25_lde_commit_dev: bad shape");
+    std::lock_guard<std::mutex> lk(g_primitives_mutex);
     lde_commit_dev(d_polys, log_n, n_polys, from_coeffs != 0, rate_bits, cap_height, d_coeffs, d_tmp,
                    d_lde, d_tree, (hipStream_t)stream);
     P25_HIP(hipGetLastError());

@@ -393,7 +393,9 @@ __global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
         if (k != gi) filter = gl::mul(filter, gl::sub((u64)k, s));
       if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
       cx.reset();
-      if (!((a.debug_gate_mask >> ge.kind) & 1u)) continue;  // profiling aid (P25_Q_MASK), all ones in production
+#ifdef P25_PROFILE_GATE_MASK  // profiling builds only (tools/qmask.sh); never compiled into libp25.so
+      if (!((a.debug_gate_mask >> ge.kind) & 1u)) continue;
+#endif
       switch (ge.kind) {
         case G_CONSTANT: gate_constant(cx, k0, k1); break;
         case G_PUBLIC_INPUT: gate_public_input(cx); break;
@@ -434,11 +436,15 @@ void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bit
 
 void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   QuotientArgs a = a_in;
+#ifdef P25_PROFILE_GATE_MASK
+  // Per-gate instruction split for tools/qmask.sh: a separately built profiling library evaluates a subset
+  // of the gates (and so produces WRONG proofs).  The shipped library has no such switch.
   static const uint32_t mask = [] {
-    const char* e = getenv("P25_Q_MASK");  // profiling only: evaluates a subset of the gates (wrong proofs!)
+    const char* e = getenv("P25_Q_MASK");
     return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
   }();
   a.debug_gate_mask = mask;
+#endif
   if (a.num_routed > (uint32_t)MAX_ROUTED) throw std::runtime_error("quotient: more than MAX_ROUTED routed wires");
   for (uint32_t gi = 0; gi < a.n_gates; gi++)  // the carry-free alpha fold holds 512 terms per gate
     if (gate_info((GateKind)a.gates[gi].kind).num_constraints > MAX_TERMS_PER_FOLD ||

@@ -36,7 +36,7 @@ struct Emitter {
     uint32_t a = outs[k];
     size_t idx = (size_t)(a & 0x7FFFFFFFu) * B + p;
     if (a & WIT_CHECK_FLAG) {
-      if (vals[idx] != v) status[p] = 4;  // P25_ERR_WITNESS_CONFLICT
+      if (vals[idx] != v) set_status(status + p, 4);  // P25_ERR_WITNESS_CONFLICT
     } else {
       vals[idx] = v;
     }
@@ -185,7 +185,7 @@ __device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* 
       break;
     }
     default:
-      status[p] = 7;
+      set_status(status + p, 7);
   }
 }
 
@@ -244,22 +244,36 @@ __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __rest
 
 // vals[slot 0] = 0; vals[input_slots[i]] = inputs[p][i]
 // A non-canonical input word (>= p) is reduced and the proof flagged P25_ERR_INVALID_ARG: the host-buffer
-// entry point rejects such inputs up front, the device-resident one can only find out here.
+// entry point rejects such inputs up front, the device-resident one can only find out here.  An input
+// connected to an earlier input is compared with it (P25_ERR_WITNESS_CONFLICT on mismatch; upstream panics
+// "was set twice with different values") instead of racing it for the slot.  This is the first kernel of a
+// proof, so when both happen the smaller code is reported (deterministic within the launch).
 __global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, const uint32_t* __restrict__ input_slots,
-                                    uint32_t n_inputs, u64* __restrict__ vals, size_t B, uint32_t n_proofs,
+                                    const uint32_t* __restrict__ input_first, uint32_t n_inputs,
+                                    u64* __restrict__ vals, size_t B, uint32_t n_proofs,
                                     uint32_t* __restrict__ status) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)(n_inputs + 1) * n_proofs) return;
   uint32_t i = (uint32_t)(idx / n_proofs), p = (uint32_t)(idx % n_proofs);
+  auto flag = [&](uint32_t code) {
+    if (atomicCAS(status + p, 0u, code) != 0u) atomicMin(status + p, code);
+  };
   if (i == n_inputs) {
     vals[p] = 0;
   } else {
     u64 v = inputs[(size_t)p * n_inputs + i];
     if (v >= gl::P) {
       v -= gl::P;
-      status[p] = 1;  // P25_ERR_INVALID_ARG
+      flag(1);  // P25_ERR_INVALID_ARG
     }
-    vals[(size_t)input_slots[i] * B + p] = v;
+    const uint32_t a = input_slots[i];
+    if (a & WIT_CHECK_FLAG) {
+      u64 w = inputs[(size_t)p * n_inputs + input_first[i]];
+      if (w >= gl::P) w -= gl::P;
+      if (w != v) flag(4);  // P25_ERR_WITNESS_CONFLICT
+    } else {
+      vals[(size_t)a * B + p] = v;
+    }
   }
 }
 
@@ -276,7 +290,7 @@ void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u6
                    size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st) {
   size_t tot = (size_t)(wp.n_inputs + 1) * n_proofs;
   hipLaunchKernelGGL(k_witgen_set_inputs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_inputs,
-                     wp.d_input_slots, wp.n_inputs, d_vals, B, n_proofs, d_status);
+                     wp.d_input_slots, wp.d_input_first, wp.n_inputs, d_vals, B, n_proofs, d_status);
   for (size_t l = 0; l + 1 < wp.level_start.size(); l++) {
     uint32_t b = wp.level_start[l], cnt = wp.level_start[l + 1] - b;
     if (!cnt) continue;

@@ -801,6 +801,12 @@ Circuit build_gadget_circuit(int kind, int param) {
       for (int i = 0; i < 4; i++) cb.connect(out[i], in());
       break;
     }
+    case GADGET_CONNECTED_INPUTS: {  // two witness-set targets under one copy constraint, then a * b == expected
+      Target a = in(), b = in(), expected = in();
+      cb.connect(a, b);
+      cb.connect(cb.mul(a, b), expected);
+      break;
+    }
     default:
       throw std::invalid_argument("unknown gadget kind");
   }

@@ -70,7 +70,7 @@ ProofLayout make_proof_layout(const Circuit& c) {
 __global__ void k_check_zeta(const u64* chal, uint32_t degree_bits, uint32_t* status) {
   gl::E2 z{chal[CH_ZETA], chal[CH_ZETA + 1]};
   gl::E2 zn = gl::exp_pow2(z, degree_bits);
-  if (zn.a == 1 && zn.b == 0) *status = 6;  // "Opening point is in the subgroup."
+  if (zn.a == 1 && zn.b == 0) set_status(status, 6);  // "Opening point is in the subgroup."
 }
 __global__ void k_interleave(const u64* a, const u64* b, uint32_t m, u64* out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,7 +82,7 @@ __global__ void k_interleave(const u64* a, const u64* b, uint32_t m, u64* out) {
 __global__ void k_finish(const u64* chal, int pow_bits, u64* proof_pow, uint32_t* status) {
   u64 w = chal[CH_POW_WITNESS];
   *proof_pow = w;
-  if (w == ~0ull || __clzll((long long)chal[CH_POW_RESPONSE]) < pow_bits) *status = 7;
+  if (w == ~0ull || __clzll((long long)chal[CH_POW_RESPONSE]) < pow_bits) set_status(status, 7);
 }
 
 // ---------------------------------------------------------------- per-proof working set
@@ -130,6 +130,7 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
   }
   wp_.d_args = up32(wp.args);
   wp_.d_input_slots = up32(wp.input_slots);
+  wp_.d_input_first = up32(wp.input_first);
   wp_.d_wire_slot_cm = up32(wp.wire_slot_cm);
   wp_.level_start = wp.level_start;
   for (size_t l = 0; l + 1 < wp.level_start.size(); l++) {

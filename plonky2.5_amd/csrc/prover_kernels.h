@@ -10,12 +10,18 @@ struct DeviceWitnessProgram {
   WitGen* d_gens = nullptr;
   uint32_t* d_args = nullptr;
   uint32_t* d_input_slots = nullptr;
+  uint32_t* d_input_first = nullptr;
   uint32_t* d_wire_slot_cm = nullptr;
   std::vector<uint32_t> level_start;
   std::vector<uint32_t> level_p2_begin, level_p2_count;  // Poseidon2 generators of each level (contiguous)
   uint32_t n_inputs = 0, num_slots = 0;
   size_t n_wire_elems = 0;
 };
+// Per-proof status word: the FIRST failure (in stream order) is the one reported -- a later kernel never
+// overwrites an earlier code (upstream stops at its first panic / Err too).
+#ifdef __HIPCC__
+__device__ __forceinline__ void set_status(uint32_t* status, uint32_t code) { atomicCAS(status, 0u, code); }
+#endif
 void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u64* d_seeds, u64* d_vals,
                    size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st);
 void launch_fill_wires(const DeviceWitnessProgram& wp, const u64* d_vals, size_t B, uint32_t p, u64* d_wires,
@@ -57,10 +63,10 @@ struct QuotientArgs {
   uint32_t n_gates, num_selectors, num_wires, num_routed, num_partial_products, degree_bits, rate_bits;
   u64 zh[8], zh_inv[8];  // Z_H on the coset (index = i mod 2^rate_bits), and inverses
   const u64* l0_inv;     // [big] 1 / (n (x - 1)) at bit-reversed positions (per circuit)
-  uint32_t debug_gate_mask;  // set by launch_quotient
+#ifdef P25_PROFILE_GATE_MASK
+  uint32_t debug_gate_mask;  // profiling builds only (tools/qmask.sh)
+#endif
 };
-constexpr int ALPHA_POWS = 192;
-constexpr int MAX_ROUTED = 128;
 void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bits, u64* d_out, hipStream_t st);
 void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st);
 void launch_quotient(const QuotientArgs& a, hipStream_t st);

@@ -14,16 +14,21 @@ WitnessProgram build_witness_program(const Circuit& c) {
   auto rep_of = [&](Target t) { return c.rep[c.target_index(t)]; };
 
   // inputs are assigned before round 1
-  for (const Target& t : c.input_targets) {
-    uint32_t r = rep_of(t);
-    if (slot_of_rep[r] == 0) {
-      slot_of_rep[r] = wp.num_slots++;
-      set_round[r] = 0;
-      wp.input_is_check.push_back(0);
-    } else {
-      wp.input_is_check.push_back(1);
+  {
+    std::vector<uint32_t> first_input(NT, UINT32_MAX);
+    for (size_t i = 0; i < c.input_targets.size(); i++) {
+      uint32_t r = rep_of(c.input_targets[i]);
+      if (slot_of_rep[r] == 0) {
+        slot_of_rep[r] = wp.num_slots++;
+        set_round[r] = 0;
+        first_input[r] = (uint32_t)i;
+        wp.input_slots.push_back(slot_of_rep[r]);
+        wp.input_first.push_back((uint32_t)i);
+      } else {
+        wp.input_slots.push_back(slot_of_rep[r] | WIT_CHECK_FLAG);
+        wp.input_first.push_back(first_input[r]);
+      }
     }
-    wp.input_slots.push_back(slot_of_rep[r]);
   }
 
   // watch lists

@@ -32,7 +32,10 @@ struct WitnessProgram {
   std::vector<uint32_t> args;
   std::vector<uint32_t> level_start;      // gens[level_start[l] .. level_start[l+1]) is level l
   std::vector<uint32_t> input_slots;      // slot of each per-proof input
-  std::vector<uint32_t> input_is_check;   // (never set for the p3 circuit) duplicate input partitions
+  // An input whose copy-constraint partition was already assigned by an EARLIER input (two connected
+  // inputs; never the case for the p3 circuit) is compared with that first input instead of stored:
+  // input_slots[i] carries WIT_CHECK_FLAG and input_first[i] is the index of the first writer.
+  std::vector<uint32_t> input_first;
   std::vector<uint32_t> wire_slot_cm;     // [num_wires][degree] column-major: slot of each wire
 };
 

@@ -31,6 +31,8 @@ def cases(oracle=None):
     e = int(rng.integers(0, 1 << 19))
     w = pow(TWO_ADIC, 1 << (32 - 19), P)
     out.append(("exp19", 6, 19, [e, 7 * pow(w, e, P) % P]))
+    a = r64()
+    out.append(("connected_inputs", 8, 0, [a, a, a * a % P]))
     if oracle is not None:
         l = [r64() for _ in range(4)]
         r = [r64() for _ in range(4)]

@@ -9,6 +9,7 @@
 #include "circuit_io.h"
 #include "p3_circuit.h"
 #include "p3_prover.h"
+#include "witness_program.h"
 typedef uint64_t u64;
 extern "C" {
 void* p25o_circuit_load(const unsigned char* blob, size_t len);
@@ -49,6 +50,38 @@ int main() {
     bool threw = false;
     try { circuit_from_blob(blob.data(), cut); } catch (const std::exception&) { threw = true; }
     CHECK(threw);
+  }
+  // bit-flip fuzz of a valid blob (a circuit handed over by another process is untrusted input): every
+  // mutant is either rejected with an exception or yields a circuit whose witness program can be built
+  // without touching memory out of bounds (ASan is the judge).
+  {
+    CircuitBuilder cbf;
+    P3ProveParams ps;
+    ps.log_n = 3; ps.num_queries = 2; ps.pow_bits = 4; ps.threads = 1;
+    P3Config cf;
+    p3_prove_fibonacci(ps, cf);
+    p3_verify_proof(cbf, cf, fib);
+    std::vector<uint8_t> small = circuit_to_blob(cbf.build());
+    const size_t header_bytes = 8 * (1 + 32 + 4 * 16 + 8);
+    u64 rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&] { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    int rejected = 0, accepted = 0;
+    for (int trial = 0; trial < 400; trial++) {
+      std::vector<uint8_t> m(small);
+      const size_t span = trial % 2 ? header_bytes : m.size();
+      const int flips = 1 + (int)(next() % 3);
+      for (int f = 0; f < flips; f++) m[next() % span] ^= (uint8_t)(1u << (next() % 8));
+      try {
+        Circuit cm = circuit_from_blob(m.data(), m.size());
+        WitnessProgram wpm = build_witness_program(cm);
+        CHECK(wpm.input_slots.size() == cm.input_targets.size());
+        accepted++;
+      } catch (const std::exception&) {
+        rejected++;
+      }
+    }
+    printf("blob fuzz: %d rejected, %d accepted\n", rejected, accepted);
+    CHECK(rejected > 50);
   }
   // oracle on a small verifier circuit
   prm.log_n = 3; prm.num_queries = 3; prm.pow_bits = 4;

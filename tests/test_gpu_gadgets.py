@@ -28,3 +28,17 @@ def test_gadgets_gpu_equals_oracle(gpu, oracle):
         diff = np.nonzero(proofs[0] != po)[0]
         assert diff.size == 0, (name, diff[:5])
         assert oc.verify(proofs[2], dg, capg)[0] == 0, name
+
+
+def test_two_connected_inputs_with_different_values_conflict(gpu, oracle):
+    """inputs sharing a copy-constraint partition are compared, not raced (upstream panics
+    "Partition ... was set twice with different values")."""
+    c = gpu.Circuit.build_gadget(8, 0)
+    oc = oracle.load_circuit(c.to_blob())
+    good = np.array([5, 5, 25], dtype=np.uint64)
+    bad = np.array([5, 6, 30], dtype=np.uint64)      # a * b is right, but a != b
+    bad2 = np.array([6, 5, 30], dtype=np.uint64)
+    proofs, st = c.prove(np.stack([good, bad, bad2, good]), seeds=[1, 1, 1, 1])
+    assert st.tolist() == [0, 4, 4, 0]
+    assert (proofs[0] == proofs[3]).all()
+    assert oc.witness(bad, seed=1)[1] == 4 and oc.witness(good, seed=1)[1] == 0

@@ -1,5 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
+# needs the profiling build: make -C plonky2.5_amd/csrc profile  (the shipped libp25.so has no gate mask)
+export P25_LIB=$PWD/tools/build/libp25_gatemask.so
 for M in 0xFFFFFFFF 0x0 $*; do
   rm -rf gpurun_out/_pmc
   P25_Q_MASK=$M rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/_pmc -- python3 tools/prove_one.py 1 > gpurun_out/_pmc.log 2>&1
