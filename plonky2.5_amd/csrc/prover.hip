@@ -540,11 +540,17 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
                                     size_t proof_stride, uint32_t* d_status, PhaseTimes* times) {
   size_t K = times ? 1 : streams_in_flight();
   if (K > n_proofs) K = n_proofs ? n_proofs : 1;
-  {
-    // keep the in-flight contexts within ~60% of the device memory (matters for 2^19-row circuits: 13 GB each)
+  if (K > ctxs_.size()) {
+    // New contexts must fit in what is actually FREE on the device (other circuits, the caller's tensors and
+    // this circuit's tables are already allocated), after the witness-value array of this call and a 5%
+    // reserve -- matters for 2^19-row circuits (13 GB per context).
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
-      size_t fit = (size_t)(0.6 * (double)total_b) / ctx_bytes();
+      const size_t pass = n_proofs < 64 ? n_proofs : 64;
+      const size_t vals_need = pass > vals_batch_ ? (size_t)wp_.num_slots * pass * 8 : 0;
+      const size_t reserve = total_b / 20;
+      const size_t avail = free_b > vals_need + reserve ? free_b - vals_need - reserve : 0;
+      size_t fit = ctxs_.size() + avail / ctx_bytes();
       if (fit < 1) fit = 1;
       if (K > fit) K = fit;
     }
