@@ -159,7 +159,7 @@ void p25_circuit_destroy(p25_circuit* c);
 typedef struct {
   uint64_t degree_bits, num_rows_used, num_wires, num_routed_wires, num_inputs, num_generators;
   uint64_t num_gate_types, num_selectors, num_constants_sigmas, num_gate_constraints;
-  uint64_t proof_words, witness_levels, witness_slots, reserved;
+  uint64_t proof_words, witness_levels, witness_slots, num_random_fill;
 } p25_circuit_info_t;
 p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out);
 /* Rows per gate type, in sorted-gate order; ids_out receives up to cap gate-id strings joined by '\n'. */
@@ -202,6 +202,11 @@ typedef struct {
 p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* seeds,
                            uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status,
                            p25_timings* timings);
+/* p25_prove_batch with EXPLICIT values for the RandomValueGenerator wires instead of seeds: filler[n_proofs][num_random_fill]
+ * (p25_circuit_info_t.num_random_fill = 131 for these circuits; order = PublicInputGate wires 4..134).  With the values a
+ * real upstream run drew from the OS RNG, the proof is the one that run produced (tests/test_upstream_golden.py). */
+p25_status p25_prove_batch_filler(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* filler,
+                                  uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status);
 /* Same with every buffer resident in HBM (device pointers; d_status is uint32_t[n_proofs]).
  * Enqueues on the circuit's stream and returns; p25_circuit_sync waits. */
 p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t n_proofs, const uint64_t* d_seeds,
@@ -215,6 +220,39 @@ p25_status p25_circuit_kernel_stats(p25_circuit* c, int enable, int reset, doubl
 /* Witness only (parity tests): wires_out[num_wires][2^degree_bits], column-major. */
 p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, uint64_t* wires_out,
                        p25_status* proof_status);
+
+/* ------------------------------------------------------------------------------------------
+ * Stages of the prover on their own (host buffers; the fine-grained entry points of SURVEY.md 8b, used by the
+ * isolated parity tests of rows a6-a10).  Each replaces one upstream function reached from `data.prove(pw)`
+ * (src/p3/mod.rs:260); NC = num_challenges (2), NP = partial products per challenge, n = 2^degree_bits.
+ * ------------------------------------------------------------------------------------------ */
+/* Challenger script (upstream iop/challenger.rs `Challenger<F, PoseidonHash>`: duplex sponge, rate 8, challenges
+ * popped from the end of the output buffer): for segment k observe seg_len[k] words of `observe` (consumed in
+ * order), then draw n_challenges[k] (<= 64) challenges, appended to challenges_out. */
+p25_status p25_transcript(const uint64_t* observe, const uint32_t* seg_len, const uint32_t* n_challenges,
+                          size_t n_segments, uint64_t* challenges_out);
+/* upstream prover.rs `wires_permutation_partial_products_and_zs`: wires[num_wires][n] (witness values, column
+ * major) + betas[NC], gammas[NC] -> out[NC * (1 + NP)][n]: the NC Z polynomials, then the NC * NP partial
+ * products (values on the subgroup, natural row order). */
+p25_status p25_partial_products(p25_circuit* c, const uint64_t* wires, const uint64_t* betas, const uint64_t* gammas,
+                                uint64_t* out);
+/* upstream prover.rs `compute_quotient_polys` (+ "split up quotient polys"), including every gate's
+ * `eval_unfiltered_base_batch` (the reference's: poseidon2_gate.rs:233-310, arithmetic_u32.rs:303-366,
+ * interleave_u32.rs:250-287, uninterleave_to_u32.rs:285-335): wires[num_wires][n] and zs_pp[NC*(1+NP)][n]
+ * (values) + betas, gammas, alphas [NC] -> out[NC * 2^rate_bits][n]: coefficients of the quotient chunks. */
+p25_status p25_quotient(p25_circuit* c, const uint64_t* wires, const uint64_t* zs_pp, const uint64_t* betas,
+                        const uint64_t* gammas, const uint64_t* alphas, uint64_t* out);
+/* upstream fri/prover.rs `fri_proof` on one batched polynomial: coeffs[2][2^log_n] (the two components of its
+ * extension-field coefficients), transcript initialised by observing seed[n_seed].  Commit phase (LDE on
+ * 7*<w>, 2^arity-ary leaves, Merkle caps, fold by beta), final polynomial, PoW grind, num_queries (<= 64) query rounds.
+ *   out: CAP[n_layers] | betas E[n_layers] | final_poly E[2^(log_n - sum arity)] | pow_witness |
+ *        query indices u64[num_queries] | per query, per layer {evals E[2^arity], siblings H[..]}
+ * p25_fri_prove_words gives the size (0 for an invalid shape).  *status_out: P25_OK or P25_ERR_INTERNAL (no PoW witness). */
+size_t p25_fri_prove_words(unsigned log_n, unsigned rate_bits, unsigned cap_height, const int32_t* arity_bits,
+                           size_t n_layers, unsigned num_queries);
+p25_status p25_fri_prove(const uint64_t* coeffs, unsigned log_n, unsigned rate_bits, unsigned cap_height,
+                         const int32_t* arity_bits, size_t n_layers, unsigned pow_bits, unsigned num_queries,
+                         const uint64_t* seed, size_t n_seed, uint64_t* out, size_t out_cap, p25_status* status_out);
 
 /* ------------------------------------------------------------------------------------------
  * Data formats either side of the path.

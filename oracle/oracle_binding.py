@@ -56,6 +56,40 @@ class OracleCircuit:
         names = ["witness", "wires_commit", "zs", "zs_commit", "quotient", "quotient_commit", "openings", "fri", "total"]
         return proof, st, dict(zip(names, [float(x) for x in tm])), msg.value.decode()
 
+    def prove_filler(self, inputs, filler):
+        """Prove with explicit RandomValueGenerator values (what a real upstream run drew from the OS RNG)."""
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
+        f = np.ascontiguousarray(filler, dtype=np.uint64)
+        assert f.size == self.lib.p25o_num_random_fill(self.h)
+        proof = np.zeros(self.proof_words, dtype=np.uint64)
+        msg = C.create_string_buffer(512)
+        st = self.lib.p25o_prove_filler(self.h, _p(inp), _p(f), _p(proof), msg, 512)
+        return proof, st, msg.value.decode()
+
+    def partial_products(self, wires, betas, gammas):
+        w = np.ascontiguousarray(wires, dtype=np.uint64)
+        info = (C.c_uint64 * 8)()
+        self.lib.p25o_circuit_info(self.h, info)
+        nz = self._nz()
+        out = np.zeros((nz, self.n), dtype=np.uint64)
+        self.lib.p25o_partial_products(self.h, _p(w), _p(np.ascontiguousarray(betas, dtype=np.uint64)),
+                                       _p(np.ascontiguousarray(gammas, dtype=np.uint64)), _p(out))
+        return out
+
+    def _nz(self):
+        nz = C.c_uint64(0)
+        self.lib.p25o_stage_shapes(self.h, C.byref(nz), None)
+        return int(nz.value)
+
+    def quotient(self, wires, zs_pp, betas, gammas, alphas):
+        nq = C.c_uint64(0)
+        self.lib.p25o_stage_shapes(self.h, None, C.byref(nq))
+        out = np.zeros((int(nq.value), self.n), dtype=np.uint64)
+        u = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        ww, zz, b, g, al = u(wires), u(zs_pp), u(betas), u(gammas), u(alphas)
+        self.lib.p25o_quotient(self.h, _p(ww), _p(zz), _p(b), _p(g), _p(al), _p(out))
+        return out
+
     def prove_many(self, inputs, seeds, threads, want_proofs=True):
         """N independent proofs, one single-threaded proof per pinned host thread.
         Returns (proofs or None, statuses, per-proof seconds, wall seconds)."""
@@ -114,6 +148,15 @@ class Oracle:
         L.p25o_prove.argtypes = [vp, vp, u64, vp, vp, C.c_char_p, sz]
         L.p25o_verify.argtypes = [vp, vp, vp, vp, C.c_char_p, sz]
         L.p25o_prove_many.argtypes = [vp, vp, vp, sz, C.c_int, vp, vp, vp]
+        L.p25o_stage_shapes.argtypes = [vp, vp, vp]
+        L.p25o_prove_filler.argtypes = [vp, vp, vp, vp, C.c_char_p, sz]
+        L.p25o_num_random_fill.argtypes = [vp]
+        L.p25o_num_random_fill.restype = sz
+        L.p25o_transcript.argtypes = [vp, vp, vp, sz, vp]
+        L.p25o_partial_products.argtypes = [vp, vp, vp, vp, vp]
+        L.p25o_quotient.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.p25o_fri_prove.argtypes = [vp, ui, ui, ui, vp, sz, ui, ui, vp, sz, vp, sz]
+        L.p25o_fri_prove.restype = sz
         L.p25o_prove_many.restype = C.c_double
         L.p25o_set_threads(min(64, os.cpu_count() or 1))
 
@@ -122,6 +165,28 @@ class Oracle:
 
     def load_circuit(self, blob):
         return OracleCircuit(self.lib, blob)
+
+    def transcript(self, segments):
+        """segments: [(words_to_observe, n_challenges), ...] -> all challenges drawn, in order."""
+        obs = np.ascontiguousarray(np.concatenate([np.asarray(w, dtype=np.uint64).ravel() for w, _ in segments]
+                                                  + [np.zeros(0, dtype=np.uint64)]))
+        lens = np.array([np.asarray(w).size for w, _ in segments], dtype=np.uint32)
+        nch = np.array([k for _, k in segments], dtype=np.uint32)
+        out = np.zeros(int(nch.sum()), dtype=np.uint64)
+        self.lib.p25o_transcript(_p(obs), _p(lens), _p(nch), len(segments), _p(out))
+        return out
+
+    def fri_prove(self, coeffs, rate_bits, cap_height, arity_bits, pow_bits, num_queries, seed):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        assert a.ndim == 2 and a.shape[0] == 2
+        log_n = int(a.shape[1]).bit_length() - 1
+        ar = np.array(arity_bits, dtype=np.int32)
+        sd = np.ascontiguousarray(seed, dtype=np.uint64)
+        out = np.zeros(1 << 22, dtype=np.uint64)
+        n = self.lib.p25o_fri_prove(_p(a), log_n, rate_bits, cap_height, _p(ar), len(ar), pow_bits, num_queries,
+                                    _p(sd), sd.size, _p(out), out.size)
+        assert n > 0, "oracle FRI failed"
+        return out[:n].copy()
 
     def poseidon_permute(self, states):
         s = np.ascontiguousarray(states, dtype=np.uint64).copy().reshape(-1, 12)

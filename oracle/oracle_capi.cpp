@@ -181,6 +181,97 @@ int p25o_prove(void* h, const u64* inputs, u64 seed, u64* proof_out, double* tim
   }
   return 0;
 }
+// ---------------------------------------------------------------- isolated stages (parity tests of a6-a10)
+// Challenger script: for each segment observe seg_len[k] words of `obs` (consumed in order), then draw
+// n_chal[k] challenges into `out` (appended in order).  upstream iop/challenger.rs.
+void p25o_transcript(const u64* obs, const u32* seg_len, const u32* n_chal, size_t n_seg, u64* out) {
+  RChallenger ch;
+  for (size_t k = 0; k < n_seg; k++) {
+    for (u32 i = 0; i < seg_len[k]; i++) ch.observe(*obs++);
+    for (u32 i = 0; i < n_chal[k]; i++) *out++ = ch.challenge();
+  }
+}
+// rows of the Z/partial-products matrix and of the quotient-chunk matrix
+void p25o_stage_shapes(void* h, u64* nz, u64* nq) {
+  const RCircuit& c = ((OracleCircuit*)h)->c;
+  if (nz) *nz = (u64)c.num_challenges * (1 + c.num_partial_products);
+  if (nq) *nq = (u64)c.num_challenges * c.quotient_degree_factor;
+}
+// wires[num_wires][n] -> out[NC * (1 + NP)][n]
+void p25o_partial_products(void* h, const u64* wires, const u64* betas, const u64* gammas, u64* out) {
+  auto* oc = (OracleCircuit*)h;
+  const RCircuit& c = oc->c;
+  const size_t n = c.n();
+  std::vector<std::vector<u64>> w(c.num_wires);
+  for (int col = 0; col < c.num_wires; col++) w[col].assign(wires + (size_t)col * n, wires + (size_t)(col + 1) * n);
+  std::vector<u64> b(betas, betas + c.num_challenges), g(gammas, gammas + c.num_challenges);
+  auto z = ref_partial_products(c, w, b, g);
+  for (size_t k = 0; k < z.size(); k++) memcpy(out + k * n, z[k].data(), n * 8);
+}
+// wires[num_wires][n], zs_pp[NC*(1+NP)][n] (values) -> out[NC * Q][n] quotient chunk coefficients
+void p25o_quotient(void* h, const u64* wires, const u64* zs_pp, const u64* betas, const u64* gammas, const u64* alphas,
+                   u64* out) {
+  auto* oc = (OracleCircuit*)h;
+  p25o_precompute(h);
+  const RCircuit& c = oc->c;
+  const size_t n = c.n();
+  const int nz = c.num_challenges * (1 + c.num_partial_products);
+  std::vector<std::vector<u64>> w(c.num_wires), z(nz);
+  for (int col = 0; col < c.num_wires; col++) w[col].assign(wires + (size_t)col * n, wires + (size_t)(col + 1) * n);
+  for (int k = 0; k < nz; k++) z[k].assign(zs_pp + (size_t)k * n, zs_pp + (size_t)(k + 1) * n);
+  RPolyBatch wb = ref_commit_values(w, c.rate_bits, c.cap_height), zb = ref_commit_values(z, c.rate_bits, c.cap_height);
+  std::vector<u64> b(betas, betas + c.num_challenges), g(gammas, gammas + c.num_challenges),
+      a(alphas, alphas + c.num_challenges);
+  auto q = ref_quotient_chunks(c, oc->pre->constants_sigmas, wb, zb, b, g, a);
+  for (size_t k = 0; k < q.size(); k++) memcpy(out + k * n, q[k].data(), n * 8);
+}
+// FRI on one batched polynomial: coeffs[2][2^log_n] (extension components), transcript initialised by observing
+// `seed`.  out: CAP[n_layers] | betas E[n_layers] | final_poly E[..] | pow_witness | indices u64[num_queries] |
+// per query, per layer {evals E[2^arity], siblings H[..]}.  Returns words written (0 on failure).
+size_t p25o_fri_prove(const u64* coeffs, unsigned log_n, unsigned rate_bits, unsigned cap_height, const int* arity_bits,
+                      size_t n_layers, unsigned pow_bits, unsigned num_queries, const u64* seed, size_t n_seed, u64* out,
+                      size_t cap) {
+  const size_t n = (size_t)1 << log_n;
+  RFriParams fp{(int)log_n, (int)rate_bits, (int)cap_height, std::vector<int>(arity_bits, arity_bits + n_layers),
+                (int)pow_bits, (int)num_queries};
+  std::vector<RE2> poly(n);
+  for (size_t i = 0; i < n; i++) poly[i] = RE2{coeffs[i], coeffs[n + i]};
+  RChallenger ch;
+  for (size_t i = 0; i < n_seed; i++) ch.observe(seed[i]);
+  // the betas are not part of a proof: recover them by replaying the transcript on a copy
+  RChallenger replay = ch;
+  RProof pr;
+  std::vector<size_t> idx;
+  std::string m;
+  if (ref_fri_prove(fp, poly, ch, nullptr, pr, &idx, &m)) return 0;
+  std::vector<u64> o;
+  for (auto& c : pr.fri_caps)
+    for (auto& hsh : c) o.insert(o.end(), hsh.e, hsh.e + 4);
+  for (auto& c : pr.fri_caps) {
+    replay.observe_cap(c);
+    RE2 b = replay.ext_challenge();
+    o.push_back(b.a);
+    o.push_back(b.b);
+  }
+  for (auto& e : pr.final_poly) {
+    o.push_back(e.a);
+    o.push_back(e.b);
+  }
+  o.push_back(pr.pow_witness);
+  for (size_t x : idx) o.push_back((u64)x);
+  for (auto& q : pr.queries)
+    for (size_t l = 0; l < q.step_evals.size(); l++) {
+      for (auto& e : q.step_evals[l]) {
+        o.push_back(e.a);
+        o.push_back(e.b);
+      }
+      for (auto& hsh : q.step_path[l]) o.insert(o.end(), hsh.e, hsh.e + 4);
+    }
+  if (o.size() > cap) return 0;
+  memcpy(out, o.data(), o.size() * 8);
+  return o.size();
+}
+
 // CPU-baseline leg "one proof per core": n_proofs independent proofs on n_threads host threads, each
 // proof single-threaded (as the reference build: Cargo.toml:15-18 has no `parallel` feature) and each
 // thread pinned to its own CPU of the process's affinity set.  inputs[n_proofs][num_inputs],
@@ -230,6 +321,21 @@ double p25o_prove_many(void* h, const u64* inputs, const u64* seeds, size_t n_pr
   for (auto& x : th) x.join();
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
+
+// Same with explicit RandomValueGenerator values filler[num_random_fill] instead of the seed.
+int p25o_prove_filler(void* h, const u64* inputs, const u64* filler, u64* proof_out, char* msg, size_t msglen) {
+  auto* oc = (OracleCircuit*)h;
+  p25o_precompute(h);
+  RProof pr;
+  std::string m;
+  int st = ref_prove(oc->c, *oc->pre, inputs, 0, pr, nullptr, &m, filler);
+  put_msg(msg, msglen, m);
+  if (st) return st;
+  std::vector<u64> flat = ref_proof_flatten(oc->c, pr);
+  memcpy(proof_out, flat.data(), flat.size() * 8);
+  return 0;
+}
+size_t p25o_num_random_fill(void* h) { return ((OracleCircuit*)h)->c.num_random_fill; }
 
 // digest4 / cs_cap: the verifier-side circuit data (VerifierOnlyCircuitData); pass the oracle's own
 // (p25o_circuit_digest) or the product's to cross-check.

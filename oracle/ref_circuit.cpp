@@ -63,6 +63,7 @@ RCircuit ref_circuit_parse(const unsigned char* blob, size_t len) {
   c.gens.resize(n_gen);
   for (auto& g : c.gens) {
     g.kind = (u32)r.w(); g.c0 = r.w(); g.c1 = r.w(); g.aux = (int)r.w();
+    if (g.kind == RGEN_RANDOM) g.c1 = c.num_random_fill++;  // ordinal among the RandomValueGenerators
     g.n_deps = (u32)r.w(); g.n_outs = (u32)r.w();
     g.arg_off = c.gen_args.size();
     c.gen_args.resize(g.arg_off + g.n_deps + g.n_outs);
@@ -109,7 +110,7 @@ struct PartitionWitness {
 };
 
 // Runs one generator; outputs appended to `out` in the generator's `outs` order.
-void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitness& w, u64 seed,
+void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitness& w, u64 seed, const u64* filler,
                    std::vector<u64>& out) {
   const u32* dep = c.gen_args.data() + g.arg_off;
   auto d = [&](int i) { return w.get(dep[i]); };
@@ -119,7 +120,9 @@ void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitnes
       out.push_back(g.c0);
       break;
     case RGEN_RANDOM:
-      out.push_back(ref_random_fill(seed, (u64)g.aux));
+      // explicit filler (e.g. the values a real upstream run drew from the OS RNG), indexed by the generator's
+      // ordinal among the RandomValueGenerators, or the deterministic SplitMix64 stand-in
+      out.push_back(filler ? filler[g.c1] : ref_random_fill(seed, (u64)g.aux));
       break;
     case RGEN_ARITHMETIC:  // out = c0*m0*m1 + c1*addend
       out.push_back(rf_add(rf_mul(rf_mul(d(0), d(1)), g.c0), rf_mul(d(2), g.c1)));
@@ -240,7 +243,7 @@ void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitnes
 }
 }  // namespace
 
-RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed) {
+RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed, const u64* filler) {
   RWitnessResult res;
   res.status = 0;
   PartitionWitness w(c);
@@ -273,7 +276,7 @@ RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 se
       bool ready = true;
       for (u32 i = 0; i < g.n_deps && ready; i++) ready = w.has(c.gen_args[g.arg_off + i]);
       if (!ready) continue;
-      run_generator(c, g, w, seed, out);
+      run_generator(c, g, w, seed, filler, out);
       expired[gi] = 1;
       remaining--;
       for (u32 i = 0; i < g.n_outs; i++) {

@@ -28,6 +28,7 @@ struct RGateType {
   int selector_index, group_start, group_end;
 };
 struct RCircuit {
+  size_t num_random_fill = 0;  // RandomValueGenerators (upstream randomises the PublicInputGate's unused wires)
   int degree_bits, num_wires, num_routed, num_constants, num_challenges, quotient_degree_factor;
   int rate_bits, cap_height, pow_bits, num_queries, num_selectors, num_gate_constraints;
   int num_partial_products, pi_row;
@@ -55,5 +56,5 @@ struct RWitnessResult {
   std::string message;
   std::vector<std::vector<u64>> wires;  // [num_wires][n]  (full_witness: unset wires are 0)
 };
-RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed);
+RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed, const u64* filler = nullptr);
 u64 ref_random_fill(u64 seed, u64 k);

@@ -336,37 +336,14 @@ static std::vector<u64> flatten_exts(const std::vector<RE2>& v) {
 }
 static int leading_zeros64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 
-// ---------------------------------------------------------------- prover (App. A.0-A.8)
-int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64 seed, RProof& out, RTimings* tm,
-              std::string* msg) {
-  RTimings T;
-  double t_start = now_s(), t0 = t_start;
+// ---------------------------------------------------------------- partial products and Z (App. A.5)
+// upstream prover.rs `wires_permutation_partial_products_and_zs`: rows 0..NC = Z, then NC*NP partial products
+std::vector<std::vector<u64>> ref_partial_products(const RCircuit& c, const std::vector<std::vector<u64>>& wires_values,
+                                                   const std::vector<u64>& betas, const std::vector<u64>& gammas) {
   const size_t n = c.n();
   const int NC = c.num_challenges, RW = c.num_routed, NP = c.num_partial_products, Q = c.quotient_degree_factor;
-  const int lde_bits = c.degree_bits + c.rate_bits;
-  const size_t big = (size_t)1 << lde_bits;
   const int n_consts = c.num_constants_total();
-
-  RWitnessResult wr = ref_generate_witness(c, inputs, seed);
-  if (wr.status) {
-    if (msg) *msg = wr.message;
-    return wr.status;
-  }
-  T.witness = now_s() - t0; t0 = now_s();
-  const u64 pih[4] = {0, 0, 0, 0};  // hash_no_pad([]) : no public inputs (src/p3/mod.rs:264 prints [])
-
-  RPolyBatch wires = ref_commit_values(wr.wires, c.rate_bits, c.cap_height);
-  T.wires_commit = now_s() - t0; t0 = now_s();
-
-  RChallenger ch;
-  ch.observe_hash(pre.circuit_digest);
-  ch.observe_hash(RHash{{pih[0], pih[1], pih[2], pih[3]}});
-  ch.observe_cap(wires.tree.cap());
-  std::vector<u64> betas(NC), gammas(NC);
-  for (auto& b : betas) b = ch.challenge();
-  for (auto& g : gammas) g = ch.challenge();
-
-  // partial products and Z (App. A.5)
+  struct { const std::vector<std::vector<u64>>& wires; } wr{wires_values};
   std::vector<u64> subgroup(n);
   {
     u64 g = rf_root_of_unity(c.degree_bits), x = 1;
@@ -409,14 +386,22 @@ int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64
       zs_pp[ci][r] = zrow;
     }
   }
-  T.zs = now_s() - t0; t0 = now_s();
-  RPolyBatch zs_batch = ref_commit_values(zs_pp, c.rate_bits, c.cap_height);
-  T.zs_commit = now_s() - t0; t0 = now_s();
-  ch.observe_cap(zs_batch.tree.cap());
-  std::vector<u64> alphas(NC);
-  for (auto& a : alphas) a = ch.challenge();
+  return zs_pp;
+}
 
-  // quotient polynomials (App. A.6)
+// ---------------------------------------------------------------- quotient polynomials (App. A.6)
+// upstream prover.rs `compute_quotient_polys` + "split up quotient polys": NC * Q coefficient vectors of length n
+std::vector<std::vector<u64>> ref_quotient_chunks(const RCircuit& c, const RPolyBatch& constants_sigmas,
+                                                  const RPolyBatch& wires, const RPolyBatch& zs_batch,
+                                                  const std::vector<u64>& betas, const std::vector<u64>& gammas,
+                                                  const std::vector<u64>& alphas) {
+  const size_t n = c.n();
+  const int NC = c.num_challenges, RW = c.num_routed, NP = c.num_partial_products, Q = c.quotient_degree_factor;
+  const int lde_bits = c.degree_bits + c.rate_bits;
+  const size_t big = (size_t)1 << lde_bits;
+  const int n_consts = c.num_constants_total();
+  const u64 pih[4] = {0, 0, 0, 0};
+  struct { const RPolyBatch& constants_sigmas; } pre{constants_sigmas};
   std::vector<std::vector<u64>> qvals(NC, std::vector<u64>(big));
   {
     const u64 w_big = rf_root_of_unity(lde_bits);
@@ -460,6 +445,140 @@ int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64
     ref_coset_ifft(qvals[k], 7);
     for (int j = 0; j < Q; j++) qchunks.emplace_back(qvals[k].begin() + j * n, qvals[k].begin() + (j + 1) * n);
   }
+  return qchunks;
+}
+
+// ---------------------------------------------------------------- FRI commit phase, PoW, queries (App. A.8)
+// upstream fri/prover.rs `fri_proof`: given the batched polynomial (n extension coefficients) and the
+// transcript, fills fri_caps, final_poly, pow_witness and the query rounds of `out`.  `oracles` (the four
+// initial polynomial batches) may be null: then only the FRI layers are opened.
+int ref_fri_prove(const RFriParams& fp, const std::vector<RE2>& final_poly, RChallenger& ch,
+                  const RPolyBatch* const* oracles, RProof& out, std::vector<size_t>* indices_out, std::string* msg) {
+  const size_t big = final_poly.size() << fp.rate_bits;
+  // commit phase (App. A.8)
+  std::vector<RE2> coeffs(final_poly);
+  coeffs.resize(big, re(0));
+  std::vector<RE2> values(coeffs);
+  ref_coset_fft_ext(values, 7);
+  u64 shift = 7;
+  std::vector<RMerkleTree> fri_trees;
+  std::vector<std::vector<std::vector<u64>>> fri_leaves;
+  std::vector<RE2> fri_betas;
+  for (int arity_bits : fp.arity_bits) {
+    const size_t arity = (size_t)1 << arity_bits;
+    const size_t len = values.size();
+    unsigned lg = 0;
+    while (((size_t)1 << lg) < len) lg++;
+    std::vector<RE2> br(len);
+    for (size_t i = 0; i < len; i++) br[rbits(i, lg)] = values[i];
+    std::vector<std::vector<u64>> leaves(len / arity);
+    for (size_t l = 0; l < leaves.size(); l++)
+      for (size_t k = 0; k < arity; k++) {
+        leaves[l].push_back(br[l * arity + k].a);
+        leaves[l].push_back(br[l * arity + k].b);
+      }
+    RMerkleTree tree = merkle_parallel(leaves, fp.cap_height);
+    ch.observe_cap(tree.cap());
+    out.fri_caps.push_back(tree.cap());
+    fri_trees.push_back(tree);
+    fri_leaves.push_back(leaves);
+    RE2 beta = ch.ext_challenge();
+    fri_betas.push_back(beta);
+    std::vector<RE2> folded(coeffs.size() / arity);
+    for (size_t i = 0; i < folded.size(); i++) {
+      RE2 s = re(0);
+      for (size_t k = arity; k-- > 0;) s = re_add(re_mul(s, beta), coeffs[i * arity + k]);
+      folded[i] = s;
+    }
+    coeffs.swap(folded);
+    shift = rf_pow(shift, arity);
+    values = coeffs;
+    ref_coset_fft_ext(values, shift);
+  }
+  coeffs.resize(coeffs.size() >> fp.rate_bits);
+  out.final_poly = coeffs;
+  for (auto& e : coeffs) ch.observe_ext(e);
+
+  // proof of work: smallest witness whose response has >= pow_bits leading zeros
+  {
+    u64 st[12];
+    memcpy(st, ch.state, sizeof(st));
+    size_t pos = ch.in.size();
+    for (size_t i = 0; i < pos; i++) st[i] = ch.in[i];
+    u64 cand = 0;
+    for (;; cand++) {
+      u64 s2[12];
+      memcpy(s2, st, sizeof(st));
+      s2[pos] = cand;
+      ref_poseidon(s2);
+      if (leading_zeros64(s2[7]) >= fp.pow_bits) break;
+    }
+    out.pow_witness = cand;
+    ch.observe(cand);
+    u64 resp = ch.challenge();
+    if (leading_zeros64(resp) < fp.pow_bits) {
+      if (msg) *msg = "internal: PoW response mismatch";
+      return 7;
+    }
+  }
+  // query rounds
+  out.queries.resize(fp.num_queries);
+  for (auto& q : out.queries) {
+    size_t x_index = (size_t)(ch.challenge() % big);
+    if (indices_out) indices_out->push_back(x_index);
+    for (int o = 0; oracles && o < 4; o++) {
+      q.initial_leaf.push_back(oracles[o]->leaves[x_index]);
+      q.initial_path.push_back(oracles[o]->tree.prove(x_index));
+    }
+    for (size_t l = 0; l < fp.arity_bits.size(); l++) {
+      size_t ci = x_index >> fp.arity_bits[l];
+      std::vector<RE2> evals;
+      for (size_t k = 0; k < fri_leaves[l][ci].size(); k += 2) evals.push_back(RE2{fri_leaves[l][ci][k], fri_leaves[l][ci][k + 1]});
+      q.step_evals.push_back(evals);
+      q.step_path.push_back(fri_trees[l].prove(ci));
+      x_index = ci;
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- prover (App. A.0-A.8)
+int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64 seed, RProof& out, RTimings* tm,
+              std::string* msg, const u64* filler) {
+  RTimings T;
+  double t_start = now_s(), t0 = t_start;
+  const size_t n = c.n();
+  const int NC = c.num_challenges;
+  const int n_consts = c.num_constants_total();
+
+  RWitnessResult wr = ref_generate_witness(c, inputs, seed, filler);
+  if (wr.status) {
+    if (msg) *msg = wr.message;
+    return wr.status;
+  }
+  T.witness = now_s() - t0; t0 = now_s();
+  const u64 pih[4] = {0, 0, 0, 0};  // hash_no_pad([]) : no public inputs (src/p3/mod.rs:264 prints [])
+
+  RPolyBatch wires = ref_commit_values(wr.wires, c.rate_bits, c.cap_height);
+  T.wires_commit = now_s() - t0; t0 = now_s();
+
+  RChallenger ch;
+  ch.observe_hash(pre.circuit_digest);
+  ch.observe_hash(RHash{{pih[0], pih[1], pih[2], pih[3]}});
+  ch.observe_cap(wires.tree.cap());
+  std::vector<u64> betas(NC), gammas(NC);
+  for (auto& b : betas) b = ch.challenge();
+  for (auto& g : gammas) g = ch.challenge();
+
+  std::vector<std::vector<u64>> zs_pp = ref_partial_products(c, wr.wires, betas, gammas);
+  T.zs = now_s() - t0; t0 = now_s();
+  RPolyBatch zs_batch = ref_commit_values(zs_pp, c.rate_bits, c.cap_height);
+  T.zs_commit = now_s() - t0; t0 = now_s();
+  ch.observe_cap(zs_batch.tree.cap());
+  std::vector<u64> alphas(NC);
+  for (auto& a : alphas) a = ch.challenge();
+
+  std::vector<std::vector<u64>> qchunks = ref_quotient_chunks(c, pre.constants_sigmas, wires, zs_batch, betas, gammas, alphas);
   T.quotient = now_s() - t0; t0 = now_s();
   RPolyBatch quot = ref_commit_coeffs(qchunks, c.rate_bits, c.cap_height);
   T.quotient_commit = now_s() - t0; t0 = now_s();
@@ -542,88 +661,10 @@ int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64
     }
     for (size_t k = 0; k + 1 < n; k++) final_poly[k + 1] = acc[k];  // multiply by X
   }
-  // commit phase (App. A.8)
-  std::vector<RE2> coeffs(final_poly);
-  coeffs.resize(big, re(0));
-  std::vector<RE2> values(coeffs);
-  ref_coset_fft_ext(values, 7);
-  u64 shift = 7;
-  std::vector<RMerkleTree> fri_trees;
-  std::vector<std::vector<std::vector<u64>>> fri_leaves;
-  std::vector<RE2> fri_betas;
-  for (int arity_bits : c.arity_bits) {
-    const size_t arity = (size_t)1 << arity_bits;
-    const size_t len = values.size();
-    unsigned lg = 0;
-    while (((size_t)1 << lg) < len) lg++;
-    std::vector<RE2> br(len);
-    for (size_t i = 0; i < len; i++) br[rbits(i, lg)] = values[i];
-    std::vector<std::vector<u64>> leaves(len / arity);
-    for (size_t l = 0; l < leaves.size(); l++)
-      for (size_t k = 0; k < arity; k++) {
-        leaves[l].push_back(br[l * arity + k].a);
-        leaves[l].push_back(br[l * arity + k].b);
-      }
-    RMerkleTree tree = merkle_parallel(leaves, c.cap_height);
-    ch.observe_cap(tree.cap());
-    out.fri_caps.push_back(tree.cap());
-    fri_trees.push_back(tree);
-    fri_leaves.push_back(leaves);
-    RE2 beta = ch.ext_challenge();
-    fri_betas.push_back(beta);
-    std::vector<RE2> folded(coeffs.size() / arity);
-    for (size_t i = 0; i < folded.size(); i++) {
-      RE2 s = re(0);
-      for (size_t k = arity; k-- > 0;) s = re_add(re_mul(s, beta), coeffs[i * arity + k]);
-      folded[i] = s;
-    }
-    coeffs.swap(folded);
-    shift = rf_pow(shift, arity);
-    values = coeffs;
-    ref_coset_fft_ext(values, shift);
-  }
-  coeffs.resize(coeffs.size() >> c.rate_bits);
-  out.final_poly = coeffs;
-  for (auto& e : coeffs) ch.observe_ext(e);
-
-  // proof of work: smallest witness whose response has >= pow_bits leading zeros
   {
-    u64 st[12];
-    memcpy(st, ch.state, sizeof(st));
-    size_t pos = ch.in.size();
-    for (size_t i = 0; i < pos; i++) st[i] = ch.in[i];
-    u64 cand = 0;
-    for (;; cand++) {
-      u64 s2[12];
-      memcpy(s2, st, sizeof(st));
-      s2[pos] = cand;
-      ref_poseidon(s2);
-      if (leading_zeros64(s2[7]) >= c.pow_bits) break;
-    }
-    out.pow_witness = cand;
-    ch.observe(cand);
-    u64 resp = ch.challenge();
-    if (leading_zeros64(resp) < c.pow_bits) {
-      if (msg) *msg = "internal: PoW response mismatch";
-      return 7;
-    }
-  }
-  // query rounds
-  out.queries.resize(c.num_queries);
-  for (auto& q : out.queries) {
-    size_t x_index = (size_t)(ch.challenge() % big);
-    for (int o = 0; o < 4; o++) {
-      q.initial_leaf.push_back(oracles[o]->leaves[x_index]);
-      q.initial_path.push_back(oracles[o]->tree.prove(x_index));
-    }
-    for (size_t l = 0; l < c.arity_bits.size(); l++) {
-      size_t ci = x_index >> c.arity_bits[l];
-      std::vector<RE2> evals;
-      for (size_t k = 0; k < fri_leaves[l][ci].size(); k += 2) evals.push_back(RE2{fri_leaves[l][ci][k], fri_leaves[l][ci][k + 1]});
-      q.step_evals.push_back(evals);
-      q.step_path.push_back(fri_trees[l].prove(ci));
-      x_index = ci;
-    }
+    RFriParams fp{c.degree_bits, c.rate_bits, c.cap_height, c.arity_bits, c.pow_bits, c.num_queries};
+    int st = ref_fri_prove(fp, final_poly, ch, oracles, out, nullptr, msg);
+    if (st) return st;
   }
   T.fri = now_s() - t0;
   T.total = now_s() - t_start;

@@ -55,9 +55,25 @@ size_t ref_proof_words(const RCircuit& c);
 std::vector<u64> ref_proof_flatten(const RCircuit& c, const RProof& p);
 RProof ref_proof_unflatten(const RCircuit& c, const u64* w);
 
+// Stages of the prover, callable on their own (isolated parity tests of the product's p25_partial_products /
+// p25_quotient / p25_fri_prove entry points).
+std::vector<std::vector<u64>> ref_partial_products(const RCircuit& c, const std::vector<std::vector<u64>>& wires_values,
+                                                   const std::vector<u64>& betas, const std::vector<u64>& gammas);
+std::vector<std::vector<u64>> ref_quotient_chunks(const RCircuit& c, const RPolyBatch& constants_sigmas,
+                                                  const RPolyBatch& wires, const RPolyBatch& zs_batch,
+                                                  const std::vector<u64>& betas, const std::vector<u64>& gammas,
+                                                  const std::vector<u64>& alphas);
+struct RFriParams {
+  int degree_bits, rate_bits, cap_height;
+  std::vector<int> arity_bits;
+  int pow_bits, num_queries;
+};
+int ref_fri_prove(const RFriParams& fp, const std::vector<RE2>& final_poly, RChallenger& ch,
+                  const RPolyBatch* const* oracles, RProof& out, std::vector<size_t>* indices_out, std::string* msg);
+
 // returns 0 or a p25 status code (4 witness conflict, 5 generators not run, 6 opening in subgroup)
 int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64 seed, RProof& out,
-              RTimings* tm, std::string* msg);
+              RTimings* tm, std::string* msg, const u64* filler = nullptr);
 // returns 0 if the proof verifies, else a non-zero code with a message
 int ref_verify(const RCircuit& c, const RHash& circuit_digest, const std::vector<RHash>& constants_sigmas_cap,
                const RProof& p, std::string* msg);

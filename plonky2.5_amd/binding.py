@@ -7,7 +7,7 @@ import numpy as np
 __all__ = ["P25Error", "lib", "lib_path", "device_init", "poseidon_permute", "poseidon2_permute",
            "merkle_commit", "merkle_tree_words", "lde_commit", "EXPORTED_SYMBOLS", "P",
            "P3Config", "Circuit", "p3_proof_from_json", "Timings", "p3_prove_fibonacci", "p3_inputs_to_json",
-           "Air", "p3_prove_air"]
+           "Air", "p3_prove_air", "transcript", "fri_prove"]
 
 P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -101,7 +101,7 @@ class CircuitInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("degree_bits", "num_rows_used", "num_wires", "num_routed_wires",
                                           "num_inputs", "num_generators", "num_gate_types", "num_selectors",
                                           "num_constants_sigmas", "num_gate_constraints", "proof_words",
-                                          "witness_levels", "witness_slots", "reserved")]
+                                          "witness_levels", "witness_slots", "num_random_fill")]
 
 
 class Timings(C.Structure):
@@ -137,10 +137,16 @@ EXPORTED_SYMBOLS = {
     "p25_circuit_gate_counts": (i32, [vp, vp, sz, C.c_char_p, sz]),
     "p25_circuit_digest": (i32, [vp, vp, vp]),
     "p25_prove_batch": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
+    "p25_prove_batch_filler": (i32, [vp, vp, sz, vp, vp, sz, vp]),
     "p25_prove_batch_dev": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
     "p25_circuit_sync": (i32, [vp]),
     "p25_circuit_kernel_stats": (i32, [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "p25_witness": (i32, [vp, vp, C.c_uint64, vp, C.POINTER(i32)]),
+    "p25_transcript": (i32, [vp, vp, vp, sz, vp]),
+    "p25_partial_products": (i32, [vp, vp, vp, vp, vp]),
+    "p25_quotient": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+    "p25_fri_prove_words": (sz, [ui, ui, ui, vp, sz, ui]),
+    "p25_fri_prove": (i32, [vp, ui, ui, ui, vp, sz, ui, ui, vp, sz, vp, sz, C.POINTER(i32)]),
     "p25_p3_proof_from_json": (i32, [C.c_char_p, sz, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
     "p25_proof_to_json": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
     "p25_p3_prove_fibonacci": (i32, [i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
@@ -220,6 +226,36 @@ def lde_commit(polys, rate_bits, cap_height, from_coeffs=False, want_lde=True):
     _check(lib().p25_lde_commit(_ptr(a), log_n, n_polys, int(from_coeffs), rate_bits, cap_height,
                                 _ptr(coeffs), _ptr(lde), _ptr(cap)))
     return coeffs, lde, cap
+
+
+def transcript(segments):
+    """Challenger script: segments = [(words_to_observe, n_challenges), ...] -> all challenges drawn, in order
+    (upstream iop/challenger.rs)."""
+    obs = np.ascontiguousarray(np.concatenate([np.asarray(w, dtype=np.uint64).ravel() for w, _ in segments]
+                                              + [np.zeros(0, dtype=np.uint64)]))
+    lens = np.array([np.asarray(w).size for w, _ in segments], dtype=np.uint32)
+    nch = np.array([k for _, k in segments], dtype=np.uint32)
+    out = np.zeros(int(nch.sum()), dtype=np.uint64)
+    _check(lib().p25_transcript(_ptr(obs), _ptr(lens), _ptr(nch), len(segments), _ptr(out)))
+    return out
+
+
+def fri_prove(coeffs, rate_bits, cap_height, arity_bits, pow_bits, num_queries, seed):
+    """FRI on one batched polynomial, coeffs[2][2^log_n] (extension components).  Returns (flat output, status);
+    layout in include/p25.h (p25_fri_prove)."""
+    a = _u64(coeffs)
+    assert a.ndim == 2 and a.shape[0] == 2
+    log_n = int(a.shape[1]).bit_length() - 1
+    ar = np.array(arity_bits, dtype=np.int32)
+    sd = _u64(seed)
+    n = lib().p25_fri_prove_words(log_n, rate_bits, cap_height, _ptr(ar), len(ar), num_queries)
+    if n == 0:
+        raise P25Error(1, "bad FRI shape")
+    out = np.zeros(n, dtype=np.uint64)
+    st = i32(0)
+    _check(lib().p25_fri_prove(_ptr(a), log_n, rate_bits, cap_height, _ptr(ar), len(ar), pow_bits, num_queries,
+                               _ptr(sd), sd.size, _ptr(out), out.size, C.byref(st)))
+    return out, st.value
 
 
 def p3_proof_from_json(text):
@@ -360,6 +396,25 @@ class Circuit:
         _check(lib().p25_witness(self._h, _ptr(inp), seed, _ptr(wires), C.byref(st)))
         return wires, st.value
 
+    def partial_products(self, wires, betas, gammas):
+        """Z and partial products from witness values: wires [num_wires][n] -> [NC*(1+NP)][n]."""
+        w, b, g = _u64(wires), _u64(betas), _u64(gammas)
+        n = 1 << int(self.info.degree_bits)
+        assert w.shape == (int(self.info.num_wires), n) and b.size == 2 and g.size == 2
+        npp = -(-int(self.info.num_routed_wires) // 8) - 1
+        out = np.zeros((2 * (1 + npp), n), dtype=np.uint64)
+        _check(lib().p25_partial_products(self._h, _ptr(w), _ptr(b), _ptr(g), _ptr(out)))
+        return out
+
+    def quotient(self, wires, zs_pp, betas, gammas, alphas):
+        """Quotient chunk coefficients [NC*8][n] from witness and Z/partial-product values."""
+        w, z, b, g, a = _u64(wires), _u64(zs_pp), _u64(betas), _u64(gammas), _u64(alphas)
+        n = 1 << int(self.info.degree_bits)
+        assert w.shape == (int(self.info.num_wires), n) and z.shape[1] == n
+        out = np.zeros((16, n), dtype=np.uint64)
+        _check(lib().p25_quotient(self._h, _ptr(w), _ptr(z), _ptr(b), _ptr(g), _ptr(a), _ptr(out)))
+        return out
+
     def prove(self, inputs, seeds=None, timings=False):
         """inputs: [n_proofs][num_inputs].  Returns (proofs [n_proofs][proof_words], statuses[, timings])."""
         inp = _u64(inputs)
@@ -375,6 +430,16 @@ class Circuit:
         _check(lib().p25_prove_batch(self._h, _ptr(inp), n, _ptr(sd), _ptr(proofs), pw, _ptr(st),
                                      C.byref(tm) if timings else None))
         return (proofs, st, tm) if timings else (proofs, st)
+
+    def prove_filler(self, inputs, filler):
+        """prove() with explicit RandomValueGenerator values filler[n_proofs][num_random_fill] instead of seeds."""
+        inp = _u64(inputs).reshape(-1, int(self.info.num_inputs))
+        f = _u64(filler).reshape(inp.shape[0], int(self.info.num_random_fill))
+        pw = int(self.info.proof_words)
+        proofs = np.zeros((inp.shape[0], pw), dtype=np.uint64)
+        st = np.zeros(inp.shape[0], dtype=np.int32)
+        _check(lib().p25_prove_batch_filler(self._h, _ptr(inp), inp.shape[0], _ptr(f), _ptr(proofs), pw, _ptr(st)))
+        return proofs, st
 
     def prove_dev(self, d_inputs, n_proofs, d_seeds, d_proofs, proof_stride, d_status, timings=None):
         """Device-resident batch (raw device addresses, e.g. torch tensor .data_ptr())."""

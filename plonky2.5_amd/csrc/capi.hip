@@ -401,6 +401,7 @@ p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out) {
     if (!c->wp_info) c->wp_info.reset(new p25::WitnessProgram(p25::build_witness_program(k)));
     out->witness_levels = c->wp_info->level_start.size() - 1;
     out->witness_slots = c->wp_info->num_slots;
+    out->num_random_fill = c->wp_info->num_random_fill;
     return P25_OK;
   });
 }
@@ -450,6 +451,15 @@ p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proo
     return P25_OK;
   });
 }
+p25_status p25_prove_batch_filler(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* filler,
+                                  uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status) {
+  return guarded([&]() -> p25_status {
+    if (!c || !inputs || !filler || !proofs_out || !per_proof_status) throw std::invalid_argument("null argument");
+    if (!n_proofs) return P25_OK;
+    c->device().prove_batch(inputs, n_proofs, nullptr, proofs_out, proof_stride_words, per_proof_status, nullptr, filler);
+    return P25_OK;
+  });
+}
 p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t n_proofs, const uint64_t* d_seeds,
                                uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status, p25_timings* timings) {
   return guarded([&]() -> p25_status {
@@ -485,6 +495,77 @@ p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, ui
     if (!c || !inputs || !wires_out) throw std::invalid_argument("null argument");
     int32_t st = c->device().witness(inputs, seed, wires_out);
     if (proof_status) *proof_status = st;
+    return P25_OK;
+  });
+}
+
+p25_status p25_transcript(const uint64_t* observe, const uint32_t* seg_len, const uint32_t* n_challenges,
+                          size_t n_segments, uint64_t* challenges_out) {
+  return guarded([&]() -> p25_status {
+    if ((n_segments && (!seg_len || !n_challenges)) || !challenges_out) throw std::invalid_argument("null argument");
+    size_t n_obs = 0;
+    for (size_t k = 0; k < n_segments; k++) n_obs += seg_len[k];
+    if (n_obs && !observe) throw std::invalid_argument("null argument");
+    p25::transcript_script(observe, seg_len, n_challenges, n_segments, challenges_out);
+    return P25_OK;
+  });
+}
+p25_status p25_partial_products(p25_circuit* c, const uint64_t* wires, const uint64_t* betas, const uint64_t* gammas,
+                                uint64_t* out) {
+  return guarded([&]() -> p25_status {
+    if (!c || !wires || !betas || !gammas || !out) throw std::invalid_argument("null argument");
+    c->device().partial_products(wires, betas, gammas, out);
+    return P25_OK;
+  });
+}
+p25_status p25_quotient(p25_circuit* c, const uint64_t* wires, const uint64_t* zs_pp, const uint64_t* betas,
+                        const uint64_t* gammas, const uint64_t* alphas, uint64_t* out) {
+  return guarded([&]() -> p25_status {
+    if (!c || !wires || !zs_pp || !betas || !gammas || !alphas || !out) throw std::invalid_argument("null argument");
+    c->device().quotient(wires, zs_pp, betas, gammas, alphas, out);
+    return P25_OK;
+  });
+}
+static bool fri_shape_from_c(unsigned log_n, unsigned rate_bits, unsigned cap_height, const int32_t* arity_bits,
+                             size_t n_layers, unsigned pow_bits, unsigned num_queries, p25::FriShape& sh) {
+  if (log_n < 1 || log_n > 22 || rate_bits > 3 || cap_height > 16 || n_layers > 8 || (n_layers && !arity_bits) ||
+      num_queries < 1 || num_queries > 64 || pow_bits > 32)
+    return false;
+  sh.log_n = (int)log_n;
+  sh.rate_bits = (int)rate_bits;
+  sh.cap_height = cap_height;
+  sh.arity_bits.assign(arity_bits, arity_bits + n_layers);
+  sh.pow_bits = (int)pow_bits;
+  sh.num_queries = (int)num_queries;
+  int deg = (int)log_n, bits = (int)(log_n + rate_bits);
+  if (bits < (int)cap_height) return false;
+  for (int a : sh.arity_bits) {
+    if (a < 1 || a > 8) return false;
+    deg -= a;
+    bits -= a;
+    if (deg < 0 || bits < (int)cap_height) return false;
+  }
+  return true;
+}
+size_t p25_fri_prove_words(unsigned log_n, unsigned rate_bits, unsigned cap_height, const int32_t* arity_bits,
+                           size_t n_layers, unsigned num_queries) {
+  p25::FriShape sh;
+  if (!fri_shape_from_c(log_n, rate_bits, cap_height, arity_bits, n_layers, 0, num_queries, sh)) return 0;
+  return p25::fri_prove_words(sh);
+}
+p25_status p25_fri_prove(const uint64_t* coeffs, unsigned log_n, unsigned rate_bits, unsigned cap_height,
+                         const int32_t* arity_bits, size_t n_layers, unsigned pow_bits, unsigned num_queries,
+                         const uint64_t* seed, size_t n_seed, uint64_t* out, size_t out_cap, p25_status* status_out) {
+  return guarded([&]() -> p25_status {
+    if (!coeffs || !out || !status_out || (n_seed && !seed)) throw std::invalid_argument("null argument");
+    p25::FriShape sh;
+    if (!fri_shape_from_c(log_n, rate_bits, cap_height, arity_bits, n_layers, pow_bits, num_queries, sh))
+      throw std::invalid_argument("p25_fri_prove: bad shape");
+    if (out_cap < p25::fri_prove_words(sh)) throw std::invalid_argument("buffer too small");
+    std::lock_guard<std::mutex> lk(g_primitives_mutex);
+    int32_t st = 0;
+    p25::fri_prove_standalone(tables(), coeffs, sh, seed, n_seed, out, &st);
+    *status_out = st;
     return P25_OK;
   });
 }

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_queries(QueryArgs a) {
   size_t x = (size_t)(a.chal[CH_QUERIES + q] & (big - 1));  // challenge mod 2^lde_bits
   u64* out = a.proof + a.query_offset + (size_t)q * a.query_stride;
   const uint32_t path_len = a.lde_bits - a.cap_height;
-  for (int o = 0; o < 4; o++) {
+  for (uint32_t o = 0; o < a.n_oracles; o++) {
     for (uint32_t c = t; c < a.oracle_width[o]; c += nt) out[c] = a.oracle_lde[o][(size_t)c * big + x];
     out += a.oracle_width[o];
     for (uint32_t e = t; e < 4 * path_len; e += nt) {

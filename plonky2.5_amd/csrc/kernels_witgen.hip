@@ -51,7 +51,8 @@ __device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* 
                                                   const uint32_t* __restrict__ args, uint32_t g_begin,
                                                   uint32_t g_count, u64* __restrict__ vals, size_t B,
                                                   uint32_t n_proofs, const u64* __restrict__ seeds,
-                                                  uint32_t* __restrict__ status, int skip_poseidon2) {
+                                                  uint32_t* __restrict__ status, int skip_poseidon2,
+                                                  const u64* __restrict__ filler, uint32_t n_filler) {
   size_t idx = (size_t)block * blockDim.x + threadIdx.x;
   if (idx >= (size_t)g_count * n_proofs) return;
   const uint32_t gi = g_begin + (uint32_t)(idx / n_proofs);
@@ -66,7 +67,7 @@ __device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* 
       emit(0, g.c0);
       break;
     case GEN_RANDOM:
-      emit(0, random_fill(seeds[p], g.aux));
+      emit(0, filler ? filler[(size_t)p * n_filler + g.c1] : random_fill(seeds[p], g.aux));
       break;
     case GEN_ARITHMETIC:
       emit(0, gl::add(gl::mul(gl::mul(d(0), d(1)), g.c0), gl::mul(d(2), g.c1)));
@@ -193,8 +194,10 @@ __global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__
                                                       const uint32_t* __restrict__ args, uint32_t g_begin,
                                                       uint32_t g_count, u64* __restrict__ vals, size_t B,
                                                       uint32_t n_proofs, const u64* __restrict__ seeds,
-                                                      uint32_t* __restrict__ status, int skip_poseidon2) {
-  witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, skip_poseidon2);
+                                                      uint32_t* __restrict__ status, int skip_poseidon2,
+                                                      const u64* __restrict__ filler, uint32_t n_filler) {
+  witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, skip_poseidon2, filler,
+                    n_filler);
 }
 
 // Poseidon2 generators of one level, one 16-lane group per (generator, proof): used for small batches,
@@ -232,10 +235,11 @@ __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __rest
                                                             uint32_t g_count, uint32_t p2_begin, uint32_t p2_count,
                                                             uint32_t nb_level, u64* __restrict__ vals, size_t B,
                                                             uint32_t n_proofs, const u64* __restrict__ seeds,
-                                                            uint32_t* __restrict__ status) {
+                                                            uint32_t* __restrict__ status,
+                                                            const u64* __restrict__ filler, uint32_t n_filler) {
   __shared__ u64 k_lds[coop::P2_LDS_WORDS];
   if (blockIdx.x < nb_level) {
-    witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, 1);
+    witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, 1, filler, n_filler);
   } else {
     coop::stage_poseidon2_rc(k_lds);
     witgen_p2_coop_body(blockIdx.x - nb_level, k_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
@@ -287,7 +291,7 @@ __global__ void k_witgen_fill_wires(const u64* __restrict__ vals, size_t B, uint
 }
 
 void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u64* d_seeds, u64* d_vals,
-                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st) {
+                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st, const u64* d_filler) {
   size_t tot = (size_t)(wp.n_inputs + 1) * n_proofs;
   hipLaunchKernelGGL(k_witgen_set_inputs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_inputs,
                      wp.d_input_slots, wp.d_input_first, wp.n_inputs, d_vals, B, n_proofs, d_status);
@@ -300,12 +304,13 @@ void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u6
     const int coop_p2 = (n_proofs < 16 && p2c > 0) ? 1 : 0;
     if (!coop_p2) {
       hipLaunchKernelGGL(k_witgen_level, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, wp.d_gens, wp.d_args,
-                         b, cnt, d_vals, B, n_proofs, d_seeds, d_status, 0);
+                         b, cnt, d_vals, B, n_proofs, d_seeds, d_status, 0, d_filler, wp.num_random_fill);
     } else {
       const unsigned nb1 = p2c < cnt ? (unsigned)((th + 255) / 256) : 0;
       const size_t th2 = (size_t)p2c * n_proofs * coop::GROUP;
       hipLaunchKernelGGL(k_witgen_level_fused, dim3(nb1 + (unsigned)((th2 + 255) / 256)), dim3(256), 0, st, wp.d_gens,
-                         wp.d_args, b, cnt, wp.level_p2_begin[l], p2c, nb1, d_vals, B, n_proofs, d_seeds, d_status);
+                         wp.d_args, b, cnt, wp.level_p2_begin[l], p2c, nb1, d_vals, B, n_proofs, d_seeds, d_status, d_filler,
+                         wp.num_random_fill);
     }
   }
 }

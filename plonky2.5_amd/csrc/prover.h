@@ -33,6 +33,28 @@ struct DevMem {  // owning device allocation
   DevMem& operator=(const DevMem&) = delete;
 };
 
+// FRI working set and shape: shared by the whole-proof pipeline and the standalone p25_fri_prove entry point.
+struct FriWork {
+  DevMem coeffs[9], vals[9], tree[9];
+  void alloc(int log_n, int rate_bits, unsigned cap_height, const std::vector<int>& arity_bits);
+};
+struct FriShape {
+  int log_n, rate_bits;
+  unsigned cap_height;
+  std::vector<int> arity_bits;
+  int pow_bits, num_queries;
+};
+struct FriOffsets {  // word offsets into the flat proof buffer
+  size_t caps, final_poly, pow_witness, queries, query_stride;
+};
+void fri_commit_pow_query(NttTables& tables, FriWork& w, const FriShape& sh, Transcript* tr, u64* chal, QueryArgs qy,
+                          u64* d_proof, const FriOffsets& fo, uint32_t* d_status, hipStream_t st, bool single_proof);
+
+void transcript_script(const u64* obs, const uint32_t* seg_len, const uint32_t* n_chal, size_t n_seg, u64* out);
+size_t fri_prove_words(const FriShape& sh);
+void fri_prove_standalone(NttTables& tables, const u64* coeffs, const FriShape& sh, const u64* seed, size_t n_seed,
+                          u64* out, int32_t* status_out);
+
 struct PhaseTimes {  // milliseconds, device time measured with HIP events on the proving stream
   float witness = 0, wires_commit = 0, zs_pp = 0, zs_commit = 0, quotient = 0, quotient_commit = 0, openings = 0,
         fri = 0, total = 0;
@@ -52,17 +74,23 @@ class DeviceCircuit {
   // Proves n_proofs independent inputs.  inputs[n_proofs][num_inputs] (host), seeds (host, nullable),
   // proofs_out[n_proofs][proof_stride] (host), statuses[n_proofs].  Returns first non-zero HIP-level
   // failure as exception; per-proof failures go to statuses.
+  // filler (nullable): explicit RandomValueGenerator values [n_proofs][num_random_fill()] replacing the seeds
   void prove_batch(const u64* inputs, size_t n_proofs, const u64* seeds, u64* proofs_out, size_t proof_stride,
-                   int32_t* statuses, PhaseTimes* times);
+                   int32_t* statuses, PhaseTimes* times, const u64* filler = nullptr);
+  uint32_t num_random_fill() const { return wp_.num_random_fill; }
   // debug / parity: full witness of one input -> wires[num_wires][n] (host)
   int32_t witness(const u64* inputs, u64 seed, u64* wires_out);
 
   // Device-resident API used by bench.py: inputs already in HBM ([n_proofs][num_inputs]), proofs
   // written to a device buffer; asynchronous on the internal stream until sync().
   void prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs, size_t proof_stride,
-                       uint32_t* d_status, PhaseTimes* times);
+                       uint32_t* d_status, PhaseTimes* times, const u64* d_filler = nullptr);
   void sync();
   hipStream_t stream() const { return stream_; }
+  // Isolated stages (host buffers; parity tests of SURVEY 8a7 / 8a8 through p25_partial_products / p25_quotient):
+  // wires[num_wires][n] -> out[NC*(1+NP)][n];  wires + zs_pp values -> out[NC*8][n] quotient chunk coefficients
+  void partial_products(const u64* wires, const u64* betas, const u64* gammas, u64* out);
+  void quotient(const u64* wires, const u64* zs_pp, const u64* betas, const u64* gammas, const u64* alphas, u64* out);
   // Dominant-kernel accounting for bench.py's roofline line: HIP events bracket every launch of the
   // wires leaf-sponge kernel (k_hash_leaves over the 135-column LDE) on the proving stream.
   void kernel_stats_enable(bool on) { kstats_on_ = on; }
@@ -72,6 +100,9 @@ class DeviceCircuit {
  private:
   struct Ctx;  // per-proof working set
   void prove_one(Ctx& cx, const u64* d_vals, size_t B, uint32_t p, u64* d_proof, uint32_t* d_status, PhaseTimes* t);
+  void enqueue_partial_products(Ctx& cx, hipStream_t st);
+  void enqueue_quotient(Ctx& cx, hipStream_t st);
+  void set_challenges(Ctx& cx, const u64* betas, const u64* gammas, const u64* alphas);
   size_t ctx_bytes() const;
   void ensure_ctx(size_t count);
   void ensure_vals(size_t batch);

@@ -85,13 +85,86 @@ __global__ void k_finish(const u64* chal, int pow_bits, u64* proof_pow, uint32_t
   if (w == ~0ull || __clzll((long long)chal[CH_POW_RESPONSE]) < pow_bits) set_status(status, 7);
 }
 
+// ---------------------------------------------------------------- FRI (upstream fri/prover.rs `fri_proof`)
+void FriWork::alloc(int log_n, int rate_bits, unsigned cap_height, const std::vector<int>& arity_bits) {
+  size_t m = (size_t)1 << log_n;
+  const size_t nl = arity_bits.size();
+  if (nl > 8) throw std::invalid_argument("too many FRI layers");
+  for (size_t l = 0; l <= nl; l++) {
+    coeffs[l] = DevMem(2 * m);
+    if (l < nl) {
+      size_t nvals = m << rate_bits;
+      vals[l] = DevMem(2 * nvals);
+      tree[l] = DevMem(merkle_tree_words(nvals >> arity_bits[l], cap_height));
+      m >>= arity_bits[l];
+    }
+  }
+}
+
+// Commit phase ("fold codewords in the commitment phase"), "find proof-of-work witness", query rounds.
+// In: the batched polynomial's coefficients in w.coeffs[0] (components a | b, n each), the transcript, and the
+// initial-oracle part of `qy` (n_oracles may be 0).  Out: caps, final polynomial, PoW witness and query openings
+// in the flat proof at the offsets of `fo`; betas / PoW / query challenges in the challenge block.
+void fri_commit_pow_query(NttTables& tables, FriWork& w, const FriShape& sh, Transcript* tr, u64* chal, QueryArgs qy,
+                          u64* d_proof, const FriOffsets& fo, uint32_t* d_status, hipStream_t st, bool single_proof) {
+  const size_t capw = (size_t)4 << sh.cap_height;
+  auto d2d = [&](u64* dst, const u64* src, size_t words) {
+    P25_HIP(hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToDevice, st));
+  };
+  size_t m = (size_t)1 << sh.log_n;
+  int log_m = sh.log_n;
+  u64 shift = gl::GENERATOR;
+  const size_t nl = sh.arity_bits.size();
+  for (size_t l = 0; l < nl; l++) {
+    const int ab = sh.arity_bits[l];
+    const size_t nvals = m << sh.rate_bits;
+    // values of the current polynomial on shift*<w>, bit-reversed positions, components a | b
+    ntt_lde_bitrev(tables, w.coeffs[l].p, m, w.vals[l].p, nvals, log_m, sh.rate_bits, 2, shift, st);
+    const size_t n_leaves = nvals >> ab;
+    launch_fri_leaf_hash(w.vals[l].p, w.vals[l].p + nvals, (uint32_t)n_leaves, ab, w.tree[l].p, st, single_proof);
+    launch_tree_from_digests(w.tree[l].p, n_leaves, sh.cap_height, st, single_proof);
+    const size_t ltw = merkle_tree_words(n_leaves, sh.cap_height);
+    const u64* cap = w.tree[l].p + ltw - capw;
+    d2d(d_proof + fo.caps + l * capw, cap, capw);
+    launch_transcript(tr, 0, cap, (uint32_t)capw, chal + CH_FRI_BETAS + 2 * l, 2, st);
+    launch_fri_fold(w.coeffs[l].p, w.coeffs[l].p + m, (uint32_t)(m >> ab), ab, chal + CH_FRI_BETAS + 2 * l,
+                    w.coeffs[l + 1].p, w.coeffs[l + 1].p + (m >> ab), st);
+    qy.arity_bits[l] = ab;
+    qy.layer_va[l] = w.vals[l].p;
+    qy.layer_vb[l] = w.vals[l].p + nvals;
+    qy.layer_tree[l] = w.tree[l].p;
+    shift = gl::pow(shift, (u64)1 << ab);
+    m >>= ab;
+    log_m -= ab;
+  }
+  // final polynomial (the coefficients that survive truncation by the rate)
+  hipLaunchKernelGGL(k_interleave, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w.coeffs[nl].p,
+                     w.coeffs[nl].p + m, (uint32_t)m, d_proof + fo.final_poly);
+  launch_transcript(tr, 0, d_proof + fo.final_poly, (uint32_t)(2 * m), chal, 0, st);
+  qy.n_layers = (uint32_t)nl;
+  // "find proof-of-work witness"
+  launch_pow_search(tr, sh.pow_bits, chal + CH_POW_WITNESS, st);
+  launch_transcript(tr, 0, chal + CH_POW_WITNESS, 1, chal + CH_POW_RESPONSE, 1 + sh.num_queries, st);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, chal, sh.pow_bits, d_proof + fo.pow_witness, d_status);
+  // query rounds
+  qy.chal = chal;
+  qy.num_queries = sh.num_queries;
+  qy.lde_bits = sh.log_n + sh.rate_bits;
+  qy.cap_height = sh.cap_height;
+  qy.proof = d_proof;
+  qy.query_offset = (uint32_t)fo.queries;
+  qy.query_stride = (uint32_t)fo.query_stride;
+  launch_queries(qy, st);
+}
+
 // ---------------------------------------------------------------- per-proof working set
 struct DeviceCircuit::Ctx {
   DevMem wires_vals, wires_coeffs, tmp, wires_lde, wires_tree;
   DevMem zs_vals, zs_coeffs, zs_lde, zs_tree, zpp_chunk, zpp_tot, zpp_btot;
   DevMem q_vals, q_tmp, q_coeffs, q_lde, q_tree;
   DevMem transcript, chal, alpha_pows, eval_pows;
-  DevMem fri_comp, fri_scan, fri_coeffs[9], fri_vals[9], fri_tree[9];
+  DevMem fri_comp, fri_scan;
+  FriWork fri;
   DevMem proof, status;
   hipEvent_t ev[12];
   hipStream_t st = nullptr;
@@ -145,6 +218,7 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
   }
   wp_.n_inputs = (uint32_t)wp.input_slots.size();
   wp_.num_slots = wp.num_slots;
+  wp_.num_random_fill = wp.num_random_fill;
   wp_.n_wire_elems = wp.wire_slot_cm.size();
 
   // constants_sigmas commitment (PolynomialBatch::from_values) -- once per circuit
@@ -264,17 +338,7 @@ void DeviceCircuit::ensure_ctx(size_t count) {
   x.fri_comp = DevMem(4 * n);
   size_t total_polys = layout_.oracle_width[0] + layout_.oracle_width[1] + layout_.oracle_width[2] + layout_.oracle_width[3];
   x.fri_scan = DevMem(2 * (total_polys + 1) + 8 * (n + 1) + 4 * ((n + 255) / 256) + 64);
-  size_t m = n;
-  const size_t nl = c_.fri_reduction_arity_bits.size();
-  for (size_t l = 0; l <= nl; l++) {
-    x.fri_coeffs[l] = DevMem(2 * m);
-    if (l < nl) {
-      size_t vals = m << c_.cfg.rate_bits;
-      x.fri_vals[l] = DevMem(2 * vals);
-      x.fri_tree[l] = DevMem(merkle_tree_words(vals >> c_.fri_reduction_arity_bits[l], c_.cfg.cap_height));
-      m >>= c_.fri_reduction_arity_bits[l];
-    }
-  }
+  x.fri.alloc(c_.degree_bits, c_.cfg.rate_bits, c_.cfg.cap_height, c_.fri_reduction_arity_bits);
   x.proof = DevMem(layout_.total);
   x.status = DevMem(1);
   for (auto& e : x.ev) P25_HIP(hipEventCreate(&e));
@@ -319,7 +383,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   const size_t n = c_.degree(), B = big();
   const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;
   const int nz = NC * (1 + NP), nq = NC * c_.cfg.max_quotient_degree_factor;
-  const int db = c_.degree_bits, rb = c_.cfg.rate_bits, lde_bits = db + rb;
+  const int db = c_.degree_bits, rb = c_.cfg.rate_bits;
   const unsigned cap_h = c_.cfg.cap_height;
   const size_t capw = (size_t)4 << cap_h;
   const size_t tw = merkle_tree_words(B, cap_h);
@@ -362,23 +426,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   launch_transcript(tr, 0, wires_cap, (uint32_t)capw, chal + CH_BETAS, 2 * NC, st);  // betas, gammas
   mark();  // 2
   // "compute partial products"
-  {
-    ZppArgs za;
-    za.wires = x.wires_vals.p;
-    za.sigmas = cs_vals_.p + (size_t)(c_.num_selectors + c_.cfg.num_constants) * n;
-    za.pow_n = tables_.pow_table(db, false);
-    za.k_is = k_is_.p;
-    za.chal = chal;
-    za.chunk = x.zpp_chunk.p;
-    za.tot = x.zpp_tot.p;
-    za.block_tot = x.zpp_btot.p;
-    za.out = x.zs_vals.p;
-    za.n = (uint32_t)n;
-    za.num_routed = c_.cfg.num_routed_wires;
-    za.num_partial_products = NP;
-    za.num_challenges = NC;
-    launch_zpp(za, st);
-  }
+  enqueue_partial_products(x, st);
   mark();  // 3
   // "commit to partial products, Z's"
   ntt_inverse(tables_, x.zs_vals.p, n, false, x.tmp.p, n, x.zs_coeffs.p, n, db, nz, 1, st);
@@ -389,18 +437,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   launch_transcript(tr, 0, zs_cap, (uint32_t)capw, chal + CH_ALPHAS, NC, st);
   mark();  // 4
   // "compute quotient polys"
-  launch_alpha_pows(chal, x.alpha_pows.p, st);
-  {
-    QuotientArgs qa = qa_proto_;
-    qa.wires_lde = x.wires_lde.p;
-    qa.zs_lde = x.zs_lde.p;
-    qa.chal = chal;
-    qa.alpha_pows = x.alpha_pows.p;
-    qa.out = x.q_vals.p;
-    launch_quotient(qa, st);
-  }
-  // coset iNTT of the 2 value vectors (stored at bit-reversed positions) -> 8n coefficients each
-  ntt_inverse(tables_, x.q_vals.p, B, true, x.q_tmp.p, B, x.q_coeffs.p, B, lde_bits, NC, gl::GENERATOR, st);
+  enqueue_quotient(x, st);
   mark();  // 5
   // "split up quotient polys" (chunks of n are contiguous: [NC][8][n] == [16][n]) + "commit to quotient polys"
   ntt_lde_bitrev(tables_, x.q_coeffs.p, n, x.q_lde.p, B, db, rb, nq, gl::GENERATOR, st);
@@ -437,66 +474,26 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
     fa.g = g;
     fa.comp = x.fri_comp.p;
     fa.scan_tmp = x.fri_scan.p;
-    fa.final_a = x.fri_coeffs[0].p;
-    fa.final_b = x.fri_coeffs[0].p + n;
+    fa.final_a = x.fri.coeffs[0].p;
+    fa.final_b = x.fri.coeffs[0].p + n;
     launch_fri_combine(fa, st);
   }
-  // commit phase
-  QueryArgs qy;
-  memset(&qy, 0, sizeof(qy));
+  // commit phase, PoW, query rounds
   {
-    size_t m = n;
-    int log_m = db;
-    u64 shift = gl::GENERATOR;
-    const size_t nl = c_.fri_reduction_arity_bits.size();
-    for (size_t l = 0; l < nl; l++) {
-      const int ab = c_.fri_reduction_arity_bits[l];
-      const size_t vals = m << rb;
-      // values of the current polynomial on shift*<w>, bit-reversed positions, components a | b
-      ntt_lde_bitrev(tables_, x.fri_coeffs[l].p, m, x.fri_vals[l].p, vals, log_m, rb, 2, shift, st);
-      const size_t n_leaves = vals >> ab;
-      launch_fri_leaf_hash(x.fri_vals[l].p, x.fri_vals[l].p + vals, (uint32_t)n_leaves, ab, x.fri_tree[l].p, st, single_proof_);
-      launch_tree_from_digests(x.fri_tree[l].p, n_leaves, cap_h, st, single_proof_);
-      const size_t ltw = merkle_tree_words(n_leaves, cap_h);
-      const u64* cap = x.fri_tree[l].p + ltw - capw;
-      d2d(d_proof + L.fri_caps + l * capw, cap, capw);
-      launch_transcript(tr, 0, cap, (uint32_t)capw, chal + CH_FRI_BETAS + 2 * l, 2, st);
-      launch_fri_fold(x.fri_coeffs[l].p, x.fri_coeffs[l].p + m, (uint32_t)(m >> ab), ab, chal + CH_FRI_BETAS + 2 * l,
-                      x.fri_coeffs[l + 1].p, x.fri_coeffs[l + 1].p + (m >> ab), st);
-      qy.arity_bits[l] = ab;
-      qy.layer_va[l] = x.fri_vals[l].p;
-      qy.layer_vb[l] = x.fri_vals[l].p + vals;
-      qy.layer_tree[l] = x.fri_tree[l].p;
-      shift = gl::pow(shift, (u64)1 << ab);
-      m >>= ab;
-      log_m -= ab;
+    QueryArgs qy;
+    memset(&qy, 0, sizeof(qy));
+    const u64* ldes[4] = {cs_lde_.p, x.wires_lde.p, x.zs_lde.p, x.q_lde.p};
+    const u64* trees[4] = {cs_tree_.p, x.wires_tree.p, x.zs_tree.p, x.q_tree.p};
+    qy.n_oracles = 4;
+    for (int k = 0; k < 4; k++) {
+      qy.oracle_lde[k] = ldes[k];
+      qy.oracle_tree[k] = trees[k];
+      qy.oracle_width[k] = L.oracle_width[k];
     }
-    // final polynomial (the coefficients that survive truncation by the rate)
-    hipLaunchKernelGGL(k_interleave, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, x.fri_coeffs[nl].p,
-                       x.fri_coeffs[nl].p + m, (uint32_t)m, d_proof + L.final_poly);
-    launch_transcript(tr, 0, d_proof + L.final_poly, (uint32_t)(2 * m), chal, 0, st);
-    qy.n_layers = (uint32_t)nl;
+    FriShape sh{db, rb, cap_h, c_.fri_reduction_arity_bits, c_.cfg.proof_of_work_bits, c_.cfg.num_query_rounds};
+    FriOffsets fo{L.fri_caps, L.final_poly, L.pow_witness, L.queries, L.query_stride};
+    fri_commit_pow_query(tables_, x.fri, sh, tr, chal, qy, d_proof, fo, d_status, st, single_proof_);
   }
-  // "find proof-of-work witness"
-  launch_pow_search(tr, c_.cfg.proof_of_work_bits, chal + CH_POW_WITNESS, st);
-  launch_transcript(tr, 0, chal + CH_POW_WITNESS, 1, chal + CH_POW_RESPONSE, 1 + c_.cfg.num_query_rounds, st);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, chal, c_.cfg.proof_of_work_bits, d_proof + L.pow_witness, d_status);
-  // query rounds
-  qy.chal = chal;
-  qy.num_queries = c_.cfg.num_query_rounds;
-  qy.lde_bits = lde_bits;
-  qy.cap_height = cap_h;
-  const u64* ldes[4] = {cs_lde_.p, x.wires_lde.p, x.zs_lde.p, x.q_lde.p};
-  const u64* trees[4] = {cs_tree_.p, x.wires_tree.p, x.zs_tree.p, x.q_tree.p};
-  for (int k = 0; k < 4; k++) {
-    qy.oracle_lde[k] = ldes[k];
-    qy.oracle_tree[k] = trees[k];
-    qy.oracle_width[k] = L.oracle_width[k];
-  }
-  qy.proof = d_proof;
-  qy.query_offset = (uint32_t)L.queries;
-  qy.query_stride = (uint32_t)L.query_stride;
-  launch_queries(qy, st);
   mark();  // 8
   P25_HIP(hipGetLastError());
   if (t) {
@@ -515,6 +512,192 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
     P25_HIP(hipEventElapsedTime(&tot, x.ev[0], x.ev[8]));
     t->total += tot;
   }
+}
+
+// "compute partial products": Z and partial products (values, natural row order) from the witness values and
+// betas / gammas of the context's challenge block.
+void DeviceCircuit::enqueue_partial_products(Ctx& x, hipStream_t st) {
+  const size_t n = c_.degree();
+  const int NC = c_.cfg.num_challenges, NP = c_.num_partial_products, db = c_.degree_bits;
+  u64* chal = x.chal.p;
+  {
+    ZppArgs za;
+    za.wires = x.wires_vals.p;
+    za.sigmas = cs_vals_.p + (size_t)(c_.num_selectors + c_.cfg.num_constants) * n;
+    za.pow_n = tables_.pow_table(db, false);
+    za.k_is = k_is_.p;
+    za.chal = chal;
+    za.chunk = x.zpp_chunk.p;
+    za.tot = x.zpp_tot.p;
+    za.block_tot = x.zpp_btot.p;
+    za.out = x.zs_vals.p;
+    za.n = (uint32_t)n;
+    za.num_routed = c_.cfg.num_routed_wires;
+    za.num_partial_products = NP;
+    za.num_challenges = NC;
+    launch_zpp(za, st);
+  }
+}
+
+// "compute quotient polys": quotient values on the coset from the wires / Z LDEs and the challenge block, then the
+// coset iNTT to 8n coefficients per challenge (= the NC x 8 chunks of n, contiguous).
+void DeviceCircuit::enqueue_quotient(Ctx& x, hipStream_t st) {
+  const size_t B = big();
+  const int NC = c_.cfg.num_challenges, lde_bits = c_.degree_bits + c_.cfg.rate_bits;
+  u64* chal = x.chal.p;
+  launch_alpha_pows(chal, x.alpha_pows.p, st);
+  {
+    QuotientArgs qa = qa_proto_;
+    qa.wires_lde = x.wires_lde.p;
+    qa.zs_lde = x.zs_lde.p;
+    qa.chal = chal;
+    qa.alpha_pows = x.alpha_pows.p;
+    qa.out = x.q_vals.p;
+    launch_quotient(qa, st);
+  }
+  // coset iNTT of the 2 value vectors (stored at bit-reversed positions) -> 8n coefficients each
+  ntt_inverse(tables_, x.q_vals.p, B, true, x.q_tmp.p, B, x.q_coeffs.p, B, lde_bits, NC, gl::GENERATOR, st);
+}
+
+// ---------------------------------------------------------------- isolated stages (parity tests; include/p25.h)
+void DeviceCircuit::set_challenges(Ctx& x, const u64* betas, const u64* gammas, const u64* alphas) {
+  u64 ch[CH_WORDS] = {0};
+  for (int i = 0; i < c_.cfg.num_challenges; i++) {
+    if (betas) ch[CH_BETAS + i] = betas[i];
+    if (gammas) ch[CH_GAMMAS + i] = gammas[i];
+    if (alphas) ch[CH_ALPHAS + i] = alphas[i];
+  }
+  for (u64 v : ch)
+    if (v >= gl::P) throw std::invalid_argument("non-canonical challenge");
+  P25_HIP(hipMemcpyAsync(x.chal.p, ch, sizeof(ch), hipMemcpyHostToDevice, x.st));
+  P25_HIP(hipStreamSynchronize(x.st));  // ch is on this stack
+}
+static void check_canonical(const u64* v, size_t n, const char* what) {
+  for (size_t i = 0; i < n; i++)
+    if (v[i] >= gl::P) throw std::invalid_argument(std::string("non-canonical field element in ") + what);
+}
+void DeviceCircuit::partial_products(const u64* wires, const u64* betas, const u64* gammas, u64* out) {
+  ensure_ctx(1);
+  sync();
+  Ctx& x = *ctxs_[0];
+  const size_t n = c_.degree();
+  const size_t W = c_.cfg.num_wires, nz = (size_t)c_.cfg.num_challenges * (1 + c_.num_partial_products);
+  check_canonical(wires, W * n, "wires");
+  set_challenges(x, betas, gammas, nullptr);
+  P25_HIP(hipMemcpyAsync(x.wires_vals.p, wires, W * n * 8, hipMemcpyHostToDevice, x.st));
+  enqueue_partial_products(x, x.st);
+  P25_HIP(hipMemcpyAsync(out, x.zs_vals.p, nz * n * 8, hipMemcpyDeviceToHost, x.st));
+  P25_HIP(hipStreamSynchronize(x.st));
+  P25_HIP(hipGetLastError());
+}
+void DeviceCircuit::quotient(const u64* wires, const u64* zs_pp, const u64* betas, const u64* gammas, const u64* alphas,
+                             u64* out) {
+  ensure_ctx(1);
+  sync();
+  Ctx& x = *ctxs_[0];
+  const size_t n = c_.degree(), B = big();
+  const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, nz = NC * (1 + c_.num_partial_products);
+  const int db = c_.degree_bits, rb = c_.cfg.rate_bits;
+  check_canonical(wires, (size_t)W * n, "wires");
+  check_canonical(zs_pp, (size_t)nz * n, "zs_partial_products");
+  set_challenges(x, betas, gammas, alphas);
+  hipStream_t st = x.st;
+  P25_HIP(hipMemcpyAsync(x.wires_vals.p, wires, (size_t)W * n * 8, hipMemcpyHostToDevice, st));
+  P25_HIP(hipMemcpyAsync(x.zs_vals.p, zs_pp, (size_t)nz * n * 8, hipMemcpyHostToDevice, st));
+  ntt_inverse(tables_, x.wires_vals.p, n, false, x.tmp.p, n, x.wires_coeffs.p, n, db, W, 1, st);
+  ntt_lde_bitrev(tables_, x.wires_coeffs.p, n, x.wires_lde.p, B, db, rb, W, gl::GENERATOR, st);
+  ntt_inverse(tables_, x.zs_vals.p, n, false, x.tmp.p, n, x.zs_coeffs.p, n, db, nz, 1, st);
+  ntt_lde_bitrev(tables_, x.zs_coeffs.p, n, x.zs_lde.p, B, db, rb, nz, gl::GENERATOR, st);
+  enqueue_quotient(x, st);
+  P25_HIP(hipMemcpyAsync(out, x.q_coeffs.p, (size_t)NC * B * 8, hipMemcpyDeviceToHost, st));
+  P25_HIP(hipStreamSynchronize(st));
+  P25_HIP(hipGetLastError());
+}
+
+// Challenger script on the device transcript (upstream iop/challenger.rs): per segment observe, then draw.
+void transcript_script(const u64* obs, const uint32_t* seg_len, const uint32_t* n_chal, size_t n_seg, u64* out) {
+  size_t n_obs = 0, n_out = 0;
+  for (size_t k = 0; k < n_seg; k++) {
+    if (n_chal[k] > 64 || seg_len[k] > (1u << 24)) throw std::invalid_argument("transcript segment too large");
+    n_obs += seg_len[k];
+    n_out += n_chal[k];
+  }
+  check_canonical(obs, n_obs, "observed words");
+  DevMem d_tr(sizeof(Transcript) / 8 + 1), d_obs(n_obs + 1), d_out(n_out + 1);
+  P25_HIP(hipMemcpy(d_obs.p, obs, n_obs * 8, hipMemcpyHostToDevice));
+  size_t o = 0, c = 0;
+  for (size_t k = 0; k < n_seg; k++) {
+    launch_transcript((Transcript*)d_tr.p, k == 0, d_obs.p + o, seg_len[k], d_out.p + c, n_chal[k], 0);
+    o += seg_len[k];
+    c += n_chal[k];
+  }
+  if (!n_seg) return;
+  P25_HIP(hipMemcpy(out, d_out.p, n_out * 8, hipMemcpyDeviceToHost));
+  P25_HIP(hipGetLastError());
+}
+
+size_t fri_prove_words(const FriShape& sh) {
+  const size_t capw = (size_t)4 << sh.cap_height, nl = sh.arity_bits.size();
+  int deg = sh.log_n, bits = sh.log_n + sh.rate_bits;
+  size_t per_q = 0;
+  for (int a : sh.arity_bits) {
+    deg -= a;
+    bits -= a;
+    per_q += 2 * ((size_t)1 << a) + 4 * (size_t)(bits - (int)sh.cap_height);
+  }
+  return nl * capw + 2 * nl + 2 * ((size_t)1 << deg) + 1 + sh.num_queries + per_q * sh.num_queries;
+}
+// out: CAP[n_layers] | betas E[n_layers] | final_poly E[..] | pow_witness | indices[num_queries] | query openings
+void fri_prove_standalone(NttTables& tables, const u64* coeffs, const FriShape& sh, const u64* seed, size_t n_seed,
+                          u64* out, int32_t* status_out) {
+  const size_t n = (size_t)1 << sh.log_n, capw = (size_t)4 << sh.cap_height, nl = sh.arity_bits.size();
+  check_canonical(coeffs, 2 * n, "polynomial coefficients");
+  check_canonical(seed, n_seed, "transcript seed");
+  int deg = sh.log_n, bits = sh.log_n + sh.rate_bits;
+  size_t per_q = 0;
+  for (int a : sh.arity_bits) {
+    if (a < 1 || a > 8) throw std::invalid_argument("FRI arity bits must be in 1..8");
+    deg -= a;
+    bits -= a;
+    if (deg < 0 || bits < (int)sh.cap_height) throw std::invalid_argument("FRI layer smaller than the Merkle cap");
+    per_q += 2 * ((size_t)1 << a) + 4 * (size_t)(bits - (int)sh.cap_height);
+  }
+  if (sh.num_queries < 1 || sh.num_queries > 64 || sh.pow_bits < 0 || sh.pow_bits > 32 || sh.rate_bits < 0 || sh.rate_bits > 3)
+    throw std::invalid_argument("FRI parameters out of range");
+  FriWork w;
+  w.alloc(sh.log_n, sh.rate_bits, sh.cap_height, sh.arity_bits);
+  FriOffsets fo;
+  fo.caps = 0;
+  fo.final_poly = nl * capw;
+  fo.pow_witness = fo.final_poly + 2 * ((size_t)1 << deg);
+  fo.queries = fo.pow_witness + 1;
+  fo.query_stride = per_q;
+  const size_t proof_words = fo.queries + per_q * sh.num_queries;
+  DevMem d_tr(sizeof(Transcript) / 8 + 1), d_chal(CH_WORDS), d_proof(proof_words), d_status(1), d_seed(n_seed + 1);
+  hipStream_t st = 0;
+  P25_HIP(hipMemcpy(w.coeffs[0].p, coeffs, 2 * n * 8, hipMemcpyHostToDevice));
+  P25_HIP(hipMemcpy(d_seed.p, seed, n_seed * 8, hipMemcpyHostToDevice));
+  P25_HIP(hipMemset(d_status.p, 0, 8));
+  P25_HIP(hipMemset(d_chal.p, 0, CH_WORDS * 8));
+  launch_transcript((Transcript*)d_tr.p, 1, d_seed.p, (uint32_t)n_seed, d_chal.p, 0, st);
+  QueryArgs qy;
+  memset(&qy, 0, sizeof(qy));
+  fri_commit_pow_query(tables, w, sh, (Transcript*)d_tr.p, d_chal.p, qy, d_proof.p, fo, (uint32_t*)d_status.p, st, true);
+  P25_HIP(hipStreamSynchronize(st));
+  P25_HIP(hipGetLastError());
+  std::vector<u64> pr(proof_words), ch(CH_WORDS);
+  uint32_t hs[2] = {0, 0};
+  P25_HIP(hipMemcpy(pr.data(), d_proof.p, proof_words * 8, hipMemcpyDeviceToHost));
+  P25_HIP(hipMemcpy(ch.data(), d_chal.p, CH_WORDS * 8, hipMemcpyDeviceToHost));
+  P25_HIP(hipMemcpy(hs, d_status.p, 8, hipMemcpyDeviceToHost));
+  *status_out = (int32_t)hs[0];
+  u64* o = out;
+  memcpy(o, pr.data(), nl * capw * 8); o += nl * capw;
+  memcpy(o, ch.data() + CH_FRI_BETAS, 2 * nl * 8); o += 2 * nl;
+  memcpy(o, pr.data() + fo.final_poly, (fo.queries - fo.final_poly) * 8); o += fo.queries - fo.final_poly;
+  const u64 mask = ((u64)1 << (sh.log_n + sh.rate_bits)) - 1;
+  for (int q = 0; q < sh.num_queries; q++) *o++ = ch[CH_QUERIES + q] & mask;
+  memcpy(o, pr.data() + fo.queries, per_q * sh.num_queries * 8);
 }
 
 static size_t streams_in_flight() {
@@ -537,7 +720,7 @@ size_t DeviceCircuit::ctx_bytes() const {
 }
 
 void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs,
-                                    size_t proof_stride, uint32_t* d_status, PhaseTimes* times) {
+                                    size_t proof_stride, uint32_t* d_status, PhaseTimes* times, const u64* d_filler) {
   size_t K = times ? 1 : streams_in_flight();
   if (K > n_proofs) K = n_proofs ? n_proofs : 1;
   if (K > ctxs_.size()) {
@@ -570,7 +753,8 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
       P25_HIP(hipEventCreate(&e1));
       P25_HIP(hipEventRecord(e0, stream_));
     }
-    launch_witgen(wp_, d_inputs + base * wp_.n_inputs, d_seeds + base, vals_.p, bsz, (uint32_t)bsz, d_status + base, stream_);
+    launch_witgen(wp_, d_inputs + base * wp_.n_inputs, d_seeds + base, vals_.p, bsz, (uint32_t)bsz, d_status + base, stream_,
+                  d_filler ? d_filler + base * wp_.num_random_fill : nullptr);
     P25_HIP(hipEventRecord(ev_witness_, stream_));
     if (times) {
       P25_HIP(hipEventRecord(e1, stream_));
@@ -590,7 +774,7 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
 }
 
 void DeviceCircuit::prove_batch(const u64* inputs, size_t n_proofs, const u64* seeds, u64* proofs_out,
-                                size_t proof_stride, int32_t* statuses, PhaseTimes* times) {
+                                size_t proof_stride, int32_t* statuses, PhaseTimes* times, const u64* filler) {
   if (proof_stride < layout_.total) throw std::invalid_argument("proof_stride smaller than the proof");
   const size_t ni = wp_.n_inputs;
   for (size_t i = 0; i < n_proofs * ni; i++)
@@ -600,7 +784,13 @@ void DeviceCircuit::prove_batch(const u64* inputs, size_t n_proofs, const u64* s
   for (size_t i = 0; i < n_proofs; i++) sd[i] = seeds ? seeds[i] : (u64)i;
   P25_HIP(hipMemcpyAsync(d_in.p, inputs, n_proofs * ni * 8, hipMemcpyHostToDevice, stream_));
   P25_HIP(hipMemcpyAsync(d_seeds.p, sd.data(), n_proofs * 8, hipMemcpyHostToDevice, stream_));
-  prove_batch_dev(d_in.p, n_proofs, d_seeds.p, d_proofs.p, layout_.total, (uint32_t*)d_status.p, times);
+  DevMem d_filler(filler ? n_proofs * wp_.num_random_fill + 1 : 0);
+  if (filler) {
+    for (size_t i = 0; i < n_proofs * wp_.num_random_fill; i++)
+      if (filler[i] >= gl::P) throw std::invalid_argument("non-canonical filler field element");
+    P25_HIP(hipMemcpyAsync(d_filler.p, filler, n_proofs * wp_.num_random_fill * 8, hipMemcpyHostToDevice, stream_));
+  }
+  prove_batch_dev(d_in.p, n_proofs, d_seeds.p, d_proofs.p, layout_.total, (uint32_t*)d_status.p, times, filler ? d_filler.p : nullptr);
   sync();
   std::vector<uint32_t> hs(n_proofs);
   P25_HIP(hipMemcpyAsync(hs.data(), d_status.p, n_proofs * 4, hipMemcpyDeviceToHost, stream_));

@@ -14,7 +14,7 @@ struct DeviceWitnessProgram {
   uint32_t* d_wire_slot_cm = nullptr;
   std::vector<uint32_t> level_start;
   std::vector<uint32_t> level_p2_begin, level_p2_count;  // Poseidon2 generators of each level (contiguous)
-  uint32_t n_inputs = 0, num_slots = 0;
+  uint32_t n_inputs = 0, num_slots = 0, num_random_fill = 0;
   size_t n_wire_elems = 0;
 };
 // Per-proof status word: the FIRST failure (in stream order) is the one reported -- a later kernel never
@@ -22,8 +22,9 @@ struct DeviceWitnessProgram {
 #ifdef __HIPCC__
 __device__ __forceinline__ void set_status(uint32_t* status, uint32_t code) { atomicCAS(status, 0u, code); }
 #endif
+// d_filler (nullable): explicit RandomValueGenerator values [n_proofs][num_random_fill] used instead of the seeds
 void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u64* d_seeds, u64* d_vals,
-                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st);
+                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st, const u64* d_filler = nullptr);
 void launch_fill_wires(const DeviceWitnessProgram& wp, const u64* d_vals, size_t B, uint32_t p, u64* d_wires,
                        hipStream_t st);
 
@@ -117,6 +118,7 @@ void launch_tree_from_digests(u64* d_tree, size_t n_leaves, unsigned cap_height,
 struct QueryArgs {
   const u64* chal;            // CH_QUERIES raw challenges
   uint32_t num_queries, lde_bits, cap_height;
+  uint32_t n_oracles;         // initial oracles opened per query (4 in a plonky2 proof, 0 for FRI alone)
   const u64* oracle_lde[4];   // [width][big]
   const u64* oracle_tree[4];
   uint32_t oracle_width[4];

@@ -103,6 +103,10 @@ WitnessProgram build_witness_program(const Circuit& c) {
   }
   if (done != G) throw std::runtime_error(std::to_string(G - done) + " generators weren't run");
 
+  // RandomValueGenerators are numbered in generator-list order (the order an explicit filler vector is given in)
+  std::vector<uint32_t> random_ordinal(G, 0);
+  for (size_t gi = 0; gi < G; gi++)
+    if (c.generators[gi].kind == GEN_RANDOM) random_ordinal[gi] = wp.num_random_fill++;
   // emit generators sorted by (level, kind, original index)
   std::vector<uint32_t> order(G);
   for (size_t i = 0; i < G; i++) order[i] = (uint32_t)i;
@@ -127,6 +131,7 @@ WitnessProgram build_witness_program(const Circuit& c) {
     w.n_outs = (uint16_t)g.outs.size();
     w.c0 = g.c0;
     w.c1 = g.c1;
+    if (g.kind == GEN_RANDOM) w.c1 = random_ordinal[gi];  // index into an explicit filler vector
     for (const Target& t : g.deps) wp.args.push_back(slot_of_rep[rep_of(t)]);
     for (size_t k = 0; k < g.outs.size(); k++) wp.args.push_back(slot_of_rep[rep_of(g.outs[k])] | out_flags[gi][k]);
     wp.gens.push_back(w);

@@ -27,6 +27,7 @@ struct WitGen {       // 32 bytes, mirrored in the kernel
 constexpr uint32_t WIT_CHECK_FLAG = 0x80000000u;  // on an out slot: compare, do not write
 
 struct WitnessProgram {
+  uint32_t num_random_fill = 0;           // RandomValueGenerators; WitGen::c1 of each = its ordinal
   uint32_t num_slots = 1;                 // slot 0 is the constant 0 (value of every unset wire)
   std::vector<WitGen> gens;               // sorted by (level, kind)
   std::vector<uint32_t> args;

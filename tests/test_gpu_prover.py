@@ -81,3 +81,26 @@ def test_non_canonical_device_resident_input_flagged(gpu, fib_circuit, fib_input
     fib_circuit.sync()
     assert d_status.cpu().tolist()[0] == 0
     assert d_status.cpu().tolist()[1] != 0
+
+
+def test_explicit_filler_equals_oracle_and_seed_path(gpu, fib_circuit, fib_oracle, fib_inputs):
+    """p25_prove_batch_filler: the RandomValueGenerator wires take the caller's values (what a real upstream run drew
+    from the OS RNG, tools/upstream_check).  Same values as the SplitMix64 stand-in of seed s -> the seed-s proof."""
+    nf = int(fib_circuit.info.num_random_fill)
+    assert nf == 131
+    rng = np.random.default_rng(5)
+    filler = rng.integers(0, 0xFFFFFFFF00000001, size=(2, nf), dtype=np.uint64)
+    proofs, st = fib_circuit.prove_filler(np.stack([fib_inputs, fib_inputs]), filler)
+    assert st.tolist() == [0, 0] and (proofs[0] != proofs[1]).any()
+    po, sto, msg = fib_oracle.prove_filler(fib_inputs, filler[1])
+    assert sto == 0, msg
+    assert (proofs[1] == po).all()
+    # the seed path is the filler path with SplitMix64(seed, wire) values: read them back from the witness
+    seed_proof, st = fib_circuit.prove(fib_inputs, seeds=[42])
+    # the PublicInputGate row is the one whose first four wires are zero and all the others filled
+    wo, _s, _m = fib_oracle.witness(fib_inputs, seed=42)
+    cand = np.nonzero((wo[:4] == 0).all(axis=0) & (wo[4:] != 0).all(axis=0))[0]
+    assert cand.size >= 1
+    via_filler, st2 = fib_circuit.prove_filler(fib_inputs, wo[4:, cand[0]])
+    assert st.tolist() == [0] and st2.tolist() == [0]
+    assert (via_filler[0] == seed_proof[0]).all()

@@ -1,0 +1,117 @@
+"""GPU: the prover's stages on their own, through the fine-grained C-ABI entry points, against the
+oracle's restatement of the same upstream functions -- so a regression in a6-a10 is reported at its stage instead
+of as "first differing proof word".
+
+  a6  Challenger                      p25_transcript        vs RChallenger
+  a7  partial products + Z            p25_partial_products  vs ref_partial_products
+  a8  quotient + every gate evaluator p25_quotient          vs ref_quotient_chunks
+  a10 FRI commit / PoW / queries      p25_fri_prove         vs ref_fri_prove
+"""
+import numpy as np
+import pytest
+
+from conftest import P, splitmix_field
+
+pytestmark = pytest.mark.gpu
+
+
+def test_transcript_scripts_vs_oracle(gpu, oracle):
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        segs = []
+        for _ in range(int(rng.integers(1, 7))):
+            n_obs = int(rng.choice([0, 1, 3, 7, 8, 9, 15, 16, 17, 64, 100, 327]))
+            n_ch = int(rng.choice([0, 1, 2, 4, 7, 8, 9, 29]))
+            segs.append((splitmix_field(n_obs, seed=int(rng.integers(1, 1 << 60))), n_ch))
+        g = gpu.transcript(segs)
+        o = oracle.transcript(segs)
+        assert (g == o).all(), (trial, [(len(w), k) for w, k in segs])
+        assert (g < np.uint64(P)).all()
+    # draw without observing anything; observe-only scripts
+    assert (gpu.transcript([([], 3)]) == oracle.transcript([([], 3)])).all()
+    assert gpu.transcript([(splitmix_field(5), 0)]).size == 0
+
+
+@pytest.fixture(scope="module")
+def small(gpu, oracle):
+    """plonky3-verifier circuit of a 2^3-row Fibonacci STARK (2^10 rows, every gate type of the fib-64 circuit)."""
+    inp, cfg = gpu.p3_prove_fibonacci(3, 3, 4)
+    c = gpu.Circuit.build_p3_verifier(cfg)
+    oc = oracle.load_circuit(c.to_blob())
+    wires, st, msg = oc.witness(inp, seed=3)
+    assert st == 0, msg
+    return c, oc, wires
+
+
+def _chal(seed):
+    return splitmix_field(6, seed=seed).reshape(3, 2)
+
+
+def _check_stage_a7_a8(c, oc, wires, seed):
+    betas, gammas, alphas = _chal(seed)
+    zg = c.partial_products(wires, betas, gammas)
+    zo = oc.partial_products(wires, betas, gammas)
+    assert zg.shape == zo.shape and (zg == zo).all(), np.argwhere(zg != zo)[:5]
+    assert (zg[:2, 0] == 1).all()                       # Z(1) = 1
+    qg = c.quotient(wires, zg, betas, gammas, alphas)
+    qo = oc.quotient(wires, zo, betas, gammas, alphas)
+    assert qg.shape == qo.shape and (qg == qo).all(), np.argwhere(qg != qo)[:5]
+    return zg, qg
+
+
+def test_partial_products_and_quotient_vs_oracle_small(small):
+    c, oc, wires = small
+    for seed in (11, 12):
+        _zs, q = _check_stage_a7_a8(c, oc, wires, seed)
+        # a satisfied witness: the quotient is a polynomial of degree < 8n whose top chunk stays below the gate degree
+        assert q.any()
+
+
+def test_quotient_sees_every_wire_column(small):
+    """Changing one witness value changes the quotient chunks on both sides in the same way (the evaluator of the
+    row's gate reads that column), and the result no longer has the low degree of a valid quotient."""
+    c, oc, wires = small
+    betas, gammas, alphas = _chal(5)
+    zs = oc.partial_products(wires, betas, gammas)
+    base = oc.quotient(wires, zs, betas, gammas, alphas)
+    bad = wires.copy()
+    bad[1, 0] = (int(bad[1, 0]) + 1) % P
+    qg = c.quotient(bad, zs, betas, gammas, alphas)
+    qo = oc.quotient(bad, zs, betas, gammas, alphas)
+    assert (qg == qo).all() and (qg != base).any()
+
+
+def test_partial_products_and_quotient_vs_oracle_fib64(gpu, fib_circuit, fib_oracle, fib_inputs):
+    """Full size: 2^16 rows x 135 wires, LDE 2^19 -- the shapes k_zpp_* and k_quotient run at in the bench."""
+    wires, st, msg = fib_oracle.witness(fib_inputs, seed=77)
+    assert st == 0, msg
+    _check_stage_a7_a8(fib_circuit, fib_oracle, wires, 21)
+
+
+@pytest.mark.parametrize("log_n,rate_bits,cap_h,arity,pow_bits,queries", [
+    (10, 3, 4, [4, 4], 8, 5),          # two layers, as a 2^10-row circuit has
+    (12, 3, 4, [4, 4, 4], 10, 28),     # upstream's schedule shape: final polynomial of 2^0.. coefficients
+    (8, 1, 0, [3, 2, 1], 4, 7),        # ragged arities, cap of one digest
+    (6, 2, 2, [], 6, 3),               # no commit-phase layer at all: final polynomial = the input
+    (16, 3, 4, [4, 4, 4], 16, 28),     # the fib-64 circuit's FRI: 2^16 coefficients, LDE 2^19, 16 PoW bits
+])
+def test_fri_prove_vs_oracle(gpu, oracle, log_n, rate_bits, cap_h, arity, pow_bits, queries):
+    coeffs = splitmix_field(2 << log_n, seed=1000 + log_n).reshape(2, 1 << log_n)
+    seed = splitmix_field(13, seed=99)
+    g, st = gpu.fri_prove(coeffs, rate_bits, cap_h, arity, pow_bits, queries, seed)
+    assert st == 0
+    o = oracle.fri_prove(coeffs, rate_bits, cap_h, arity, pow_bits, queries, seed)
+    assert g.shape == o.shape
+    diff = np.nonzero(g != o)[0]
+    assert diff.size == 0, f"first differing words {diff[:8]} of {g.size}"
+
+
+def test_fri_bad_shapes_rejected(gpu, p25):
+    coeffs = splitmix_field(2 << 6).reshape(2, 64)
+    for arity in ([7], [4, 4], [0], [9]):                 # folds below degree 1 / below the cap / out of range
+        with pytest.raises(p25.P25Error):
+            gpu.fri_prove(coeffs, 1, 2, arity, 4, 3, [1, 2, 3])
+    bad = coeffs.copy()
+    bad[0, 0] = np.uint64(P)
+    with pytest.raises(p25.P25Error):
+        gpu.fri_prove(bad, 1, 2, [2], 4, 3, [1, 2, 3])

@@ -1,0 +1,100 @@
+//! Builds the circuit of `p3::tests::test_verify_plonky3_proof` (reference src/p3/mod.rs:226-269) with the real
+//! plonky2 `CircuitBuilder`, proves it with the real prover, and dumps what tests/test_upstream_golden.py compares:
+//!
+//!   upstream_circuit.json  degree_bits, circuit_digest, constants_sigmas_cap, gate ids in `common.gates` order,
+//!                          rows per gate (from the selector polynomials), selector groups, k_is[0..4]
+//!   upstream_proof.json    serde_json::to_string(&proof)          (what src/p3/mod.rs:261 writes)
+//!   upstream_filler.json   the values the 131 RandomValueGenerators of the PublicInputGate row drew for THAT proof,
+//!                          in wire order 4..134 -- with them p25_prove_batch_filler must reproduce the proof bytes
+//!
+//! The witness is generated with `generate_partial_witness` so that the filler values can be read back before
+//! `prove_with_partition_witness` consumes it (both are public in plonky2 @ 3de92d9: plonky2/src/iop/generator.rs,
+//! plonky2/src/plonk/prover.rs).  If a later revision hides them, drop the filler file: the other two still pin
+//! the circuit and the verifier semantics.
+use anyhow::Result;
+use plonky2::iop::generator::generate_partial_witness;
+use plonky2::iop::target::Target;
+use plonky2::iop::witness::{PartialWitness, Witness};
+use plonky2::plonk::circuit_builder::CircuitBuilder;
+use plonky2::plonk::circuit_data::CircuitConfig;
+use plonky2::plonk::config::{GenericConfig, PoseidonGoldilocksConfig};
+use plonky2::plonk::prover::prove_with_partition_witness;
+use plonky2::util::timing::TimingTree;
+use plonky2_field::types::PrimeField64;
+use serde_json::json;
+
+// names as in the reference's test module (src/p3/mod.rs:160-250)
+use plonky2_5::p3::air::FibonacciAir;                      // the test AIR; make it `pub` in a local checkout if needed
+use plonky2_5::p3::serde::fri::FriConfig;
+use plonky2_5::p3::serde::proof::{P3ProofField, Proof};
+use plonky2_5::p3::CircuitBuilderP3Verifier;               // trait providing `p3_verify_proof`
+use plonky2::hash::poseidon::PoseidonHash;
+
+const D: usize = 2;
+type C = PoseidonGoldilocksConfig;
+type F = <C as GenericConfig<D>>::F;
+
+fn main() -> Result<()> {
+    let artifact = std::env::args().nth(1).unwrap_or("artifacts/proof_fibonacci.json".into());
+    let p3_proof: P3ProofField = serde_json::from_str(&std::fs::read_to_string(artifact)?)?;
+
+    let mut builder = CircuitBuilder::<F, D>::new(CircuitConfig::standard_recursion_config());
+    let proof_t = Proof::add_virtual_to(&mut builder, &p3_proof);          // proof.rs:357-373
+    builder.p3_verify_proof::<PoseidonHash>(
+        proof_t.clone(),
+        &FibonacciAir {},
+        FriConfig { log_blowup: 1, num_queries: 100, proof_of_work_bits: 16 },
+    );
+    let data = builder.build::<C>();
+    let (common, prover_only) = (&data.common, &data.prover_only);
+    let n = common.degree();
+
+    // ---- upstream_circuit.json
+    let cs_values: Vec<Vec<F>> = prover_only.constants_sigmas_commitment.polynomials.iter()
+        .map(|p| p.clone().fft().values).collect();
+    let mut rows_per_gate = vec![0usize; common.gates.len()];
+    let mut pi_row = None;
+    for r in 0..n {
+        for (g, gate) in common.gates.iter().enumerate() {
+            let s = common.selectors_info.selector_indices[g];
+            if cs_values[s][r].to_canonical_u64() == g as u64 {
+                rows_per_gate[g] += 1;
+                if gate.0.id() == "PublicInputGate" { pi_row = Some(r); }
+            }
+        }
+    }
+    let circuit = json!({
+        "plonky2_rev": "3de92d9ed1721cec133e4e1e1b3ec7facb756ccf",
+        "degree_bits": common.degree_bits(),
+        "num_gate_constraints": common.num_gate_constraints,
+        "num_partial_products": common.num_partial_products,
+        "quotient_degree_factor": common.quotient_degree_factor,
+        "circuit_digest": data.verifier_only.circuit_digest.elements.iter().map(|e| e.to_canonical_u64()).collect::<Vec<_>>(),
+        "constants_sigmas_cap": data.verifier_only.constants_sigmas_cap.0.iter()
+            .map(|h| h.elements.iter().map(|e| e.to_canonical_u64()).collect::<Vec<_>>()).collect::<Vec<_>>(),
+        "gate_ids": common.gates.iter().map(|g| g.0.id()).collect::<Vec<_>>(),
+        "rows_per_gate": rows_per_gate,
+        "selector_indices": common.selectors_info.selector_indices,
+        "selector_groups": common.selectors_info.groups.iter().map(|r| vec![r.start, r.end]).collect::<Vec<_>>(),
+        "fri_reduction_arity_bits": common.fri_params.reduction_arity_bits,
+        "k_is_head": common.k_is.iter().take(4).map(|e| e.to_canonical_u64()).collect::<Vec<_>>(),
+        "num_generators": prover_only.generators.len(),
+    });
+    std::fs::write("upstream_circuit.json", serde_json::to_string_pretty(&circuit)?)?;
+
+    // ---- witness, filler, proof
+    let mut pw = PartialWitness::new();
+    proof_t.set_witness(&mut pw, &p3_proof);                                  // proof.rs:374-383
+    let partition_witness = generate_partial_witness(pw, prover_only, common);
+    if let Some(r) = pi_row {
+        let filler: Vec<u64> = (4..common.config.num_wires)
+            .map(|c| partition_witness.get_target(Target::wire(r, c)).to_canonical_u64()).collect();
+        std::fs::write("upstream_filler.json", serde_json::to_string(&json!({"pi_row": r, "filler": filler}))?)?;
+    }
+    let proof = prove_with_partition_witness::<F, C, D>(prover_only, common, partition_witness,
+                                                          &mut TimingTree::default())?;
+    std::fs::write("upstream_proof.json", serde_json::to_string(&proof)?)?;
+    data.verify(proof)?;                                                      // src/p3/mod.rs:266
+    println!("wrote upstream_circuit.json, upstream_proof.json, upstream_filler.json (n = 2^{})", common.degree_bits());
+    Ok(())
+}
