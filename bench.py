@@ -16,9 +16,9 @@ Prints ONE JSON line on rank 0 (contract in the task description), including
                   bytes per launch / its duration measured with HIP events on the proving stream, for
                   launches that have the GPU to themselves (the figure rocprofv3 reports per kernel) and,
                   separately, for the launches of the timed region (16 proofs in flight, time-sliced)
-  cpu_baseline -- the oracle (CPU restatement, kind "port") on the host cores: one proof on ONE thread (the
-                  reference build has no `parallel` feature, Cargo.toml:15-18) and one single-threaded proof
-                  per physical core on pinned threads.
+  cpu_baseline -- the oracle (CPU restatement, kind "port") on the host cores: one proof on ONE pinned thread (the
+                  reference build has no `parallel` feature, Cargo.toml:15-18) and the whole host (independent proofs
+                  in flight on all physical cores, 16 threads each).
 """
 import argparse
 import json
@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--verify", type=int, default=8, help="proofs of the last step checked by the oracle verifier")
     ap.add_argument("--cpu-baseline", choices=("full", "one-thread", "none"), default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="cores of the one-proof-per-core leg (0 = all physical cores)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="physical cores of the whole-host leg (0 = all)")
     return ap.parse_args()
 
 
@@ -331,22 +331,21 @@ def main():
                   "sample": f"1 full fib-64 proof (witness generation + prove) by the oracle C++ restatement on ONE pinned "
                             f"thread: {wall1:.1f} s, status {int(st1[0])}"}
             if args.cpu_baseline == "full":
-                # (ii) the whole host: one independent single-threaded proof per physical core, pinned
+                # (ii) the whole host: G proofs in flight, each on T threads of the oracle's persistent pool,
+                # G x T = the physical cores.  (One single-threaded proof per core was measured too: 128 working sets
+                # of ~4 GB compete for the memory system and the host delivers 0.21 proofs/s -- DESIGN.md section 4.)
                 cores = physical_cores()
                 if args.cpu_cores:
                     cores = cores[:args.cpu_cores]
-                try:
-                    avail_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2**30
-                except (ValueError, OSError):
-                    avail_gb = 64.0
-                ncore = max(1, min(len(cores), int(avail_gb // 6)))   # ~4 GB of vectors per proof in flight
-                os.sched_setaffinity(0, set(cores[:ncore]))
-                many_in = np.stack([variants[i % len(variants)] for i in range(ncore)])
-                _pr, stn, pern, walln = oc.prove_many(many_in, np.arange(ncore, dtype=np.uint64), threads=ncore,
-                                                      want_proofs=False)
-                cb["all_cores"] = {"value": ncore / walln, "unit": "proofs/s", "cores": ncore,
-                                   "sample": f"{ncore} independent fib-64 proofs, one single-threaded proof per physical core "
-                                             f"(pinned threads, persistent, no sharing): wall {walln:.1f} s, per-proof "
+                T = min(16, len(cores))
+                G = max(1, len(cores) // T)
+                os.sched_setaffinity(0, set(cores[:G * T]))
+                many_in = np.stack([variants[i % len(variants)] for i in range(G)])
+                _pr, stn, pern, walln = oc.prove_many(many_in, np.arange(G, dtype=np.uint64), threads=G,
+                                                      want_proofs=False, threads_per_proof=T)
+                cb["all_cores"] = {"value": G / walln, "unit": "proofs/s", "cores": G * T,
+                                   "sample": f"{G} independent fib-64 proofs in flight, {T} threads each (persistent pool) on "
+                                             f"{G * T} physical cores: wall {walln:.1f} s, per-proof "
                                              f"{float(pern.min()):.1f}-{float(pern.max()):.1f} s, all ok: {bool((stn == 0).all())}"}
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

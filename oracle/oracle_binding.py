@@ -90,9 +90,9 @@ class OracleCircuit:
         self.lib.p25o_quotient(self.h, _p(ww), _p(zz), _p(b), _p(g), _p(al), _p(out))
         return out
 
-    def prove_many(self, inputs, seeds, threads, want_proofs=True):
-        """N independent proofs, one single-threaded proof per pinned host thread.
-        Returns (proofs or None, statuses, per-proof seconds, wall seconds)."""
+    def prove_many(self, inputs, seeds, threads, want_proofs=True, threads_per_proof=1):
+        """N independent proofs, `threads` in flight, each on `threads_per_proof` host threads (1 = one pinned
+        single-threaded proof per thread).  Returns (proofs or None, statuses, per-proof seconds, wall seconds)."""
         inp = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, self.num_inputs)
         n = inp.shape[0]
         sd = np.ascontiguousarray(seeds, dtype=np.uint64)
@@ -100,7 +100,8 @@ class OracleCircuit:
         proofs = np.zeros((n, self.proof_words), dtype=np.uint64) if want_proofs else None
         st = np.full(n, -1, dtype=np.int32)
         per = np.zeros(n, dtype=np.float64)
-        wall = self.lib.p25o_prove_many(self.h, _p(inp), _p(sd), n, int(threads), _p(proofs), _p(st), _p(per))
+        wall = self.lib.p25o_prove_many_grouped(self.h, _p(inp), _p(sd), n, int(threads), int(threads_per_proof),
+                                                _p(proofs), _p(st), _p(per))
         return proofs, st, per, float(wall)
 
     def verify(self, proof, digest=None, cs_cap=None):
@@ -148,6 +149,8 @@ class Oracle:
         L.p25o_prove.argtypes = [vp, vp, u64, vp, vp, C.c_char_p, sz]
         L.p25o_verify.argtypes = [vp, vp, vp, vp, C.c_char_p, sz]
         L.p25o_prove_many.argtypes = [vp, vp, vp, sz, C.c_int, vp, vp, vp]
+        L.p25o_prove_many_grouped.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp, vp, vp]
+        L.p25o_prove_many_grouped.restype = C.c_double
         L.p25o_stage_shapes.argtypes = [vp, vp, vp]
         L.p25o_prove_filler.argtypes = [vp, vp, vp, vp, C.c_char_p, sz]
         L.p25o_num_random_fill.argtypes = [vp]

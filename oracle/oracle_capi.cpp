@@ -277,8 +277,18 @@ size_t p25o_fri_prove(const u64* coeffs, unsigned log_n, unsigned rate_bits, uns
 // thread pinned to its own CPU of the process's affinity set.  inputs[n_proofs][num_inputs],
 // proofs_out[n_proofs][proof_words] (nullable), statuses[n_proofs], per_proof_s[n_proofs] (nullable:
 // wall seconds of each proof).  Returns wall seconds of the whole run.
+double p25o_prove_many_grouped(void* h, const u64* inputs, const u64* seeds, size_t n_proofs, int n_threads,
+                               int threads_per_proof, u64* proofs_out, int* statuses, double* per_proof_s);
 double p25o_prove_many(void* h, const u64* inputs, const u64* seeds, size_t n_proofs, int n_threads,
                        u64* proofs_out, int* statuses, double* per_proof_s) {
+  return p25o_prove_many_grouped(h, inputs, seeds, n_proofs, n_threads, 1, proofs_out, statuses, per_proof_s);
+}
+// Same with `threads_per_proof` host threads per proof (n_threads proofs in flight, each spreading its loops over
+// its own group through the persistent pool): the whole-host configuration that is not limited by n_threads
+// working sets of ~4 GB each competing for the memory system.  Proving threads are pinned only when
+// threads_per_proof == 1.
+double p25o_prove_many_grouped(void* h, const u64* inputs, const u64* seeds, size_t n_proofs, int n_threads,
+                               int threads_per_proof, u64* proofs_out, int* statuses, double* per_proof_s) {
   auto* oc = (OracleCircuit*)h;
   p25o_precompute(h);
   const size_t ni = oc->c.num_inputs, pw = ref_proof_words(oc->c);
@@ -296,13 +306,13 @@ double p25o_prove_many(void* h, const u64* inputs, const u64* seeds, size_t n_pr
   std::vector<std::thread> th;
   for (int t = 0; t < n_threads; t++)
     th.emplace_back([&, t] {
-      if (!cpus.empty()) {
+      if (!cpus.empty() && threads_per_proof <= 1) {
         cpu_set_t one;
         CPU_ZERO(&one);
         CPU_SET(cpus[t % cpus.size()], &one);
         (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
       }
-      ref_set_thread_local_threads(1);
+      ref_set_thread_local_threads(threads_per_proof < 1 ? 1 : threads_per_proof);
       for (;;) {
         size_t i = next.fetch_add(1);
         if (i >= n_proofs) break;

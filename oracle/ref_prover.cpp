@@ -39,7 +39,9 @@ class Pool {
     job.total_chunks = (n + job.chunk - 1) / job.chunk;
     {
       std::lock_guard<std::mutex> lk(m_);
-      while ((int)workers_.size() < T - 1) workers_.emplace_back([this] { worker(); });
+      // several proofs may be running their loops at once (one group of T threads each): enough helpers for all
+      demand_ += T - 1;
+      while ((int)workers_.size() < demand_ && workers_.size() < 1024) workers_.emplace_back([this] { worker(); });
       for (int i = 0; i < T - 1; i++) q_.push_back(&job);
     }
     cv_.notify_all();
@@ -51,6 +53,7 @@ class Pool {
     {
       std::lock_guard<std::mutex> lk2(m_);
       for (auto it = q_.begin(); it != q_.end();) it = (*it == &job) ? q_.erase(it) : it + 1;
+      demand_ -= T - 1;
     }
     // a worker that popped the job but is still inside work()/notify must be waited for (job is on this stack)
     for (;;) {
@@ -68,6 +71,7 @@ class Pool {
   std::vector<std::thread> workers_;
   std::vector<Job*> q_;
   std::vector<Job*> active_;
+  int demand_ = 0;  // helpers wanted by the loops running right now
   bool job_refs(Job* j) {
     for (Job* a : active_)
       if (a == j) return true;
