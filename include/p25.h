@@ -146,7 +146,11 @@ p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t l
  * 3 rsh(x,param) 4 reverse_bits_len(x,param) 5 Poseidon2 compress(l[4],r[4]) 6 7*w_param^e with inverse
  * 7 MerkleTreeMmcs::hash_iter_slices over `param` slices of 4 words (src/p3/commit.rs:23-46, test :143-171)
  * 8 inputs a, b under one copy constraint (`connect(a, b)`) and a*b: a != b fails with
- *   P25_ERR_WITNESS_CONFLICT like upstream's "was set twice with different values".
+ *   P25_ERR_WITNESS_CONFLICT like upstream's "was set twice with different values"
+ * 9 extension-field gadget chain (ArithmeticExtensionGate, MulExtensionGate, virtual inverse): inputs a, b, c in
+ *   F_p^2 and the expected result of ((5*((a*b+c)*a-b)+(3+9X))^7 / c + a + b + a0*b
+ * 10 Poseidon (v1) in-circuit: hash_or_noop of `param` words, then one Merkle step `permute_swapped([h, sibling, 0],
+ *   bit)` on a PoseidonGate; inputs = leaf words, sibling[4], bit, expected parent[4].
  * Inputs = operands followed by the expected result(s); a wrong expectation fails the proof with
  * P25_ERR_WITNESS_CONFLICT, as the failing `connect` panics upstream. */
 p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** out);

@@ -197,6 +197,30 @@ void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitnes
       for (int i = 0; i < 12; i++) out.push_back(st[i]);
       break;
     }
+    case RGEN_ARITH_EXT: {  // upstream ArithmeticExtensionGenerator: out = c0*m0*m1 + c1*addend in F_p^2
+      RE2 m0{d(0), d(1)}, m1{d(2), d(3)}, ad{d(4), d(5)};
+      RE2 r = re_add(re_muls(re_mul(m0, m1), g.c0), re_muls(ad, g.c1));
+      out.push_back(r.a);
+      out.push_back(r.b);
+      break;
+    }
+    case RGEN_POSEIDON: {  // upstream PoseidonGenerator (hash/poseidon.rs + gates/poseidon.rs)
+      u64 st[12];
+      for (int i = 0; i < 12; i++) st[i] = d(i);
+      u64 swap = d(12);
+      for (int i = 0; i < 4; i++) out.push_back(rf_mul(swap, rf_sub(st[i + 4], st[i])));
+      if (swap == 1)
+        for (int i = 0; i < 4; i++) {
+          u64 t = st[i];
+          st[i] = st[i + 4];
+          st[i + 4] = t;
+        }
+      u64 tr[106];
+      ref_poseidon_trace(st, tr);
+      for (int i = 0; i < 106; i++) out.push_back(tr[i]);
+      for (int i = 0; i < 12; i++) out.push_back(st[i]);
+      break;
+    }
     case RGEN_U32_ARITHMETIC: {  // arithmetic_u32.rs:389-439: outs low, high, inverse, 32 two-bit limbs
       u64 o = rf_add(rf_mul(d(0), d(1)), d(2));
       u64 hi = o >> 32, lo = o & 0xFFFFFFFFull;

@@ -8,6 +8,7 @@
 //   U32ArithmeticGate        src/common/u32/gates/arithmetic_u32.rs:106-165 (303-366)
 //   U32InterleaveGate        src/common/u32/gates/interleave_u32.rs:102-142 (250-287)
 //   UninterleaveToU32Gate    src/common/u32/gates/uninterleave_to_u32.rs:114-163 (285-335)
+//   ArithmeticExtensionGate, PoseidonGate (recursion) and
 //   Noop/Constant/PublicInput/BaseSum<2>/Arithmetic/MulExtension/Exponentiation: upstream plonky2 @
 //   3de92d9 gates/*.rs (absent crate), restated from SURVEY.md App. A.12 / the published gate definitions.
 #pragma once
@@ -39,6 +40,23 @@ namespace refp2 {
 #define REF_P2_RC_MID refp2::P2_RC_MID
 #define REF_P2_DIAG_M1 refp2::P2_MAT_DIAG_M_1
 
+namespace refp1 {
+static const u64 RC[360] = {
+#include "poseidon_constants.inc"
+};
+static const u64 MDS_CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+}
+#define REF_POSEIDON_RC refp1::RC
+template <class F>
+static void g_poseidon_mds(F s[12]) {  // circ(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...)
+  F o[12];
+  for (int r = 0; r < 12; r++) {
+    F acc = r == 0 ? s[0].smul(8) : F::from(0);
+    for (int i = 0; i < 12; i++) acc = acc + s[(i + r) % 12].smul(refp1::MDS_CIRC[i]);
+    o[r] = acc;
+  }
+  for (int r = 0; r < 12; r++) s[r] = o[r];
+}
 template <class F>
 static F g_pow7(F x) {
   F x2 = x * x, x4 = x2 * x2, x3 = x * x2;
@@ -206,6 +224,50 @@ static int ref_eval_gate(u32 kind, const F* w, const F* k, const F* pih, F* out)
         }
         for (int i = 0; i < 12; i++) st[i] = g_pow7(st[i]);
         g_p2_external(st);
+      }
+      for (int i = 0; i < 12; i++) out[nc++] = st[i] - w[12 + i];
+      return nc;
+    }
+    case RG_ARITH_EXT:  // out - (c0 * m0 * m1 + c1 * addend) over the algebra X^2 = 7, 10 ops of 8 wires
+      for (int i = 0; i < 10; i++) {
+        const F* a = w + 8 * i;
+        const F* b = w + 8 * i + 2;
+        const F* ad = w + 8 * i + 4;
+        const F* o = w + 8 * i + 6;
+        F c0 = (a[0] * b[0] + (a[1] * b[1]).smul(7)) * k[0] + ad[0] * k[1];
+        F c1 = (a[0] * b[1] + a[1] * b[0]) * k[0] + ad[1] * k[1];
+        out[nc++] = o[0] - c0;
+        out[nc++] = o[1] - c1;
+      }
+      return nc;
+    case RG_POSEIDON: {  // upstream gates/poseidon.rs eval_unfiltered, rounds in the naive form (the constraint
+                         // polynomials are the same: the fast partial rounds are a linear change of basis)
+      F swap = w[24];
+      out[nc++] = swap * (swap - one);
+      for (int i = 0; i < 4; i++) out[nc++] = swap * (w[i + 4] - w[i]) - w[25 + i];
+      F st[12];
+      for (int i = 0; i < 4; i++) {
+        st[i] = w[i] + w[25 + i];
+        st[i + 4] = w[i + 4] - w[25 + i];
+      }
+      for (int i = 8; i < 12; i++) st[i] = w[i];
+      int tr = 29;
+      for (int r = 0; r < 30; r++) {
+        for (int i = 0; i < 12; i++) st[i] = st[i] + F::from(REF_POSEIDON_RC[12 * r + i]);
+        if (r < 4 || r >= 26) {
+          if (r != 0)
+            for (int i = 0; i < 12; i++) {
+              F sb = w[tr++];
+              out[nc++] = st[i] - sb;
+              st[i] = sb;
+            }
+          for (int i = 0; i < 12; i++) st[i] = g_pow7(st[i]);
+        } else {
+          F sb = w[tr++];
+          out[nc++] = st[0] - sb;
+          st[0] = g_pow7(sb);
+        }
+        g_poseidon_mds(st);
       }
       for (int i = 0; i < 12; i++) out[nc++] = st[i] - w[12 + i];
       return nc;

@@ -97,6 +97,22 @@ void ref_poseidon_naive(u64 s[12]) {
   }
 }
 
+void ref_poseidon_trace(u64 s[12], u64* trace) {
+  int k = 0;
+  for (int r = 0; r < 30; r++) {
+    for (int i = 0; i < 12; i++) s[i] = rf_add(s[i], POSEIDON_RC[12 * r + i]);
+    if (r < 4 || r >= 26) {
+      if (r != 0 && trace)
+        for (int i = 0; i < 12; i++) trace[k++] = s[i];
+      for (int i = 0; i < 12; i++) s[i] = pow7(s[i]);
+    } else {
+      if (trace) trace[k++] = s[0];
+      s[0] = pow7(s[0]);
+    }
+    poseidon_mds(s);
+  }
+}
+
 // poseidon2.rs:184-213 (matmul_m4) + :126-147 (matmul_external)
 static void p2_external(u64 s[12]) {
   for (int b = 0; b < 3; b++) {

@@ -18,6 +18,10 @@
 
 void ref_poseidon(u64 s[12]);        // optimised partial rounds (upstream's CPU form)
 void ref_poseidon_naive(u64 s[12]);  // the definition: 30 x {add constants, S-box, MDS}
+// Poseidon (v1), naive form, with the S-box-input trace upstream's PoseidonGate stores as wires (same layout as
+// the Poseidon2 gate, which was cloned from it): [0..36) full rounds 1..3, [36..58) partial rounds, [58..106) full
+// rounds 26..29.  trace may be null.
+void ref_poseidon_trace(u64 s[12], u64* trace);
 void ref_poseidon2(u64 s[12]);
 // Poseidon2 with the S-box-input trace the Poseidon2Gate stores as wires (poseidon2_gate.rs:447-523):
 // trace[0..36) full rounds 1..3, [36..58) partial rounds, [58..106) full rounds 4..7.

@@ -23,6 +23,8 @@ static const GateInfo GATE_INFOS[G_NUM_KINDS] = {
     {"ExponentiationGate { num_power_bits: 66, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>", 4, 0, EXP_POWER_BITS + 1, 1},
     {"U32ArithmeticGate { num_ops: 3, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }", 4, 0, 3 * 36, 3},
     {"Poseidon2Gate { _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<WIDTH=12>", 7, 0, 123, 1},
+    {"ArithmeticExtensionGate { num_ops: 10 }", 3, 2, 20, 10},
+    {"PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", 7, 0, 123, 1},
 };
 const GateInfo& gate_info(GateKind k) { return GATE_INFOS[k]; }
 
@@ -143,36 +145,105 @@ Target CircuitBuilder::select(BoolTarget b, Target x, Target y) {
   return mul_sub(b, x, tmp);
 }
 
-// mul_extension = arithmetic_extension(1, 0, a, b, zero_ext): special cases, memo, MulExtensionGate
-Ext CircuitBuilder::mul_extension(Ext a, Ext b) {
-  Target z = zero();
-  Ext zext = {z, z};
-  auto as_const = [&](Ext e) -> std::optional<gl::E2> {
-    auto x = target_as_constant(e[0]), y = target_as_constant(e[1]);
-    if (x && y) return gl::E2{*x, *y};
-    return std::nullopt;
-  };
-  auto ka = as_const(a), kb = as_const(b);
-  bool first_zero = a == zext || b == zext;
-  if (first_zero) return Ext{constant(0), constant(0)};
-  if (ka && kb) {
-    gl::E2 p = gl::mul(*ka, *kb);
-    return Ext{constant(p.a), constant(p.b)};
+// upstream gadgets/arithmetic_extension.rs `arithmetic_extension`: c0 * m0 * m1 + c1 * addend in F_p^2.  Special
+// cases first (arithmetic_extension_special_cases), then the memo, then a MulExtensionGate slot when the addend is
+// the zero constant and an ArithmeticExtensionGate slot otherwise.
+std::optional<gl::E2> CircuitBuilder::target_as_constant_ext(Ext e) const {
+  auto x = target_as_constant(e[0]), y = target_as_constant(e[1]);
+  if (x && y) return gl::E2{*x, *y};
+  return std::nullopt;
+}
+Ext CircuitBuilder::arithmetic_extension(u64 c0, u64 c1, Ext m0, Ext m1, Ext addend) {
+  const Ext zext = zero_extension();
+  auto k0 = target_as_constant_ext(m0), k1 = target_as_constant_ext(m1), ka = target_as_constant_ext(addend);
+  const bool first_zero = c0 == 0 || m0 == zext || m1 == zext;
+  const bool second_zero = c1 == 0 || addend == zext;
+  std::optional<gl::E2> first_const, second_const;
+  if (first_zero)
+    first_const = gl::E2{0, 0};
+  else if (k0 && k1)
+    first_const = gl::mul(gl::mul(*k0, *k1), c0);
+  if (second_zero)
+    second_const = gl::E2{0, 0};
+  else if (ka)
+    second_const = gl::mul(*ka, c1);
+  if (first_const && second_const) return constant_extension(gl::add(*first_const, *second_const));
+  if (first_zero && c1 == 1) return addend;
+  if (second_zero) {
+    auto is_one = [](gl::E2 x) { return x.a == 1 && x.b == 0; };
+    if (k0 && is_one(gl::mul(*k0, c0))) return m1;
+    if (k1 && is_one(gl::mul(*k1, c0))) return m0;
   }
-  if (ka && ka->a == 1 && ka->b == 0) return b;
-  if (kb && kb->a == 1 && kb->b == 0) return a;
-  std::array<Target, 4> key = {a[0], a[1], b[0], b[1]};
-  auto it = mul_ext_memo_.find(key);
-  if (it != mul_ext_memo_.end()) return it->second;
-  auto [row, i] = find_slot(G_MUL_EXT, 1, 1, 0);
-  for (int d = 0; d < 2; d++) {
-    connect(a[d], wire(row, 6 * i + d));
-    connect(b[d], wire(row, 6 * i + 2 + d));
+  ExtArithKey key{c0, c1, {m0[0], m0[1], m1[0], m1[1], addend[0], addend[1]}};
+  auto it = ext_arithmetic_results_.find(key);
+  if (it != ext_arithmetic_results_.end()) return it->second;
+  Ext out;
+  if (ka && ka->a == 0 && ka->b == 0) {  // addend is the zero constant: MulExtensionGate
+    auto [row, i] = find_slot(G_MUL_EXT, 1, c0, 0);
+    for (int d = 0; d < 2; d++) {
+      connect(m0[d], wire(row, 6 * i + d));
+      connect(m1[d], wire(row, 6 * i + 2 + d));
+    }
+    out = {wire(row, 6 * i + 4), wire(row, 6 * i + 5)};
+  } else {
+    auto [row, i] = find_slot(G_ARITH_EXT, 2, c0, c1);
+    for (int d = 0; d < 2; d++) {
+      connect(m0[d], wire(row, 8 * i + d));
+      connect(m1[d], wire(row, 8 * i + 2 + d));
+      connect(addend[d], wire(row, 8 * i + 4 + d));
+    }
+    out = {wire(row, 8 * i + 6), wire(row, 8 * i + 7)};
   }
-  Ext out = {wire(row, 6 * i + 4), wire(row, 6 * i + 5)};
-  mul_ext_memo_[key] = out;
+  ext_arithmetic_results_[key] = out;
   return out;
 }
+Ext CircuitBuilder::mul_extension(Ext a, Ext b) { return arithmetic_extension(1, 0, a, b, zero_extension()); }
+Ext CircuitBuilder::add_many_extension(const std::vector<Ext>& terms) {
+  Ext sum = zero_extension();
+  for (const Ext& t : terms) sum = add_extension(sum, t);
+  return sum;
+}
+Ext CircuitBuilder::mul_many_extension(const std::vector<Ext>& terms) {
+  Ext prod = one_extension();
+  for (const Ext& t : terms) prod = mul_extension(prod, t);
+  return prod;
+}
+Ext CircuitBuilder::exp_u64_extension(Ext base, u64 exponent) {
+  if (exponent == 0) return one_extension();
+  if (exponent == 1) return base;
+  if (exponent == 2) return square_extension(base);
+  Ext current = base, product = one_extension();
+  int bits = 64 - __builtin_clzll(exponent);
+  for (int j = 0; j < bits; j++) {
+    if (j != 0) current = square_extension(current);
+    if ((exponent >> j) & 1) product = mul_extension(product, current);
+  }
+  return product;
+}
+Ext CircuitBuilder::exp_power_of_2_extension(Ext base, int power_log) {
+  for (int i = 0; i < power_log; i++) base = square_extension(base);
+  return base;
+}
+// x / y + z with a virtual inverse and QuotientGeneratorExtension (y * inv == 1 enforced)
+Ext CircuitBuilder::div_add_extension(Ext x, Ext y, Ext z) {
+  Ext inv = add_virtual_extension_target();
+  Ext one_e = one_extension();
+  Generator g;
+  g.kind = GEN_QUOTIENT_EXT;
+  g.deps = {one_e[0], one_e[1], y[0], y[1]};
+  g.outs = {inv[0], inv[1]};
+  add_generator(g);
+  Ext y_inv = mul_extension(y, inv);
+  connect_extension(y_inv, one_e);
+  return mul_add_extension(x, inv, z);
+}
+// select(b, x, y) = b*x + (1-b)*y  (upstream gadgets/select.rs: tmp = b*y - y; b*x - tmp)
+Ext CircuitBuilder::select_ext(BoolTarget b, Ext x, Ext y) {
+  Ext be = convert_to_ext(b);
+  Ext tmp = mul_sub_extension(be, y, y);
+  return mul_sub_extension(be, x, tmp);
+}
+
 // inverse(x) = inverse_extension([x, 0]).0[0] = div_add_extension(one, [x,0], zero).0[0]
 Target CircuitBuilder::inverse(Target x) {
   Target z = zero();
@@ -335,6 +406,34 @@ std::array<Target, 12> CircuitBuilder::poseidon2_permute_targets(const std::arra
   std::array<Target, 12> out;
   for (int i = 0; i < 12; i++) out[i] = wire(row, 12 + i);
   return out;
+}
+
+// upstream hash/poseidon.rs `PoseidonHash::permute_swapped` on a PoseidonGate row
+std::array<Target, 12> CircuitBuilder::poseidon_permute_swapped(const std::array<Target, 12>& in, BoolTarget swap) {
+  int row = add_gate(G_POSEIDON);
+  connect(swap, wire(row, 24));
+  for (int i = 0; i < 12; i++) connect(in[i], wire(row, i));
+  std::array<Target, 12> out;
+  for (int i = 0; i < 12; i++) out[i] = wire(row, 12 + i);
+  return out;
+}
+// upstream hash/hashing.rs `hash_n_to_m_no_pad` in-circuit (overwrite mode, rate 8), first 4 outputs
+std::array<Target, 4> CircuitBuilder::hash_n_to_hash_no_pad(const std::vector<Target>& inputs) {
+  std::array<Target, 12> state;
+  for (auto& t : state) t = zero();
+  for (size_t off = 0; off < inputs.size(); off += 8) {
+    for (size_t i = 0; i < 8 && off + i < inputs.size(); i++) state[i] = inputs[off + i];
+    state = poseidon_permute(state);
+  }
+  return {state[0], state[1], state[2], state[3]};
+}
+std::array<Target, 4> CircuitBuilder::hash_or_noop(const std::vector<Target>& inputs) {
+  if (inputs.size() <= 4) {
+    std::array<Target, 4> h;
+    for (int i = 0; i < 4; i++) h[i] = i < (int)inputs.size() ? inputs[i] : zero();
+    return h;
+  }
+  return hash_n_to_hash_no_pad(inputs);
 }
 
 // ---------------------------------------------------------------- build
@@ -608,9 +707,21 @@ Circuit CircuitBuilder::build() {
           c.generators.push_back(std::move(g));
         }
         break;
+      case G_ARITH_EXT:
+        for (int i = 0; i < ops; i++) {
+          Generator g;
+          g.kind = GEN_ARITH_EXT;
+          g.c0 = gi.constants[0];
+          g.c1 = gi.constants[1];
+          for (int k = 0; k < 6; k++) g.deps.push_back(wire(r, 8 * i + k));
+          g.outs = {wire(r, 8 * i + 6), wire(r, 8 * i + 7)};
+          c.generators.push_back(std::move(g));
+        }
+        break;
+      case G_POSEIDON:
       case G_POSEIDON2: {
         Generator g;
-        g.kind = GEN_POSEIDON2;
+        g.kind = gi.kind == G_POSEIDON ? GEN_POSEIDON : GEN_POSEIDON2;
         for (int i = 0; i < 12; i++) g.deps.push_back(wire(r, i));
         g.deps.push_back(wire(r, 24));
         for (int i = 0; i < 4; i++) g.outs.push_back(wire(r, 25 + i));     // delta

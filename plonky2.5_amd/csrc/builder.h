@@ -61,6 +61,9 @@ enum GateKind : uint8_t {
   G_EXPONENTIATION,     // ExponentiationGate{num_power_bits: 66}
   G_U32_ARITHMETIC,     // src/common/u32/gates/arithmetic_u32.rs
   G_POSEIDON2,          // src/common/poseidon2/poseidon2_gate.rs
+  // recursion: the gates of upstream's recursive verifier used by recursion.cpp
+  G_ARITH_EXT,          // ArithmeticExtensionGate{num_ops: 10}
+  G_POSEIDON,           // PoseidonGate (Poseidon v1 permutation with swap; hashes and Merkle paths of inner proofs)
   G_NUM_KINDS
 };
 struct GateInfo {
@@ -89,6 +92,8 @@ enum GenKind : uint32_t {
   GEN_U32_ARITHMETIC,   // arithmetic_u32.rs:389-439
   GEN_U32_INTERLEAVE,   // interleave_u32.rs:305-334
   GEN_U32_UNINTERLEAVE, // uninterleave_to_u32.rs:353-390
+  GEN_ARITH_EXT,        // ArithmeticExtensionGenerator: out = c0*m0*m1 + c1*addend in F_p^2
+  GEN_POSEIDON,         // PoseidonGenerator: deltas, S-box inputs, outputs of one Poseidon permutation
   GEN_NUM_KINDS
 };
 struct Generator {
@@ -176,8 +181,40 @@ class CircuitBuilder {
   Target select(BoolTarget b, Target x, Target y);
   Target _if(BoolTarget b, Target x, Target y) { return select(b, x, y); }
 
-  // ---- extension arithmetic, only what `inverse` needs (gadgets/arithmetic_extension.rs) ----
+  // ---- extension arithmetic (upstream gadgets/arithmetic_extension.rs) ----
   Ext mul_extension(Ext a, Ext b);
+  Ext arithmetic_extension(u64 c0, u64 c1, Ext m0, Ext m1, Ext addend);
+  Ext constant_extension(gl::E2 c) { return Ext{constant(c.a), constant(c.b)}; }
+  Ext zero_extension() { return Ext{zero(), zero()}; }
+  Ext one_extension() { return Ext{one(), zero()}; }
+  Ext convert_to_ext(Target t) { return Ext{t, zero()}; }
+  Ext add_virtual_extension_target() { Target a = add_virtual_target(); Target b = add_virtual_target(); return Ext{a, b}; }
+  std::optional<gl::E2> target_as_constant_ext(Ext e) const;
+  Ext add_extension(Ext a, Ext b) { return arithmetic_extension(1, 1, one_extension(), a, b); }
+  Ext sub_extension(Ext a, Ext b) { return arithmetic_extension(1, gl::P - 1, one_extension(), a, b); }
+  Ext mul_extension_with_const(u64 c, Ext a, Ext b) { return arithmetic_extension(c, 0, a, b, zero_extension()); }
+  Ext mul_add_extension(Ext a, Ext b, Ext c) { return arithmetic_extension(1, 1, a, b, c); }
+  Ext mul_sub_extension(Ext a, Ext b, Ext c) { return arithmetic_extension(1, gl::P - 1, a, b, c); }
+  Ext mul_const_extension(u64 c, Ext x) { return mul_extension_with_const(c, one_extension(), x); }
+  Ext mul_const_add_extension(u64 c, Ext x, Ext y) { return arithmetic_extension(c, 1, one_extension(), x, y); }
+  Ext scalar_mul_ext(Target a, Ext b) { return mul_extension(convert_to_ext(a), b); }
+  Ext square_extension(Ext a) { return mul_extension(a, a); }
+  Ext add_many_extension(const std::vector<Ext>& terms);
+  Ext mul_many_extension(const std::vector<Ext>& terms);
+  Ext exp_u64_extension(Ext base, u64 exponent);
+  Ext exp_power_of_2_extension(Ext base, int power_log);
+  Ext div_add_extension(Ext x, Ext y, Ext z);
+  Ext div_extension(Ext x, Ext y) { return div_add_extension(x, y, zero_extension()); }
+  Ext inverse_extension(Ext y) { return div_extension(one_extension(), y); }
+  void connect_extension(Ext a, Ext b) { connect(a[0], b[0]); connect(a[1], b[1]); }
+  Ext select_ext(BoolTarget b, Ext x, Ext y);
+
+  // ---- Poseidon (v1) in-circuit: upstream gates/poseidon.rs + hash/poseidon.rs `permute_swapped` ----
+  std::array<Target, 12> poseidon_permute_swapped(const std::array<Target, 12>& in, BoolTarget swap);
+  std::array<Target, 12> poseidon_permute(const std::array<Target, 12>& in) { return poseidon_permute_swapped(in, _false()); }
+  // hash_n_to_hash_no_pad::<PoseidonHash> (overwrite sponge, rate 8) and hash_or_noop
+  std::array<Target, 4> hash_n_to_hash_no_pad(const std::vector<Target>& inputs);
+  std::array<Target, 4> hash_or_noop(const std::vector<Target>& inputs);
 
   // ---- split/join, range checks (gadgets/split_join.rs, split_base.rs, range_check.rs) ----
   std::vector<BoolTarget> split_le(Target integer, int num_bits);
@@ -234,6 +271,16 @@ class CircuitBuilder {
   std::vector<ConstGen> constant_generators_;
   std::vector<Generator> generators_;
   std::map<std::array<Target, 4>, Ext> mul_ext_memo_;
+  struct ExtArithKey {
+    u64 c0, c1;
+    std::array<Target, 6> t;
+    bool operator<(const ExtArithKey& o) const {
+      if (c0 != o.c0) return c0 < o.c0;
+      if (c1 != o.c1) return c1 < o.c1;
+      return t < o.t;
+    }
+  };
+  std::map<ExtArithKey, Ext> ext_arithmetic_results_;
 };
 
 // FRI arity schedule (upstream FriReductionStrategy::ConstantArityBits)

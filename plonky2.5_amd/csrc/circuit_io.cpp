@@ -38,7 +38,8 @@ bool generator_shape_ok(GenKind k, size_t nd, size_t no, int aux) {
     case GEN_BASE_SUM: return nd >= 1 && nd <= 64 && no == 1;
     case GEN_LOW_HIGH: return nd == 1 && no == 2 && aux >= 1 && aux <= 63;
     case GEN_EXPONENTIATION: return nd >= 2 && nd <= 128 && no == nd;
-    case GEN_POSEIDON2: return nd == 13 && no == 122;
+    case GEN_POSEIDON2: case GEN_POSEIDON: return nd == 13 && no == 122;
+    case GEN_ARITH_EXT: return nd == 6 && no == 2;
     case GEN_U32_ARITHMETIC: return nd == 3 && no == 35;
     case GEN_U32_INTERLEAVE: return nd == 1 && no == 33;
     case GEN_U32_UNINTERLEAVE: return nd == 1 && no == 66;

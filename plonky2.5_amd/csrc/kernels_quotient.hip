@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include "builder.h"
 #include "kernels.h"
+#include "poseidon.h"
 #include "poseidon2.h"
 #include "coop.h"
 #include "prover_kernels.h"
@@ -289,6 +290,50 @@ __device__ void gate_poseidon2(Ctx& cx) {
   for (int i = 0; i < 12; i++) cx.at(nc++, gl::sub(st[i], cx.w(12 + i)));
 }
 
+// upstream gates/arithmetic_extension.rs: out - (c0 * m0 * m1 + c1 * addend) in F_p^2, 10 ops of 8 wires
+__device__ void gate_arith_ext(Ctx& cx, u64 k0, u64 k1) {
+  for (int i = 0; i < 10; i++) {
+    gl::E2 a{cx.w(8 * i), cx.w(8 * i + 1)}, b{cx.w(8 * i + 2), cx.w(8 * i + 3)}, ad{cx.w(8 * i + 4), cx.w(8 * i + 5)};
+    gl::E2 r = gl::add(gl::mul(gl::mul(a, b), k0), gl::mul(ad, k1));
+    cx.at(2 * i, gl::sub(cx.w(8 * i + 6), r.a));
+    cx.at(2 * i + 1, gl::sub(cx.w(8 * i + 7), r.b));
+  }
+}
+// upstream gates/poseidon.rs eval_unfiltered_base_one (rounds in the defining form; same constraint polynomials as
+// upstream's fast partial rounds, which are a linear change of basis on lanes 1..11)
+__device__ void gate_poseidon(Ctx& cx) {
+  int nc = 0;
+  u64 swap = cx.w(24);
+  cx.at(nc++, gl::mul_nc(swap, gl::sub(swap, 1)));
+  u64 st[12];
+  for (int i = 0; i < 4; i++) {
+    u64 lhs = cx.w(i), rhs = cx.w(i + 4), delta = cx.w(25 + i);
+    cx.at(nc++, gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+    st[i] = gl::add(lhs, delta);
+    st[i + 4] = gl::sub(rhs, delta);
+  }
+  for (int i = 8; i < 12; i++) st[i] = cx.w(i);
+  int tr = 29;
+  for (int r = 0; r < poseidon::N_ROUNDS; r++) {
+    for (int i = 0; i < 12; i++) st[i] = poseidon::add_rc(st[i], poseidon::RC[12 * r + i]);
+    if (r < poseidon::HALF_FULL || r >= poseidon::HALF_FULL + poseidon::N_PARTIAL) {
+      if (r != 0)
+        for (int i = 0; i < 12; i++) {
+          u64 sb = cx.w(tr++);
+          cx.at(nc++, gl::sub(gl::canon(st[i]), sb));
+          st[i] = sb;
+        }
+      for (int i = 0; i < 12; i++) st[i] = poseidon::sbox(st[i]);
+    } else {
+      u64 sb = cx.w(tr++);
+      cx.at(nc++, gl::sub(gl::canon(st[0]), sb));
+      st[0] = poseidon::sbox(sb);
+    }
+    poseidon::mds(st);
+  }
+  for (int i = 0; i < 12; i++) cx.at(nc++, gl::sub(gl::canon(st[i]), cx.w(12 + i)));
+}
+
 }  // namespace
 
 // alpha_pows[c][j] = alpha_c^j, j < ALPHA_POWS
@@ -307,7 +352,10 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
 #ifndef P25_Q_WAVES
 #define P25_Q_WAVES 5
 #endif
-__global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
+// REC: the gate set of recursive-verifier circuits (adds ArithmeticExtensionGate and PoseidonGate).  The fib-64 hot
+// path runs the REC = false instantiation, whose code is what it was before those gates existed.
+template <bool REC>
+__device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   __shared__ u64 ap[2 * ALPHA_POWS];
   __shared__ AlphaLimbs apl[ALPHA_POWS];
   for (int i = threadIdx.x; i < 2 * ALPHA_POWS; i += blockDim.x) {
@@ -338,7 +386,8 @@ __global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
   const size_t p_next = gl::bitrev(i_next, lde_bits);
 
   const int NC = 2, NP = (int)a.num_partial_products, RW = (int)a.num_routed;
-  const int nch = NP + 1, per = (RW + nch - 1) / nch;
+  // chunks of max_quotient_degree_factor routed wires (upstream partial_products.rs), NP + 1 of them
+  const int nch = NP + 1, per = (int)a.quotient_degree_factor;
   const u64* cs = a.cs_lde + p;
   const u64* wr = a.wires_lde + p;
   const u64* zs = a.zs_lde + p;
@@ -407,6 +456,12 @@ __global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
         case G_EXPONENTIATION: gate_exponentiation(cx); break;
         case G_U32_ARITHMETIC: gate_u32_arithmetic(cx); break;
         case G_POSEIDON2: gate_poseidon2(cx); break;
+        case G_ARITH_EXT:
+          if constexpr (REC) gate_arith_ext(cx, k0, k1);
+          break;
+        case G_POSEIDON:
+          if constexpr (REC) gate_poseidon(cx);
+          break;
         default: break;  // NoopGate: no constraints
       }
       g0 = gl::add(g0, gl::mul(filter, cx.acc0()));
@@ -419,6 +474,9 @@ __global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
   a.out[p] = gl::mul(res[0], zhi);
   a.out[big + p] = gl::mul(res[1], zhi);
 }
+
+__global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) { quotient_body<false>(a); }
+__global__ __launch_bounds__(128, 2) void k_quotient_rec(QuotientArgs a) { quotient_body<true>(a); }
 
 // out[p] = 1 / (n (x_p - 1)), x_p = g w_big^rev(p): the point-dependent factor of L_0(x) = Z_H(x) / (n (x - 1)).
 __global__ __launch_bounds__(256) void k_l0_inv(const u64* __restrict__ pow_big, uint32_t degree_bits,
@@ -451,7 +509,12 @@ void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
         gate_info((GateKind)a.gates[gi].kind).num_constraints > ALPHA_POWS)
       throw std::runtime_error("quotient: gate with too many constraints for the alpha-power table");
   const size_t big = (size_t)1 << (a.degree_bits + a.rate_bits);
-  hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
+  bool rec = false;
+  for (uint32_t gi = 0; gi < a.n_gates; gi++) rec |= a.gates[gi].kind == G_ARITH_EXT || a.gates[gi].kind == G_POSEIDON;
+  if (rec)
+    hipLaunchKernelGGL(k_quotient_rec, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
 }
 
 }  // namespace p25

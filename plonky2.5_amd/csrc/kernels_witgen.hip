@@ -12,6 +12,7 @@
 // QuotientGeneratorExtension, BaseSplitGenerator<2>, WireSplitGenerator, BaseSumGenerator<2>,
 // LowHighGenerator, ExponentiationGenerator.
 #include "kernels.h"
+#include "poseidon.h"
 #include "poseidon2.h"
 #include "coop.h"
 #include "prover_kernels.h"
@@ -143,6 +144,28 @@ __device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* 
       P2Tracer tr{emit};
       poseidon2::permute_impl(st, tr);
 #pragma unroll
+      for (int i = 0; i < 12; i++) emit(4 + 106 + i, st[i]);
+      break;
+    }
+    case GEN_ARITH_EXT: {  // upstream ArithmeticExtensionGenerator
+      gl::E2 r = gl::add(gl::mul(gl::mul(gl::E2{d(0), d(1)}, gl::E2{d(2), d(3)}), g.c0), gl::mul(gl::E2{d(4), d(5)}, g.c1));
+      emit(0, r.a);
+      emit(1, r.b);
+      break;
+    }
+    case GEN_POSEIDON: {  // upstream PoseidonGenerator: same wire layout as the Poseidon2 gate cloned from it
+      u64 st[12];
+      for (int i = 0; i < 12; i++) st[i] = d(i);
+      u64 swap = d(12);
+      for (int i = 0; i < 4; i++) emit(i, gl::mul(swap, gl::sub(st[i + 4], st[i])));
+      if (swap == 1) {
+        for (int i = 0; i < 4; i++) {
+          u64 t = st[i];
+          st[i] = st[i + 4];
+          st[i + 4] = t;
+        }
+      }
+      poseidon::permute_naive_trace(st, [&](int k, u64 v) { emit(4 + k, v); });
       for (int i = 0; i < 12; i++) emit(4 + 106 + i, st[i]);
       break;
     }

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_zpp_chunks(ZppArgs a) {
   const u64 beta = a.chal[CH_BETAS + c], gamma = a.chal[CH_GAMMAS + c];
   const u64 x = a.pow_n[r];
   const int nch = (int)a.num_partial_products + 1;
-  const int per = ((int)a.num_routed + nch - 1) / nch;  // = quotient_degree_factor
+  const int per = (int)a.quotient_degree_factor;  // routed wires per chunk (max_quotient_degree_factor)
   u64 num[MAX_CHUNKS], den[MAX_CHUNKS];
   for (int k = 0; k < nch; k++) {
     u64 np = 1, dp = 1;

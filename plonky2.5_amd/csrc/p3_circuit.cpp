@@ -807,6 +807,36 @@ Circuit build_gadget_circuit(int kind, int param) {
       cb.connect(cb.mul(a, b), expected);
       break;
     }
+    case GADGET_EXT_ARITH: {  // extension-field gadgets of upstream gadgets/arithmetic_extension.rs (recursion, 8f-4)
+      Ext a = {in(), in()}, b = {in(), in()}, c = {in(), in()};
+      Ext t = cb.mul_add_extension(a, b, c);                    // a*b + c          (ArithmeticExtensionGate)
+      t = cb.sub_extension(cb.mul_extension(t, a), b);          // t*a - b          (MulExtensionGate, ArithmeticExtensionGate)
+      t = cb.mul_const_add_extension(5, t, cb.constant_extension(gl::E2{3, 9}));
+      Ext t7 = cb.exp_u64_extension(t, 7);
+      Ext q = cb.div_extension(t7, c);                          // virtual inverse + QuotientGeneratorExtension
+      Ext s = cb.add_many_extension({q, a, b, cb.scalar_mul_ext(a[0], b)});
+      cb.connect_extension(s, Ext{in(), in()});
+      break;
+    }
+    case GADGET_POSEIDON_MERKLE: {  // hash_or_noop of `param` words, then one Merkle step with a swap bit (PoseidonGate)
+      if (param < 1 || param > 200) throw std::invalid_argument("poseidon gadget: 1..200 leaf words");
+      std::vector<Target> leaf;
+      for (int i = 0; i < param; i++) leaf.push_back(in());
+      std::array<Target, 4> h = cb.hash_or_noop(leaf);
+      std::array<Target, 4> sib;
+      for (auto& t : sib) t = in();
+      Target bit = in();
+      cb.connect(cb.mul_sub(bit, bit, bit), cb.zero());        // bit is boolean
+      std::array<Target, 12> st;
+      for (int i = 0; i < 4; i++) {
+        st[i] = h[i];
+        st[4 + i] = sib[i];
+        st[8 + i] = cb.zero();
+      }
+      auto out = cb.poseidon_permute_swapped(st, bit);
+      for (int i = 0; i < 4; i++) cb.connect(out[i], in());
+      break;
+    }
     default:
       throw std::invalid_argument("unknown gadget kind");
   }

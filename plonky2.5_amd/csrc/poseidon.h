@@ -66,6 +66,32 @@ GL_HD u64 add_rc(u64 x, u64 c) {
   return s < x ? s + gl::EPS : s;  // on wrap: +2^64 == +EPS; cannot wrap twice since c < p
 }
 
+// The permutation in its defining (naive) form with the S-box inputs handed to `tr(k, value)` (canonical), in the
+// order upstream's PoseidonGate stores them as wires: full rounds 1..3 (36), partial rounds (22, lane 0), full
+// rounds 26..29 (48).  Used by the PoseidonGate witness generator and constraint evaluator (recursion, SURVEY
+// 8f-4) -- not by the hashing kernels, which run the fused form below.
+template <class Tracer>
+GL_HD void permute_naive_trace(u64 s[WIDTH], Tracer&& tr) {
+  int k = 0;
+  for (int r = 0; r < N_ROUNDS; r++) {
+    for (int i = 0; i < WIDTH; i++) s[i] = add_rc(s[i], RC[WIDTH * r + i]);
+    if (r < HALF_FULL || r >= HALF_FULL + N_PARTIAL) {
+      if (r != 0)
+        for (int i = 0; i < WIDTH; i++) {
+          s[i] = gl::canon(s[i]);
+          tr(k++, s[i]);
+        }
+      for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
+    } else {
+      s[0] = gl::canon(s[0]);
+      tr(k++, s[0]);
+      s[0] = sbox(s[0]);
+    }
+    mds(s);
+  }
+  for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---- gfx950 device form -------------------------------------------------------------------------
 // Round constants split into zero-extended 32-bit halves, one (lo, hi) pair per constant, plus a

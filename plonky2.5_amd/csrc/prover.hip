@@ -271,6 +271,7 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
   qa_proto_.num_wires = c_.cfg.num_wires;
   qa_proto_.num_routed = c_.cfg.num_routed_wires;
   qa_proto_.num_partial_products = c_.num_partial_products;
+  qa_proto_.quotient_degree_factor = c_.cfg.max_quotient_degree_factor;
   qa_proto_.degree_bits = c_.degree_bits;
   qa_proto_.rate_bits = c_.cfg.rate_bits;
   {
@@ -535,6 +536,7 @@ void DeviceCircuit::enqueue_partial_products(Ctx& x, hipStream_t st) {
     za.num_routed = c_.cfg.num_routed_wires;
     za.num_partial_products = NP;
     za.num_challenges = NC;
+    za.quotient_degree_factor = c_.cfg.max_quotient_degree_factor;
     launch_zpp(za, st);
   }
 }

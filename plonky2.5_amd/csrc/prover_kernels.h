@@ -62,6 +62,7 @@ struct QuotientArgs {
   u64* out;              // [NC][big] quotient values at bit-reversed positions
   GateEntry gates[16];
   uint32_t n_gates, num_selectors, num_wires, num_routed, num_partial_products, degree_bits, rate_bits;
+  uint32_t quotient_degree_factor;  // routed wires per partial-product chunk (max_quotient_degree_factor)
   u64 zh[8], zh_inv[8];  // Z_H on the coset (index = i mod 2^rate_bits), and inverses
   const u64* l0_inv;     // [big] 1 / (n (x - 1)) at bit-reversed positions (per circuit)
 #ifdef P25_PROFILE_GATE_MASK
@@ -83,7 +84,7 @@ struct ZppArgs {
   u64* tot;              // scratch [NC][n]
   u64* block_tot;        // scratch [NC][n/256]
   u64* out;
-  uint32_t n, num_routed, num_partial_products, num_challenges;
+  uint32_t n, num_routed, num_partial_products, num_challenges, quotient_degree_factor;
 };
 void launch_zpp(const ZppArgs& a, hipStream_t st);
 

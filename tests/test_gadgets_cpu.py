@@ -36,6 +36,6 @@ def test_gadgets_oracle_prove_verify(p25, oracle):
 
 
 def test_gadget_bad_params(p25):
-    for kind, param in ((2, 64), (3, 32), (4, 0), (9, 0)):
+    for kind, param in ((2, 64), (3, 32), (4, 0), (10, 0), (10, 201), (99, 0)):
         with pytest.raises(p25.P25Error):
             p25.Circuit.build_gadget(kind, param)
