@@ -154,6 +154,27 @@ p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t l
  * Inputs = operands followed by the expected result(s); a wrong expectation fails the proof with
  * P25_ERR_WITNESS_CONFLICT, as the failing `connect` panics upstream. */
 p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** out);
+/* ------------------------------------------------------------------------------------------
+ * Recursion: verifying this library's proofs inside another plonky2 circuit.
+ * ------------------------------------------------------------------------------------------ */
+/* A circuit that verifies `n_proofs` (1..16) proofs of `inner` -- upstream `builder.verify_proof::<C>(proof, vd, cd)`
+ * for each: Fiat-Shamir challenges on Poseidon gates, the constraint check vanishing(zeta) = Z_H(zeta) t(zeta)
+ * with every gate's `eval_unfiltered_circuit` (the reference's: poseidon2_gate.rs:312-397,
+ * arithmetic_u32.rs:178-245, interleave_u32.rs:143-189, uninterleave_to_u32.rs:164-228), and the FRI verifier
+ * (PoW, Merkle paths, folding).  Inputs of the new circuit = the inner proofs' words in the flat layout below,
+ * concatenated.  digest4 / cs_cap: the inner circuit's verifier data, baked in as constants; pass NULL to have them
+ * computed on the GPU (p25_circuit_digest).  Gate set: upstream-standard gates only, but not row-for-row upstream's
+ * circuit (plonky2.5_amd/csrc/recursion.h).  A false inner proof fails with P25_ERR_WITNESS_CONFLICT. */
+p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64_t* digest4, const uint64_t* cs_cap,
+                                                int32_t n_proofs, p25_circuit** out);
+/* Gate-level test circuit in the spirit of the reference's `test_eval_fns` (poseidon2_gate.rs:575-581): inputs = one
+ * row's 135 wires and 2 constants as extension elements (c0, c1 each), the 4-word public-inputs hash, then the
+ * expected value of every constraint as extension elements; the circuit evaluates gate `kind` in-circuit
+ * (`eval_unfiltered_circuit`) and connects each constraint to its expectation.  kind: 1 Constant 2 PublicInput
+ * 3 BaseSum 4 U32Interleave 5 UninterleaveToU32 6 Arithmetic 7 MulExtension 8 Exponentiation 9 U32Arithmetic
+ * 10 Poseidon2 11 ArithmeticExtension (the `kind` numbering of the circuit blob). */
+p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out);
+
 /* Circuit blob (format: plonky2.5_amd/csrc/circuit_io.h): persist a built circuit / hand it to
  * another process.  export: pass buf = NULL to query the size. */
 p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out);

@@ -152,6 +152,7 @@ class Oracle:
         L.p25o_prove_many_grouped.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp, vp, vp]
         L.p25o_prove_many_grouped.restype = C.c_double
         L.p25o_stage_shapes.argtypes = [vp, vp, vp]
+        L.p25o_eval_gate.argtypes = [ui, C.c_int, vp, vp, vp, C.c_int, vp]
         L.p25o_prove_filler.argtypes = [vp, vp, vp, vp, C.c_char_p, sz]
         L.p25o_num_random_fill.argtypes = [vp]
         L.p25o_num_random_fill.restype = sz
@@ -168,6 +169,15 @@ class Oracle:
 
     def load_circuit(self, blob):
         return OracleCircuit(self.lib, blob)
+
+    def eval_gate(self, kind, wires, consts, pih, base=False):
+        """Constraints of one row of gate `kind`: wires [num_wires][2], consts [2][2], pih [4] -> [n][2]."""
+        w = np.ascontiguousarray(wires, dtype=np.uint64)
+        k = np.ascontiguousarray(consts, dtype=np.uint64)
+        h = np.ascontiguousarray(pih, dtype=np.uint64)
+        out = np.zeros((512, 2), dtype=np.uint64)
+        n = self.lib.p25o_eval_gate(kind, w.shape[0], _p(w), _p(k), _p(h), int(base), _p(out))
+        return out[:n].copy()
 
     def transcript(self, segments):
         """segments: [(words_to_observe, n_challenges), ...] -> all challenges drawn, in order."""

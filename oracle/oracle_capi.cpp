@@ -181,6 +181,33 @@ int p25o_prove(void* h, const u64* inputs, u64 seed, u64* proof_out, double* tim
   }
   return 0;
 }
+// One row's constraints over F_p^2 (upstream Gate::eval_unfiltered; the verifier's evaluator): wires[num_wires][2],
+// consts[2][2], pih[4] -> out[n][2]; returns n.  With base = 1 the wires' second components are ignored and the
+// base-field evaluator runs (out[n][2] with zero second components): the two must agree on base inputs.
+int p25o_eval_gate(unsigned kind, int num_wires, const u64* wires, const u64* consts, const u64* pih, int base, u64* out) {
+  if (base) {
+    std::vector<FB> w(num_wires), o(512);
+    for (int i = 0; i < num_wires; i++) w[i] = FB{wires[2 * i]};
+    FB k[2] = {FB{consts[0]}, FB{consts[2]}}, ph[4] = {FB{pih[0]}, FB{pih[1]}, FB{pih[2]}, FB{pih[3]}};
+    int n = ref_eval_gate<FB>(kind, w.data(), k, ph, o.data());
+    for (int j = 0; j < n; j++) {
+      out[2 * j] = o[j].v;
+      out[2 * j + 1] = 0;
+    }
+    return n;
+  }
+  std::vector<FE> w(num_wires), o(512);
+  for (int i = 0; i < num_wires; i++) w[i] = FE{RE2{wires[2 * i], wires[2 * i + 1]}};
+  FE k[2] = {FE{RE2{consts[0], consts[1]}}, FE{RE2{consts[2], consts[3]}}};
+  FE ph[4] = {FE::from(pih[0]), FE::from(pih[1]), FE::from(pih[2]), FE::from(pih[3])};
+  int n = ref_eval_gate<FE>(kind, w.data(), k, ph, o.data());
+  for (int j = 0; j < n; j++) {
+    out[2 * j] = o[j].v.a;
+    out[2 * j + 1] = o[j].v.b;
+  }
+  return n;
+}
+
 // ---------------------------------------------------------------- isolated stages (parity tests of a6-a10)
 // Challenger script: for each segment observe seg_len[k] words of `obs` (consumed in order), then draw
 // n_chal[k] challenges into `out` (appended in order).  upstream iop/challenger.rs.

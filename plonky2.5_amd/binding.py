@@ -130,6 +130,8 @@ EXPORTED_SYMBOLS = {
     "p25_poseidon_permute_dev": (i32, [vp, sz, vp]),
     "p25_circuit_build_p3_verifier": (i32, [C.POINTER(P3Config), i32, C.POINTER(vp)]),
     "p25_circuit_build_gadget": (i32, [i32, i32, C.POINTER(vp)]),
+    "p25_circuit_build_gate_eval": (i32, [i32, C.POINTER(vp)]),
+    "p25_circuit_build_recursive_verifier": (i32, [vp, vp, vp, i32, C.POINTER(vp)]),
     "p25_circuit_export": (i32, [vp, vp, sz, C.POINTER(sz)]),
     "p25_circuit_import": (i32, [vp, sz, C.POINTER(vp)]),
     "p25_circuit_destroy": (None, [vp]),
@@ -341,6 +343,22 @@ class Circuit:
         h = vp()
         _check(lib().p25_circuit_build_gadget(kind, param, C.byref(h)))
         return cls(h.value)
+
+    @classmethod
+    def build_gate_eval(cls, kind):
+        """Gate-level test circuit: evaluates gate `kind` in-circuit (eval_unfiltered_circuit) against expectations."""
+        h = vp()
+        _check(lib().p25_circuit_build_gate_eval(kind, C.byref(h)))
+        return cls(h.value)
+
+    def build_recursive_verifier(self, n_proofs=1, digest=None, cs_cap=None):
+        """A circuit verifying `n_proofs` proofs of this circuit (upstream builder.verify_proof).  digest / cs_cap:
+        this circuit's verifier data (default: computed on the GPU)."""
+        h = vp()
+        d = _u64(digest) if digest is not None else None
+        cap = _u64(cs_cap) if cs_cap is not None else None
+        _check(lib().p25_circuit_build_recursive_verifier(self._h, _ptr(d), _ptr(cap), n_proofs, C.byref(h)))
+        return Circuit(h.value)
 
     @classmethod
     def from_blob(cls, blob):

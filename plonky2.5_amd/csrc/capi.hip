@@ -245,6 +245,7 @@ p25_status p25_lde_commit_dev(const uint64_t* d_polys, unsigned log_n, size_t n_
 #include "p3_circuit.h"
 #include "p3_prover.h"
 #include "prover.h"
+#include "recursion.h"
 
 struct p25_circuit {
   p25::Circuit circuit;                       // host tables (moved into dev on first device use)
@@ -350,6 +351,54 @@ p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** o
     *out = h;
     return P25_OK;
   });
+}
+
+p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out) {
+  return host_guarded([&]() -> p25_status {
+    if (!out) throw std::invalid_argument("null argument");
+    if (kind < 0 || kind >= p25::G_NUM_KINDS) throw std::invalid_argument("unknown gate kind");
+    auto* h = new p25_circuit();
+    try {
+      h->circuit = p25::build_gate_eval_circuit((p25::GateKind)kind);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64_t* digest4, const uint64_t* cs_cap,
+                                                int32_t n_proofs, p25_circuit** out) {
+  auto body = [&]() -> p25_status {
+    if (!inner || !out) throw std::invalid_argument("null argument");
+    if ((digest4 == nullptr) != (cs_cap == nullptr)) throw std::invalid_argument("pass both digest4 and cs_cap, or neither");
+    const p25::Circuit& ic = inner->c();
+    uint64_t dg[4];
+    std::vector<u64> cap((size_t)4 << ic.cfg.cap_height);
+    if (digest4) {
+      memcpy(dg, digest4, 32);
+      memcpy(cap.data(), cs_cap, cap.size() * 8);
+      for (u64 v : cap)
+        if (v >= gl::P) throw std::invalid_argument("non-canonical cap word");
+      for (u64 v : dg)
+        if (v >= gl::P) throw std::invalid_argument("non-canonical digest word");
+    } else {
+      p25::DeviceCircuit& d = inner->device();  // needs the GPU: commits the constants/sigmas polynomials
+      memcpy(dg, d.digest(), 32);
+      cap = d.cs_cap();
+    }
+    auto* h = new p25_circuit();
+    try {
+      h->circuit = p25::build_recursive_verifier(inner->c(), dg, cap, n_proofs);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+    return P25_OK;
+  };
+  return digest4 ? host_guarded(body) : guarded(body);
 }
 
 p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out) {

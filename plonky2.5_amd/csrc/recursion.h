@@ -1,0 +1,44 @@
+// Recursive verification of this library's own proofs: a plonky2 circuit that verifies
+// `n_proofs` proofs of one inner circuit -- the natural consumer of a batch of plonky3-verifier proofs
+// ("aggregation").  Host code, once per (inner circuit, n_proofs) shape; the resulting Circuit is proved on the GPU
+// like any other.
+//
+// What is restated and from where:
+//  * the in-circuit constraint evaluators `Gate::eval_unfiltered_circuit` of the reference's four gates
+//      Poseidon2Gate           /root/reference/src/common/poseidon2/poseidon2_gate.rs:312-397 (helpers poseidon2.rs:381-500)
+//      U32ArithmeticGate       src/common/u32/gates/arithmetic_u32.rs:178-245
+//      U32InterleaveGate       src/common/u32/gates/interleave_u32.rs:143-189
+//      UninterleaveToU32Gate   src/common/u32/gates/uninterleave_to_u32.rs:164-228
+//    and of the upstream gates the inner circuit uses (Constant, PublicInput, BaseSum<2>, Arithmetic, MulExtension,
+//    Exponentiation; plonky2 @ 3de92d9 gates/*.rs, absent crate, restated from their definitions);
+//  * the structure of upstream's recursive verifier (plonk/recursive_verifier.rs `verify_proof`,
+//    plonk/vanishing_poly.rs `eval_vanishing_poly_circuit`, iop/challenger.rs `RecursiveChallenger`,
+//    hash/merkle_proofs.rs `verify_merkle_proof_to_cap_with_cap_index`, fri/recursive_verifier.rs).
+//
+// DEVIATION (documented in DESIGN.md): upstream's recursive verifier also uses RandomAccessGate, ReducingGate,
+// ReducingExtensionGate and CosetInterpolationGate.  Here the same checks are expressed with ArithmeticGate /
+// ArithmeticExtensionGate / MulExtensionGate operations (select trees, Horner chains, barycentric interpolation),
+// so the circuit is a valid plonky2 circuit with upstream-standard gates only, but it is NOT row-for-row the
+// circuit `builder.verify_proof::<C>()` would emit (same statement, ~2^13 rows per inner fib-64 proof).
+#pragma once
+#include <vector>
+#include "builder.h"
+
+namespace p25 {
+
+// Constraints of one row of gate `kind`, evaluated in-circuit on extension targets (upstream
+// `Gate::eval_unfiltered_circuit`): `wires` = the row's wires opened at zeta, `consts` = its two constants,
+// `pih` = the public-inputs hash.  Same constraint order as the base / extension evaluators.
+std::vector<Ext> eval_gate_circuit(CircuitBuilder& b, GateKind kind, const std::vector<Ext>& wires, const Ext consts[2],
+                                   const std::array<Target, 4>& pih);
+
+// Test circuit in the spirit of the reference's `test_eval_fns` (poseidon2_gate.rs:575-581): inputs = the wires and
+// constants of one row as extension elements followed by the expected constraint values; the circuit evaluates the
+// gate in-circuit and connects every constraint to its expectation.
+Circuit build_gate_eval_circuit(GateKind kind);
+
+// The recursive verifier: inputs = n_proofs inner proofs, each in the flat layout of include/p25.h.  `digest` /
+// `cs_cap` are the inner circuit's verifier data (VerifierOnlyCircuitData), baked in as constants.
+Circuit build_recursive_verifier(const Circuit& inner, const u64 digest[4], const std::vector<u64>& cs_cap, int n_proofs);
+
+}  // namespace p25

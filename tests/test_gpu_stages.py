@@ -90,7 +90,8 @@ def test_partial_products_and_quotient_vs_oracle_fib64(gpu, fib_circuit, fib_ora
 
 @pytest.mark.parametrize("log_n,rate_bits,cap_h,arity,pow_bits,queries", [
     (10, 3, 4, [4, 4], 8, 5),          # two layers, as a 2^10-row circuit has
-    (12, 3, 4, [4, 4, 4], 10, 28),     # upstream's schedule shape: final polynomial of 2^0.. coefficients
+    (12, 3, 4, [4, 4], 10, 28),        # 28 queries, final polynomial of 2^4 coefficients
+    (12, 3, 2, [4, 4, 4], 10, 9),      # folds down to a constant final polynomial
     (8, 1, 0, [3, 2, 1], 4, 7),        # ragged arities, cap of one digest
     (6, 2, 2, [], 6, 3),               # no commit-phase layer at all: final polynomial = the input
     (16, 3, 4, [4, 4, 4], 16, 28),     # the fib-64 circuit's FRI: 2^16 coefficients, LDE 2^19, 16 PoW bits
