@@ -172,7 +172,7 @@ p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64
  * expected value of every constraint as extension elements; the circuit evaluates gate `kind` in-circuit
  * (`eval_unfiltered_circuit`) and connects each constraint to its expectation.  kind: 1 Constant 2 PublicInput
  * 3 BaseSum 4 U32Interleave 5 UninterleaveToU32 6 Arithmetic 7 MulExtension 8 Exponentiation 9 U32Arithmetic
- * 10 Poseidon2 11 ArithmeticExtension (the `kind` numbering of the circuit blob). */
+ * 10 Poseidon2 11 ArithmeticExtension 12 Poseidon (the `kind` numbering of the circuit blob). */
 p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out);
 
 /* Circuit blob (format: plonky2.5_amd/csrc/circuit_io.h): persist a built circuit / hand it to

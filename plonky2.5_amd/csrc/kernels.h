@@ -53,6 +53,7 @@ struct NttPass {
   const u64* pre;        // optional [n_cosets][N]: input element at address k is multiplied by pre[coset][k]
   const u64* post_t;     // optional [NT]
   const u64* post_i;     // optional [R]
+  uint32_t n_tiles, n_cosets, xcd_map;  // set by launch_ntt_pass
 };
 void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st);
 

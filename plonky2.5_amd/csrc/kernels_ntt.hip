@@ -61,8 +61,24 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
   const int TP = T > 1 ? T + 1 : 1;  // row padding: conflict-free for both access directions
   u64* wl = lds + (size_t)R * TP;    // R/2 twiddles of the sub-transform
   const u32 NT = 1u << a.log_nt;
-  const u32 tg0 = blockIdx.x * T;
-  const int poly = blockIdx.y, coset = blockIdx.z;
+  // Block -> (tile, polynomial, coset).  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.
+  // With xcd_map the 1-D grid is decoded so that the n_cosets blocks reading the SAME coefficient tile run on the
+  // same XCD back to back (the tile is fetched from HBM once, not once per coset) and an XCD only ever touches
+  // tiles = xcd (mod 8), i.e. 1/8 of the per-coset pre-scale table, which then stays L2-resident across polynomials.
+  u32 tile, poly, coset;
+  if (a.xcd_map) {
+    const u32 L = blockIdx.x, xcd = L & 7u, m = L >> 3;
+    const u32 tiles8 = a.n_tiles >> 3;
+    coset = m % a.n_cosets;
+    const u32 r = m / a.n_cosets;
+    tile = (r % tiles8) * 8 + xcd;
+    poly = r / tiles8;
+  } else {
+    tile = blockIdx.x;
+    poly = blockIdx.y;
+    coset = blockIdx.z;
+  }
+  const u32 tg0 = tile * T;
   const u64* in = a.in + (size_t)poly * a.in_poly_stride;
   u64* out = a.out + (size_t)poly * a.out_poly_stride + a.coset_out_off[coset];
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -143,8 +159,12 @@ void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st
   const int R = 1 << p.log_r, T = 1 << p.log_t;
   const int TP = T > 1 ? T + 1 : 1;
   size_t lds = ((size_t)R * TP + R / 2) * sizeof(u64);
-  dim3 grid(1u << (p.log_nt - p.log_t), n_polys, n_cosets);
-  hipLaunchKernelGGL(k_ntt_tile, grid, dim3(256), lds, st, p);
+  NttPass q = p;
+  q.n_tiles = 1u << (p.log_nt - p.log_t);
+  q.n_cosets = (uint32_t)n_cosets;
+  q.xcd_map = n_cosets > 1 && (q.n_tiles & 7u) == 0;
+  dim3 grid = q.xcd_map ? dim3(q.n_tiles * (uint32_t)n_polys * (uint32_t)n_cosets) : dim3(q.n_tiles, n_polys, n_cosets);
+  hipLaunchKernelGGL(k_ntt_tile, grid, dim3(256), lds, st, q);
 }
 
 static int pick_log_t(int log_r, int log_nt) {

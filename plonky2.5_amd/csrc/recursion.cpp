@@ -2,6 +2,7 @@
 #include "recursion.h"
 #include <stdexcept>
 #include <string>
+#include "poseidon.h"
 #include "poseidon2.h"
 
 namespace p25 {
@@ -234,6 +235,47 @@ std::vector<Ext> eval_gate_circuit(CircuitBuilder& b, GateKind kind, const std::
       for (int i = 0; i < 12; i++) c.push_back(b.sub_extension(st[i], w[12 + i]));
       break;
     }
+    case G_POSEIDON: {  // upstream gates/poseidon.rs eval_unfiltered_circuit, rounds in the defining form: the MDS layer
+                        // as mul_const_add chains on ArithmeticExtensionGate ops (upstream routes it through PoseidonMdsGate)
+      Ext swap = w[24];
+      c.push_back(b.mul_sub_extension(swap, swap, swap));
+      for (int i = 0; i < 4; i++) {
+        Ext diff = b.sub_extension(w[i + 4], w[i]);
+        c.push_back(b.mul_sub_extension(swap, diff, w[25 + i]));
+      }
+      St st;
+      for (int i = 0; i < 4; i++) {
+        st[i] = b.add_extension(w[i], w[25 + i]);
+        st[i + 4] = b.sub_extension(w[i + 4], w[25 + i]);
+      }
+      for (int i = 8; i < 12; i++) st[i] = w[i];
+      int tr = 29;
+      for (int r = 0; r < poseidon::N_ROUNDS; r++) {
+        for (int i = 0; i < 12; i++) st[i] = b.add_extension(st[i], cext(b, poseidon::RC[12 * r + i]));
+        if (r < poseidon::HALF_FULL || r >= poseidon::HALF_FULL + poseidon::N_PARTIAL) {
+          if (r != 0)
+            for (int i = 0; i < 12; i++) {
+              Ext sb = w[tr++];
+              c.push_back(b.sub_extension(st[i], sb));
+              st[i] = sb;
+            }
+          for (int i = 0; i < 12; i++) st[i] = b.exp_u64_extension(st[i], 7);
+        } else {
+          Ext sb = w[tr++];
+          c.push_back(b.sub_extension(st[0], sb));
+          st[0] = b.exp_u64_extension(sb, 7);
+        }
+        St nx;
+        for (int row = 0; row < 12; row++) {  // out[row] = sum_i circ[i] * s[(i + row) % 12] + diag[row] * s[row]
+          Ext acc = row == 0 ? b.mul_const_extension(poseidon::MDS_DIAG0, st[0]) : b.zero_extension();
+          for (int i = 0; i < 12; i++) acc = b.mul_const_add_extension(poseidon::MDS_CIRC[i], st[(i + row) % 12], acc);
+          nx[row] = acc;
+        }
+        st = nx;
+      }
+      for (int i = 0; i < 12; i++) c.push_back(b.sub_extension(st[i], w[12 + i]));
+      break;
+    }
     default:
       throw std::invalid_argument("eval_gate_circuit: gate has no in-circuit evaluator (only gates of the inner "
                                   "plonky3-verifier circuits are supported)");
@@ -243,7 +285,7 @@ std::vector<Ext> eval_gate_circuit(CircuitBuilder& b, GateKind kind, const std::
 }
 
 Circuit build_gate_eval_circuit(GateKind kind) {
-  if (kind >= G_NUM_KINDS || kind == G_POSEIDON) throw std::invalid_argument("no in-circuit evaluator for this gate");
+  if (kind >= G_NUM_KINDS) throw std::invalid_argument("no in-circuit evaluator for this gate");
   CircuitBuilder cb;
   auto in = [&]() {
     Target t = cb.add_virtual_target();
@@ -632,8 +674,6 @@ void verify_one(CircuitBuilder& b, const Circuit& c, const Hash& digest, const s
 Circuit build_recursive_verifier(const Circuit& inner, const u64 digest[4], const std::vector<u64>& cs_cap, int n_proofs) {
   if (n_proofs < 1 || n_proofs > 16) throw std::invalid_argument("recursive verifier: 1..16 inner proofs");
   if (cs_cap.size() != ((size_t)4 << inner.cfg.cap_height)) throw std::invalid_argument("recursive verifier: bad cap size");
-  for (GateKind k : inner.gates)
-    if (k == G_POSEIDON) throw std::invalid_argument("recursive verifier: inner circuits with PoseidonGate rows are not supported");
   CircuitBuilder cb(inner.cfg);
   Hash dg;
   for (int i = 0; i < 4; i++) dg[i] = cb.constant(digest[i]);

@@ -10,6 +10,7 @@
 #include "p3_circuit.h"
 #include "p3_prover.h"
 #include "witness_program.h"
+#include "recursion.h"
 typedef uint64_t u64;
 extern "C" {
 void* p25o_circuit_load(const unsigned char* blob, size_t len);
@@ -109,6 +110,23 @@ int main() {
   std::vector<u64> bad(inp);
   bad[9] ^= 1;
   CHECK(p25o_witness(h, bad.data(), 1, wires.data(), msg, sizeof msg) != 0);
+  // recursion: gate-level evaluator circuits and the recursive verifier of the small circuit above, witness
+  // generated from the oracle's proof
+  for (int k : {3, 9, 10, 11}) CHECK(build_gate_eval_circuit((GateKind)k).degree() >= 4);
+  {
+    proof[100] ^= 1;  // undo the tampering above
+    std::vector<u64> capv(cap);
+    Circuit outer = build_recursive_verifier(c3, dg, capv, 1);
+    std::vector<uint8_t> ob = circuit_to_blob(outer);
+    void* ho = p25o_circuit_load(ob.data(), ob.size());
+    CHECK(ho != nullptr);
+    std::vector<u64> ow((size_t)outer.degree() * 135);
+    CHECK(p25o_witness(ho, proof.data(), 2, ow.data(), msg, sizeof msg) == 0);
+    CHECK(p25o_check_constraints(ho, ow.data(), msg, sizeof msg) == 0);
+    proof[200] ^= 1;
+    CHECK(p25o_witness(ho, proof.data(), 2, ow.data(), msg, sizeof msg) != 0);
+    p25o_circuit_free(ho);
+  }
   p25o_circuit_free(h);
   printf("SANITIZE OK\n");
   return 0;

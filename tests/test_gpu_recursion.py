@@ -101,3 +101,28 @@ def test_two_to_one_aggregation_of_fib64_proofs(gpu, oracle, fib_circuit, fib_in
     code, msg = oo.verify(proofs[0], dg, cap)
     assert code == 0, msg
     print("2-to-1 aggregation circuit: 2^%d rows" % int(agg.info.degree_bits))
+
+
+def test_aggregation_tree_of_four_fib64_proofs(gpu, oracle, fib_circuit, fib_inputs):
+    """4 fib-64 proofs -> 2 aggregation proofs -> 1 root proof, every level proved on the GPU: the shape of the tree that
+    turns a 2048-proof batch into one proof (BASELINE.json north star: "final aggregation")."""
+    variants = [fib_inputs] + [gpu.p3_prove_fibonacci(6, 100, 16, pow_start=v << 24)[0] for v in (1, 2, 3)]
+    leaves, st = fib_circuit.prove(np.stack(variants), seeds=[21, 22, 23, 24])
+    assert st.tolist() == [0] * 4
+    agg1 = fib_circuit.build_recursive_verifier(2)
+    l1, st = agg1.prove(np.stack([np.concatenate([leaves[0], leaves[1]]), np.concatenate([leaves[2], leaves[3]])]),
+                        seeds=[1, 2])
+    assert st.tolist() == [0, 0]
+    agg2 = agg1.build_recursive_verifier(2)
+    root, st, tm = agg2.prove(np.concatenate([l1[0], l1[1]]), seeds=[1], timings=True)
+    assert st.tolist() == [0]
+    print("aggregation tree: leaf 2^%d rows -> level 1 2^%d rows -> root 2^%d rows; root proof %.1f ms"
+          % (int(fib_circuit.info.degree_bits), int(agg1.info.degree_bits), int(agg2.info.degree_bits), tm.total_ms))
+    o2 = oracle.load_circuit(agg2.to_blob())
+    dg, cap = agg2.digest()
+    code, msg = o2.verify(root[0], dg, cap)
+    assert code == 0, msg
+    # a root built over a corrupted level-1 proof has no witness
+    bad = np.concatenate([l1[0], l1[1]])
+    bad[77] = (int(bad[77]) + 1) % P
+    assert agg2.prove(bad, seeds=[1])[1].tolist() == [4]

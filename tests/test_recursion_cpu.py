@@ -14,7 +14,8 @@ import pytest
 from conftest import P, splitmix_field
 
 GATES = {1: "Constant", 2: "PublicInput", 3: "BaseSum", 4: "U32Interleave", 5: "UninterleaveToU32", 6: "Arithmetic",
-         7: "MulExtension", 8: "Exponentiation", 9: "U32Arithmetic", 10: "Poseidon2", 11: "ArithmeticExtension"}
+         7: "MulExtension", 8: "Exponentiation", 9: "U32Arithmetic", 10: "Poseidon2", 11: "ArithmeticExtension",
+         12: "Poseidon"}
 
 
 @pytest.mark.parametrize("kind", sorted(GATES))
@@ -47,7 +48,7 @@ def test_eval_fns_base_extension_and_circuit_agree(p25, oracle, kind):
 
 
 def test_gate_eval_rejects_gates_without_evaluator(p25):
-    for kind in (12, 99, -1):
+    for kind in (13, 99, -1):
         with pytest.raises(p25.P25Error):
             p25.Circuit.build_gate_eval(kind)
 
@@ -116,3 +117,23 @@ def test_recursive_verifier_with_fri_layers(p25, oracle):
     tampered[-40] = (int(tampered[-40]) + 1) % P
     assert oo.witness(tampered, seed=1)[1] == 4
     print("outer: 2^%d rows for an inner circuit of 2^%d" % (int(outer.info.degree_bits), int(inner.info.degree_bits)))
+
+
+def test_recursion_of_recursion(p25, oracle, small_recursion):
+    """Depth 2: a circuit verifying a proof of the recursive verifier (whose rows include PoseidonGate and
+    ArithmeticExtensionGate, evaluated in-circuit) -- what every inner node of an aggregation tree is."""
+    inner, oi, proof, outer = small_recursion
+    oo = oracle.load_circuit(outer.to_blob())
+    outer_proof, st, _t, msg = oo.prove(proof, seed=9)
+    assert st == 0, msg
+    dg, cap = oo.digest()
+    outer2 = outer.build_recursive_verifier(1, digest=dg, cs_cap=cap)
+    o2 = oracle.load_circuit(outer2.to_blob())
+    wires, st, msg = o2.witness(outer_proof, seed=3)
+    assert st == 0, msg
+    bad, msg = o2.check_constraints(wires)
+    assert bad == 0, msg
+    tampered = outer_proof.copy()
+    tampered[200] = (int(tampered[200]) + 1) % P
+    assert o2.witness(tampered, seed=3)[1] == 4
+    print("depth-2 circuit: 2^%d rows" % int(outer2.info.degree_bits))
