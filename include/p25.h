@@ -303,6 +303,13 @@ p25_status p25_p3_inputs_to_json(const uint64_t* inputs, size_t n, const p25_p3_
  * buf may be NULL to query *len_out. */
 p25_status p25_proof_to_json(p25_circuit* c, const uint64_t* proof, char* buf, size_t cap, size_t* len_out);
 
+/* Flat proof <-> upstream's binary form `ProofWithPublicInputs::to_bytes()` / `from_bytes()` (plonky2 util/serialization.rs
+ * write_proof_with_public_inputs, restated -- the crate is absent, so unpinned like the JSON): every field element as 8
+ * little-endian bytes in the order of the flat layout, each Merkle proof preceded by its sibling count as one byte,
+ * no public inputs.  buf may be NULL to query *len_out.  from_bytes rejects truncated / trailing / non-canonical data. */
+p25_status p25_proof_to_bytes(p25_circuit* c, const uint64_t* proof, uint8_t* buf, size_t cap, size_t* len_out);
+p25_status p25_proof_from_bytes(p25_circuit* c, const uint8_t* bytes, size_t len, uint64_t* proof_out, size_t cap_words);
+
 #ifdef __cplusplus
 }
 #endif

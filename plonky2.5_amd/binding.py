@@ -151,6 +151,8 @@ EXPORTED_SYMBOLS = {
     "p25_fri_prove": (i32, [vp, ui, ui, ui, vp, sz, ui, ui, vp, sz, vp, sz, C.POINTER(i32)]),
     "p25_p3_proof_from_json": (i32, [C.c_char_p, sz, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
     "p25_proof_to_json": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+    "p25_proof_to_bytes": (i32, [vp, vp, vp, sz, C.POINTER(sz)]),
+    "p25_proof_from_bytes": (i32, [vp, vp, sz, vp, sz]),
     "p25_p3_prove_fibonacci": (i32, [i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
     "p25_p3_inputs_to_json": (i32, [vp, sz, C.POINTER(P3Config), vp, sz, C.POINTER(sz)]),
     "p25_circuit_build_p3_verifier_air": (i32, [C.POINTER(P3Config), C.POINTER(AirC), C.POINTER(vp)]),
@@ -472,6 +474,21 @@ class Circuit:
         ms, n = C.c_double(0), C.c_uint64(0)
         _check(lib().p25_circuit_kernel_stats(self._h, int(enable), int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def proof_to_bytes(self, proof):
+        """upstream ProofWithPublicInputs::to_bytes() of a flat proof."""
+        p = _u64(proof)
+        n = sz(0)
+        _check(lib().p25_proof_to_bytes(self._h, _ptr(p), None, 0, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        _check(lib().p25_proof_to_bytes(self._h, _ptr(p), _ptr(buf), buf.size, C.byref(n)))
+        return buf.tobytes()
+
+    def proof_from_bytes(self, data):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        out = np.zeros(int(self.info.proof_words), dtype=np.uint64)
+        _check(lib().p25_proof_from_bytes(self._h, _ptr(buf), buf.size, _ptr(out), out.size))
+        return out
 
     def proof_to_json(self, proof):
         p = _u64(proof)

@@ -779,4 +779,28 @@ p25_status p25_proof_to_json(p25_circuit* c, const uint64_t* proof, char* buf, s
   });
 }
 
+p25_status p25_proof_to_bytes(p25_circuit* c, const uint64_t* proof, uint8_t* buf, size_t cap, size_t* len_out) {
+  return host_guarded([&]() -> p25_status {
+    if (!c || !proof || !len_out) throw std::invalid_argument("null argument");
+    const p25::Circuit& k = c->c();
+    std::vector<uint8_t> b = p25::proof_to_bytes(k, p25::make_proof_layout(k), proof);
+    *len_out = b.size();
+    if (buf) {
+      if (cap < b.size()) throw std::invalid_argument("buffer too small");
+      memcpy(buf, b.data(), b.size());
+    }
+    return P25_OK;
+  });
+}
+p25_status p25_proof_from_bytes(p25_circuit* c, const uint8_t* bytes, size_t len, uint64_t* proof_out, size_t cap_words) {
+  return host_guarded([&]() -> p25_status {
+    if (!c || !bytes || !proof_out) throw std::invalid_argument("null argument");
+    const p25::Circuit& k = c->c();
+    p25::ProofLayout L = p25::make_proof_layout(k);
+    if (cap_words < L.total) throw std::invalid_argument("buffer too small");
+    p25::proof_from_bytes(k, L, bytes, len, proof_out);
+    return P25_OK;
+  });
+}
+
 }  // extern "C"

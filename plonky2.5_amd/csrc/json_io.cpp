@@ -297,4 +297,76 @@ std::string proof_to_json(const Circuit& c, const ProofLayout& L, const u64* w) 
   return o.s;
 }
 
+// upstream util/serialization.rs `Buffer::write_proof_with_public_inputs` (what `ProofWithPublicInputs::to_bytes()`
+// emits; absent crate, restated): every field element as 8 little-endian bytes in the order of the flat layout --
+// caps, the opening set (constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, [lookup_zs, next_lookup_zs: empty],
+// partial_products, quotient_polys), commit-phase caps, query rounds, final polynomial, PoW witness, public inputs
+// (none) -- with ONE difference: every Merkle proof is preceded by its sibling count as a u8 (write_merkle_proof).
+namespace {
+// calls f(is_path_len, value / count, n_words) over the proof in order
+template <class F>
+void walk_proof(const Circuit& c, const ProofLayout& L, F&& f) {
+  const int lde_bits = c.degree_bits + c.cfg.rate_bits;
+  f(false, L.queries);  // caps, openings, FRI caps: plain words
+  for (int q = 0; q < c.cfg.num_query_rounds; q++) {
+    for (int k = 0; k < 4; k++) {
+      f(false, (size_t)L.oracle_width[k]);
+      f(true, (size_t)(lde_bits - c.cfg.cap_height));
+    }
+    int bits = lde_bits;
+    for (int ab : c.fri_reduction_arity_bits) {
+      bits -= ab;
+      f(false, 2 * ((size_t)1 << ab));
+      f(true, (size_t)(bits - c.cfg.cap_height));
+    }
+  }
+  f(false, L.total - L.final_poly);
+}
+}  // namespace
+std::vector<uint8_t> proof_to_bytes(const Circuit& c, const ProofLayout& L, const u64* w) {
+  std::vector<uint8_t> out;
+  out.reserve(L.total * 8 + 256);
+  size_t pos = 0;
+  auto words = [&](size_t n) {
+    for (size_t i = 0; i < n; i++) {
+      u64 v = w[pos++];
+      for (int b = 0; b < 8; b++) out.push_back((uint8_t)(v >> (8 * b)));
+    }
+  };
+  walk_proof(c, L, [&](bool is_path, size_t n) {
+    if (is_path) {
+      if (n > 255) throw std::invalid_argument("Merkle proof length must fit in u8");
+      out.push_back((uint8_t)n);
+      words(4 * n);
+    } else {
+      words(n);
+    }
+  });
+  if (pos != L.total) throw std::logic_error("proof_to_bytes: layout walk out of step");
+  return out;
+}
+void proof_from_bytes(const Circuit& c, const ProofLayout& L, const uint8_t* data, size_t len, u64* w) {
+  size_t pos = 0, off = 0;
+  auto words = [&](size_t n) {
+    if (off + 8 * n > len) throw std::invalid_argument("proof bytes truncated");
+    for (size_t i = 0; i < n; i++) {
+      u64 v = 0;
+      for (int b = 0; b < 8; b++) v |= (u64)data[off + b] << (8 * b);
+      if (v >= gl::P) throw std::invalid_argument("proof bytes: non-canonical field element");
+      w[pos++] = v;
+      off += 8;
+    }
+  };
+  walk_proof(c, L, [&](bool is_path, size_t n) {
+    if (is_path) {
+      if (off >= len || data[off] != (uint8_t)n) throw std::invalid_argument("proof bytes: unexpected Merkle proof length");
+      off++;
+      words(4 * n);
+    } else {
+      words(n);
+    }
+  });
+  if (off != len) throw std::invalid_argument("proof bytes: trailing data (public inputs are not supported)");
+}
+
 }  // namespace p25
