@@ -9,7 +9,9 @@ w = json.load(open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_WRITE_SIZE.json"
 K = "p25::k_hash_leaves_wide"
 fetch_kb, write_kb = f[K]["FETCH_SIZE"] / f[K]["calls"], w[K]["WRITE_SIZE"] / w[K]["calls"]
 n_big, width = 1 << 19, 135
+import subprocess
 out = {
+    "head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) "
               "-- python3 tools/prove_one.py 4 (per-proof figures)   [tools/collect_profiles.sh " + tag + "]",
     "kernel": "k_hash_leaves_wide on the 2^19 x 135 wires LDE (one launch per proof)",
