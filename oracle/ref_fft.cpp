@@ -63,6 +63,40 @@ static void fft_core(std::vector<u64>& a, u64 root) {
   }
 }
 
+// natural order in, BIT-REVERSED order out (decimation in frequency): out[rbits(i)] = sum_k a[k] root^(i k).  Used for
+// the LDE, whose values are wanted in bit-reversed (Merkle leaf) order anyway: no permutation pass at all.
+static void fft_dif_core(std::vector<u64>& a, u64 root) {
+  const size_t n = a.size();
+  if (n < 2) return;
+  const std::vector<u64>& tw = stage_twiddles(n, root);
+  u64* d = a.data();
+  for (size_t len = n / 2; len >= 2; len >>= 1) {
+    const u64* w = tw.data() + len;
+    for (size_t s = 0; s < n; s += 2 * len)
+      for (size_t j = 0; j < len; j++) {
+        u64 u = d[s + j], v = d[s + j + len];
+        d[s + j] = rf_add(u, v);
+        d[s + j + len] = rf_mul(rf_sub(u, v), w[j]);
+      }
+  }
+  for (size_t s = 0; s < n; s += 2) {
+    u64 u = d[s], v = d[s + 1];
+    d[s] = rf_add(u, v);
+    d[s + 1] = rf_sub(u, v);
+  }
+}
+std::vector<u64> ref_lde_values_bitrev(const std::vector<u64>& coeffs, unsigned rate_bits, u64 shift) {
+  std::vector<u64> v(coeffs);
+  v.resize(coeffs.size() << rate_bits, 0);
+  u64 p = 1;
+  for (size_t k = 0; k < coeffs.size(); k++) {
+    v[k] = rf_mul(v[k], p);
+    p = rf_mul(p, shift);
+  }
+  fft_dif_core(v, rf_root_of_unity(log2_exact(v.size())));
+  return v;
+}
+
 void ref_fft(std::vector<u64>& a) { fft_core(a, rf_root_of_unity(log2_exact(a.size()))); }
 void ref_ifft(std::vector<u64>& a) {
   fft_core(a, rf_inv(rf_root_of_unity(log2_exact(a.size()))));

@@ -14,3 +14,6 @@ void ref_fft_ext(std::vector<RE2>& a);
 void ref_coset_fft_ext(std::vector<RE2>& a, u64 shift);
 // lde: coefficient vector -> values of the rate-2^rate_bits LDE on shift*<w>, natural order
 std::vector<u64> ref_lde_values(const std::vector<u64>& coeffs, unsigned rate_bits, u64 shift);
+// the same values at BIT-REVERSED index (out[rbits(i)] = f(shift w^i)): the Merkle-leaf order, computed without a
+// permutation pass (decimation in frequency)
+std::vector<u64> ref_lde_values_bitrev(const std::vector<u64>& coeffs, unsigned rate_bits, u64 shift);

@@ -132,13 +132,9 @@ static double now_s() {
 }
 
 // ---------------------------------------------------------------- commitments (App. A.3)
-static RMerkleTree merkle_parallel(const std::vector<std::vector<u64>>& leaves, unsigned cap_height) {
+static RMerkleTree merkle_levels(std::vector<RHash> cur, unsigned cap_height) {
   RMerkleTree t;
   t.cap_height = cap_height;
-  std::vector<RHash> cur(leaves.size());
-  parallel_for(leaves.size(), [&](size_t b, size_t e) {
-    for (size_t i = b; i < e; i++) cur[i] = ref_hash_or_noop(leaves[i].data(), leaves[i].size());
-  });
   t.levels.push_back(cur);
   while (cur.size() > ((size_t)1 << cap_height)) {
     std::vector<RHash> nxt(cur.size() / 2);
@@ -150,6 +146,20 @@ static RMerkleTree merkle_parallel(const std::vector<std::vector<u64>>& leaves, 
   }
   return t;
 }
+static RMerkleTree merkle_parallel(const std::vector<std::vector<u64>>& leaves, unsigned cap_height) {
+  std::vector<RHash> cur(leaves.size());
+  parallel_for(leaves.size(), [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; i++) cur[i] = ref_hash_or_noop(leaves[i].data(), leaves[i].size());
+  });
+  return merkle_levels(std::move(cur), cap_height);
+}
+static RMerkleTree merkle_parallel_flat(const u64* leaves, size_t n_leaves, size_t width, unsigned cap_height) {
+  std::vector<RHash> cur(n_leaves);
+  parallel_for(n_leaves, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; i++) cur[i] = ref_hash_or_noop(leaves + i * width, width);
+  });
+  return merkle_levels(std::move(cur), cap_height);
+}
 
 RPolyBatch ref_commit_coeffs(const std::vector<std::vector<u64>>& coeffs, int rate_bits, int cap_height) {
   RPolyBatch b;
@@ -160,15 +170,25 @@ RPolyBatch ref_commit_coeffs(const std::vector<std::vector<u64>>& coeffs, int ra
   while (((size_t)1 << b.log_n) < n) b.log_n++;
   b.coeffs = coeffs;
   const size_t big = n << rate_bits;
-  b.leaves.assign(big, std::vector<u64>(b.n_polys));
-  const unsigned lg = b.log_n + rate_bits;
-  parallel_for(b.n_polys, [&](size_t pb, size_t pe) {
-    for (size_t p = pb; p < pe; p++) {
-      std::vector<u64> v = ref_lde_values(coeffs[p], rate_bits, 7);
-      for (size_t i = 0; i < big; i++) b.leaves[rbits(i, lg)][p] = v[i];
+  // One flat row-major matrix (a leaf = one contiguous row), filled eight columns at a time so that every 64-byte
+  // line of it is written once, in address order: the LDE comes out of the decimation-in-frequency transform already
+  // at bit-reversed index.  (A vector of 2^19 little vectors scattered one word at a time made this the slowest part
+  // of the CPU baseline and stopped it scaling across cores.)
+  b.leaves_flat.assign(big * b.n_polys, 0);
+  const size_t np = b.n_polys, blocks = (np + 7) / 8;
+  parallel_for(blocks, [&](size_t bb, size_t be) {
+    std::vector<std::vector<u64>> cols;
+    for (size_t blk = bb; blk < be; blk++) {
+      const size_t p0 = blk * 8, p1 = p0 + 8 < np ? p0 + 8 : np;
+      cols.clear();
+      for (size_t p = p0; p < p1; p++) cols.push_back(ref_lde_values_bitrev(coeffs[p], rate_bits, 7));
+      for (size_t r = 0; r < big; r++) {
+        u64* row = b.leaves_flat.data() + r * np + p0;
+        for (size_t k = 0; k < cols.size(); k++) row[k] = cols[k][r];
+      }
     }
   });
-  b.tree = merkle_parallel(b.leaves, cap_height);
+  b.tree = merkle_parallel_flat(b.leaves_flat.data(), big, b.n_polys, cap_height);
   return b;
 }
 RPolyBatch ref_commit_values(const std::vector<std::vector<u64>>& values, int rate_bits, int cap_height) {
@@ -424,13 +444,13 @@ std::vector<std::vector<u64>> ref_quotient_chunks(const RCircuit& c, const RPoly
       u64 x = rf_mul(7, rf_pow(w_big, ib));
       for (size_t i = ib; i < ie; i++, x = rf_mul(x, w_big)) {
         size_t pos = rbits(i, lde_bits), pos_next = rbits((i + next_step) % big, lde_bits);
-        const std::vector<u64>& cs = pre.constants_sigmas.leaves[pos];
+        const u64* cs = pre.constants_sigmas.leaf(pos);
         for (int k = 0; k < n_consts; k++) consts[k] = FB{cs[k]};
         for (int k = 0; k < RW; k++) sig[k] = FB{cs[n_consts + k]};
-        const std::vector<u64>& wl = wires.leaves[pos];
+        const u64* wl = wires.leaf(pos);
         for (int k = 0; k < c.num_wires; k++) wv[k] = FB{wl[k]};
-        const std::vector<u64>& zl = zs_batch.leaves[pos];
-        const std::vector<u64>& znl = zs_batch.leaves[pos_next];
+        const u64* zl = zs_batch.leaf(pos);
+        const u64* znl = zs_batch.leaf(pos_next);
         for (int k = 0; k < NC; k++) {
           z[k] = FB{zl[k]};
           zn[k] = FB{znl[k]};
@@ -531,7 +551,7 @@ int ref_fri_prove(const RFriParams& fp, const std::vector<RE2>& final_poly, RCha
     size_t x_index = (size_t)(ch.challenge() % big);
     if (indices_out) indices_out->push_back(x_index);
     for (int o = 0; oracles && o < 4; o++) {
-      q.initial_leaf.push_back(oracles[o]->leaves[x_index]);
+      q.initial_leaf.push_back(std::vector<u64>(oracles[o]->leaf(x_index), oracles[o]->leaf(x_index) + oracles[o]->n_polys));
       q.initial_path.push_back(oracles[o]->tree.prove(x_index));
     }
     for (size_t l = 0; l < fp.arity_bits.size(); l++) {

@@ -20,7 +20,8 @@ struct RPolyBatch {
   size_t n_polys = 0;
   int log_n = 0, rate_bits = 0;
   std::vector<std::vector<u64>> coeffs;  // [n_polys][n]
-  std::vector<std::vector<u64>> leaves;  // [n << rate_bits][n_polys], bit-reversed index order
+  std::vector<u64> leaves_flat;          // [n << rate_bits][n_polys] row-major, bit-reversed index order
+  const u64* leaf(size_t i) const { return leaves_flat.data() + i * n_polys; }
   RMerkleTree tree;
 };
 RPolyBatch ref_commit_values(const std::vector<std::vector<u64>>& values, int rate_bits, int cap_height);
