@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--cpu-baseline", choices=("full", "one-thread", "none"), default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--cpu-cores", type=int, default=0, help="physical cores of the whole-host leg (0 = all)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL over xGMI, one GPU per rank (the real thing); gloo = test mode: every rank on GPU 0, "
+                         "collectives on host copies (exercises the multi-rank path on a one-GPU box)")
     return ap.parse_args()
 
 
@@ -103,7 +106,7 @@ def main():
     import __graft_entry__ as ge
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.dist_backend == "nccl" else 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -111,7 +114,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     p25 = ge.load_package()
     p25.device_init(local_rank)
@@ -153,7 +159,10 @@ def main():
         circuit.sync()
         if distributed:  # the final aggregation step: finished proofs gathered onto rank 0 over RCCL/xGMI
             g0 = time.perf_counter()
-            pdist.gather_proofs(d_proofs, d_status, world * B)
+            if args.dist_backend == "nccl":
+                pdist.gather_proofs(d_proofs, d_status, world * B)
+            else:
+                pdist.gather_proofs(d_proofs.cpu(), d_status.cpu(), world * B)
             torch.cuda.synchronize()
             gather_s[0] += time.perf_counter() - g0
 
@@ -174,10 +183,11 @@ def main():
     elapsed = time.perf_counter() - t0
     per_rank = None
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([local_elapsed, gather_s[0]], dtype=torch.float64, device=dev)
+        mine = torch.tensor([local_elapsed, gather_s[0]], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "proofs_per_s": round(B * args.steps / float(x[0]), 2),
@@ -187,7 +197,7 @@ def main():
     statuses = d_status.cpu().numpy()
     ok = bool((statuses == 0).all())
     if distributed:
-        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if args.dist_backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
@@ -298,7 +308,8 @@ def main():
                     "p3 prover with other PoW witnesses) cycled through the batch, distinct filler seeds",
             "config": {"workload": f"batch of {B} independent fib-64 plonky3-verifier proofs per GPU "
                                    f"(n = 2^{int(info.degree_bits)} rows x 135 wires, LDE 2^{int(info.degree_bits) + 3}), "
-                                   f"{world} GPU(s), replicas + RCCL gather",
+                                   f"{world} GPU(s), replicas + RCCL gather"
+                                   + ("" if args.dist_backend == "nccl" else " [TEST MODE: all ranks on GPU 0, gloo]"),
                        "proofs_per_gpu_per_step": B, "all_statuses_ok": ok,
                        "oracle_verifier_accepts": not ver_fail, "oracle_verified_indices": ver_idx,
                        "circuit_build_s": round(build_s, 2), "head": head,

@@ -37,3 +37,21 @@ def test_bench_json_contract():
     # the roofline line is the kernel with the GPU to itself; the in-flight figure is reported beside it
     assert rf["launches"] == 8 and rf["avg_launch_ms"] > 0 and rf["avg_launch_ms_timed_region"] >= 0.9 * rf["avg_launch_ms"]
     assert len(d["config"]["oracle_verified_indices"]) == 8
+
+
+def test_bench_multi_rank_path_bare_launch():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself (before torch
+    or HIP is touched).  Test mode: both ranks share GPU 0 and the collectives run on host copies (gloo) -- the rank
+    bookkeeping, barriers, max-over-ranks timing, gather and JSON assembly are the code the 8-GPU run executes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "1",
+                        "--warmup", "1", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=1500,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["all_statuses_ok"]
+    assert d["config"]["oracle_verifier_accepts"] and "cpu_baseline" not in d
+    assert len(d["per_rank"]) == 2 and all(p["proofs_per_s"] > 0 for p in d["per_rank"])
+    assert abs(d["value"] - 2 * 8 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
