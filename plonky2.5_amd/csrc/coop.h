@@ -76,6 +76,45 @@ __device__ inline u64 poseidon_permute(u64 s, int lane, const u64* __restrict__ 
   return gl::canon(s);
 }
 
+// The same with the S-box inputs handed to emit(k, canonical value) by the lane that owns them, in PoseidonGate wire
+// order (full rounds 1..3, the 22 partial rounds' lane 0, full rounds 26..29): the witness generator of recursive
+// verifier circuits, whose Merkle paths are chains of dependent permutations.
+template <class Emit>
+__device__ inline u64 poseidon_permute_trace(u64 s, int lane, const u64* __restrict__ rc, Emit emit) {
+  const int base = lane & ~(GROUP - 1);
+  const int rr = lane & (GROUP - 1);
+  const bool active = rr < 12;
+  const int r = active ? rr : 0;
+  s = poseidon::add_rc(s, rc[r]);
+  for (int rd = 0; rd < poseidon::N_ROUNDS; rd++) {
+    const bool full = rd < poseidon::HALF_FULL || rd >= poseidon::HALF_FULL + poseidon::N_PARTIAL;
+    s = gl::canon(s);
+    if (full) {
+      if (rd != 0 && active) emit((rd < poseidon::HALF_FULL ? 12 * (rd - 1) : 58 + 12 * (rd - poseidon::HALF_FULL - poseidon::N_PARTIAL)) + r, s);
+    } else if (rr == 0) {
+      emit(36 + (rd - poseidon::HALF_FULL), s);
+    }
+    const u64 sb = poseidon::sbox(s);
+    s = (full || r == 0) ? sb : s;
+    const u64 c = rd + 1 < poseidon::N_ROUNDS ? rc[12 * (rd + 1) + r] : 0;
+    u32 lo = (u32)s, hi = (u32)(s >> 32);
+    u64 al = (u32)c, ah = c >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      int src = i + r;
+      src = base + (src >= 12 ? src - 12 : src);
+      al += (u64)__shfl(lo, src) * poseidon::MDS_CIRC[i];
+      ah += (u64)__shfl(hi, src) * poseidon::MDS_CIRC[i];
+    }
+    if (r == 0) {
+      al += (u64)lo * poseidon::MDS_DIAG0;
+      ah += (u64)hi * poseidon::MDS_DIAG0;
+    }
+    s = reduce_row(al, ah);
+  }
+  return gl::canon(s);
+}
+
 // Same permutation when the wave carries ONE state (the transcript): state word r lives in lane r of the
 // wave and the MDS layer broadcasts each word through SGPRs (v_readlane) instead of 24 LDS-crossbar
 // shuffles -- the multiply-adds then take the word as their scalar operand and a per-lane coefficient.

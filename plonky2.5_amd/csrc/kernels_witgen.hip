@@ -52,14 +52,14 @@ __device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* 
                                                   const uint32_t* __restrict__ args, uint32_t g_begin,
                                                   uint32_t g_count, u64* __restrict__ vals, size_t B,
                                                   uint32_t n_proofs, const u64* __restrict__ seeds,
-                                                  uint32_t* __restrict__ status, int skip_poseidon2,
+                                                  uint32_t* __restrict__ status, uint32_t skip_kind,
                                                   const u64* __restrict__ filler, uint32_t n_filler) {
   size_t idx = (size_t)block * blockDim.x + threadIdx.x;
   if (idx >= (size_t)g_count * n_proofs) return;
   const uint32_t gi = g_begin + (uint32_t)(idx / n_proofs);
   const uint32_t p = (uint32_t)(idx % n_proofs);
   const WitGen g = gens[gi];
-  if (skip_poseidon2 && g.kind == GEN_POSEIDON2) return;  // done cooperatively (k_witgen_level_fused)
+  if (g.kind == skip_kind) return;  // done cooperatively (k_witgen_level_fused)
   const uint32_t* dep = args + g.arg_off;
   Emitter emit{vals, dep + g.n_deps, B, p, status};
   auto d = [&](int i) -> u64 { return vals[(size_t)dep[i] * B + p]; };
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__
                                                       const uint32_t* __restrict__ args, uint32_t g_begin,
                                                       uint32_t g_count, u64* __restrict__ vals, size_t B,
                                                       uint32_t n_proofs, const u64* __restrict__ seeds,
-                                                      uint32_t* __restrict__ status, int skip_poseidon2,
+                                                      uint32_t* __restrict__ status, uint32_t skip_kind,
                                                       const u64* __restrict__ filler, uint32_t n_filler) {
-  witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, skip_poseidon2, filler,
+  witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, skip_kind, filler,
                     n_filler);
 }
 
@@ -251,6 +251,33 @@ __device__ __forceinline__ void witgen_p2_coop_body(uint32_t block, const u64* k
   s = coop::poseidon2_permute(s, lane, k_lds, [&](int i, u64 v) { emit(4 + i, v); });
   if (rr < 12) emit(4 + 106 + rr, s);
 }
+// The same for PoseidonGate generators (recursive verifier circuits; upstream PoseidonGenerator).
+__device__ __forceinline__ void witgen_p1_coop_body(uint32_t block, const u64* rc_lds, const WitGen* __restrict__ gens,
+                                                    const uint32_t* __restrict__ args, uint32_t g_begin,
+                                                    uint32_t g_count, u64* __restrict__ vals, size_t B,
+                                                    uint32_t n_proofs, uint32_t* __restrict__ status) {
+  size_t grp = ((size_t)block * blockDim.x + threadIdx.x) / coop::GROUP;
+  const size_t n_groups = (size_t)g_count * n_proofs;
+  const bool valid = grp < n_groups;
+  if (!valid) grp = n_groups - 1;  // every lane takes part in the shuffles
+  const int lane = threadIdx.x & 63, rr = threadIdx.x & (coop::GROUP - 1), base = lane & ~(coop::GROUP - 1);
+  const uint32_t gi = g_begin + (uint32_t)(grp / n_proofs);
+  const uint32_t p = (uint32_t)(grp % n_proofs);
+  const WitGen g = gens[gi];
+  const uint32_t* dep = args + g.arg_off;
+  Emitter em{vals, dep + g.n_deps, B, p, status};
+  auto emit = [&](int k, u64 v) {
+    if (valid) em(k, v);
+  };
+  u64 s = rr < 12 ? vals[(size_t)dep[rr] * B + p] : 0;
+  const u64 swap = vals[(size_t)dep[12] * B + p];
+  u64 up = coop::shfl64(s, base + ((rr + 4) & (coop::GROUP - 1)));
+  u64 dn = coop::shfl64(s, base + ((rr + 12) & (coop::GROUP - 1)));
+  if (rr < 4) emit(rr, gl::mul(swap, gl::sub(up, s)));
+  if (swap == 1) s = rr < 4 ? up : (rr < 8 ? dn : s);
+  s = coop::poseidon_permute_trace(s, lane, rc_lds, [&](int i, u64 v) { emit(4 + i, v); });
+  if (rr < 12) emit(4 + 106 + rr, s);
+}
 // One launch per level for small batches (every launch costs ~12 us of a single proof's latency): blocks
 // [0, nb_level) run the per-lane generators of the level, the rest its Poseidon2 generators cooperatively.
 __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __restrict__ gens,
@@ -259,13 +286,17 @@ __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __rest
                                                             uint32_t nb_level, u64* __restrict__ vals, size_t B,
                                                             uint32_t n_proofs, const u64* __restrict__ seeds,
                                                             uint32_t* __restrict__ status,
-                                                            const u64* __restrict__ filler, uint32_t n_filler) {
-  __shared__ u64 k_lds[coop::P2_LDS_WORDS];
+                                                            const u64* __restrict__ filler, uint32_t n_filler,
+                                                            uint32_t coop_kind) {
+  __shared__ u64 k_lds[360];  // Poseidon round constants (360) or the Poseidon2 set (coop::P2_LDS_WORDS)
   if (blockIdx.x < nb_level) {
-    witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, 1, filler, n_filler);
-  } else {
+    witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, coop_kind, filler, n_filler);
+  } else if (coop_kind == GEN_POSEIDON2) {
     coop::stage_poseidon2_rc(k_lds);
     witgen_p2_coop_body(blockIdx.x - nb_level, k_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
+  } else {
+    coop::stage_poseidon_rc(k_lds);
+    witgen_p1_coop_body(blockIdx.x - nb_level, k_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
   }
 }
 
@@ -327,13 +358,13 @@ void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u6
     const int coop_p2 = (n_proofs < 16 && p2c > 0) ? 1 : 0;
     if (!coop_p2) {
       hipLaunchKernelGGL(k_witgen_level, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, wp.d_gens, wp.d_args,
-                         b, cnt, d_vals, B, n_proofs, d_seeds, d_status, 0, d_filler, wp.num_random_fill);
+                         b, cnt, d_vals, B, n_proofs, d_seeds, d_status, 0xFFFFFFFFu, d_filler, wp.num_random_fill);
     } else {
       const unsigned nb1 = p2c < cnt ? (unsigned)((th + 255) / 256) : 0;
       const size_t th2 = (size_t)p2c * n_proofs * coop::GROUP;
       hipLaunchKernelGGL(k_witgen_level_fused, dim3(nb1 + (unsigned)((th2 + 255) / 256)), dim3(256), 0, st, wp.d_gens,
                          wp.d_args, b, cnt, wp.level_p2_begin[l], p2c, nb1, d_vals, B, n_proofs, d_seeds, d_status, d_filler,
-                         wp.num_random_fill);
+                         wp.num_random_fill, wp.level_coop_kind[l]);
     }
   }
 }

@@ -207,14 +207,19 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
   wp_.d_wire_slot_cm = up32(wp.wire_slot_cm);
   wp_.level_start = wp.level_start;
   for (size_t l = 0; l + 1 < wp.level_start.size(); l++) {
-    uint32_t b = wp.level_start[l], e = wp.level_start[l + 1], pb = e, pc = 0;
-    for (uint32_t g = b; g < e; g++)
-      if (wp.gens[g].kind == GEN_POSEIDON2) {
-        if (!pc) pb = g;
-        pc++;
-      }
+    uint32_t b = wp.level_start[l], e = wp.level_start[l + 1];
+    uint32_t kind = GEN_POSEIDON2, pb = e, pc = 0;
+    for (int pass = 0; pass < 2 && !pc; pass++) {
+      kind = pass == 0 ? GEN_POSEIDON2 : GEN_POSEIDON;
+      for (uint32_t g = b; g < e; g++)
+        if (wp.gens[g].kind == kind) {
+          if (!pc) pb = g;
+          pc++;
+        }
+    }
     wp_.level_p2_begin.push_back(pb);
     wp_.level_p2_count.push_back(pc);
+    wp_.level_coop_kind.push_back(kind);
   }
   wp_.n_inputs = (uint32_t)wp.input_slots.size();
   wp_.num_slots = wp.num_slots;

@@ -13,7 +13,9 @@ struct DeviceWitnessProgram {
   uint32_t* d_input_first = nullptr;
   uint32_t* d_wire_slot_cm = nullptr;
   std::vector<uint32_t> level_start;
-  std::vector<uint32_t> level_p2_begin, level_p2_count;  // Poseidon2 generators of each level (contiguous)
+  // the permutation generators of each level that run cooperatively for small batches (contiguous: gens are sorted
+  // by kind within a level): Poseidon2Gate's (inner circuits) or, where a level has none, PoseidonGate's (recursion)
+  std::vector<uint32_t> level_p2_begin, level_p2_count, level_coop_kind;
   uint32_t n_inputs = 0, num_slots = 0, num_random_fill = 0;
   size_t n_wire_elems = 0;
 };
