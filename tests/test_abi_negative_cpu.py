@@ -1,0 +1,74 @@
+"""CPU: the C ABI refuses malformed input with a status code instead of crashing -- null pointers, undersized
+buffers, corrupted JSON / proof bytes / blobs -- and reports P25_ERR_NO_DEVICE (never a CPU fallback) for compute
+entry points on a box without a GPU."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ARTIFACT, P
+
+
+def test_json_reader_survives_corruption(p25):
+    text = open(ARTIFACT, "rb").read()
+    inp, cfg = p25.p3_proof_from_json(text)
+    assert inp.size == 15751
+    rng = np.random.default_rng(3)
+    rejected = 0
+    for trial in range(300):
+        b = bytearray(text)
+        kind = trial % 3
+        if kind == 0:                                   # truncate
+            b = b[: int(rng.integers(0, len(b)))]
+        elif kind == 1:                                 # flip bytes
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        else:                                           # drop a slice
+            i = int(rng.integers(0, len(b) - 50))
+            del b[i:i + int(rng.integers(1, 50))]
+        try:
+            out, _cfg = p25.p3_proof_from_json(bytes(b))
+            assert out.size > 0 and (out < np.uint64(P)).all()
+        except p25.P25Error as e:
+            assert e.status in (1, 8)                   # INVALID_ARG / PARSE
+            rejected += 1
+    assert rejected > 150
+
+
+def test_null_and_undersized_arguments(p25):
+    lib = p25.lib()
+    assert lib.p25_circuit_build_gadget(0, 0, None) == 1
+    assert lib.p25_circuit_import(None, 0, None) == 1
+    assert lib.p25_p3_proof_from_json(None, 0, None, 0, None, None) == 1
+    c = p25.Circuit.build_gadget(0, 0)
+    n = C.c_size_t(0)
+    assert lib.p25_circuit_export(c._h, None, 0, C.byref(n)) == 0 and n.value > 1000
+    small = np.zeros(16, dtype=np.uint8)
+    assert lib.p25_circuit_export(c._h, small.ctypes.data_as(C.c_void_p), small.size, C.byref(n)) == 1
+    assert b"too small" in lib.p25_last_error()
+    assert lib.p25_circuit_info(c._h, None) == 1
+    proof = np.zeros(int(c.info.proof_words), dtype=np.uint64)
+    assert lib.p25_proof_to_json(c._h, proof.ctypes.data_as(C.c_void_p), small.ctypes.data_as(C.c_void_p), 4, C.byref(n)) == 1
+    assert lib.p25_proof_from_bytes(c._h, small.ctypes.data_as(C.c_void_p), small.size,
+                                    proof.ctypes.data_as(C.c_void_p), proof.size) == 1
+    assert lib.p25_fri_prove_words(6, 1, 2, None, 0, 3) > 0 and lib.p25_fri_prove_words(6, 1, 9, None, 0, 3) == 0
+    assert lib.p25_merkle_tree_words(12, 0) == 0 and lib.p25_merkle_tree_words(8, 4) == 0
+
+
+def test_no_device_means_error_not_fallback(p25):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = p25.lib()
+    st = np.zeros(12, dtype=np.uint64)
+    assert lib.p25_poseidon_permute(st.ctypes.data_as(C.c_void_p), 1) == 2          # P25_ERR_NO_DEVICE
+    c = p25.Circuit.build_gadget(0, 0)
+    with pytest.raises(p25.P25Error) as e:
+        c.prove(np.zeros(3, dtype=np.uint64))
+    assert e.value.status == 2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(p25.P25Error):
+        c.build_recursive_verifier(1)          # needs the device for the inner digest unless it is passed in
+    with pytest.raises(p25.P25Error):
+        p25.transcript([([1, 2, 3], 1)])
