@@ -127,6 +127,8 @@ class Oracle:
         L.p25o_poseidon_permute.argtypes = [vp, sz]
         L.p25o_poseidon2_permute.argtypes = [vp, sz]
         L.p25o_poseidon2_trace.argtypes = [vp, vp]
+        L.p25o_poseidon_trace.argtypes = [vp, vp]
+        L.p25o_poseidon_fast_partial_inputs.argtypes = [vp, vp]
         L.p25o_hash_no_pad.argtypes = [vp, sz, vp]
         L.p25o_mul.argtypes = [u64, u64]
         L.p25o_mul.restype = u64
@@ -216,6 +218,20 @@ class Oracle:
         tr = np.zeros(106, dtype=np.uint64)
         self.lib.p25o_poseidon2_trace(_p(s), _p(tr))
         return s, tr
+
+    def poseidon_trace(self, state):
+        """Poseidon v1, naive form: (output state, the 106 S-box inputs in PoseidonGate wire order)."""
+        s = np.ascontiguousarray(state, dtype=np.uint64).copy()
+        tr = np.zeros(106, dtype=np.uint64)
+        self.lib.p25o_poseidon_trace(_p(s), _p(tr))
+        return s, tr
+
+    def poseidon_fast_partial_inputs(self, state):
+        """Poseidon v1 in upstream's fast-partial-rounds form: (output, lane 0's 22 partial-round S-box inputs)."""
+        s = np.ascontiguousarray(state, dtype=np.uint64).copy()
+        pi = np.zeros(22, dtype=np.uint64)
+        self.lib.p25o_poseidon_fast_partial_inputs(_p(s), _p(pi))
+        return s, pi
 
     def hash_no_pad(self, words):
         a = np.ascontiguousarray(words, dtype=np.uint64)

@@ -25,6 +25,8 @@ void p25o_poseidon2_permute(u64* states, size_t n) {
   for (size_t i = 0; i < n; i++) ref_poseidon2(states + 12 * i);
 }
 void p25o_poseidon2_trace(u64* state, u64* trace) { ref_poseidon2_trace(state, trace); }
+void p25o_poseidon_trace(u64* state, u64* trace) { ref_poseidon_trace(state, trace); }
+void p25o_poseidon_fast_partial_inputs(u64* state, u64* partial_in) { ref_poseidon_fast_partial_inputs(state, partial_in); }
 void p25o_hash_no_pad(const u64* in, size_t n, u64* out4) {
   RHash h = ref_hash_no_pad(in, n);
   memcpy(out4, h.e, 32);

@@ -45,7 +45,9 @@ static inline u64 red_acc(u128 acc, u32 ov) {
   // acc + ov * 2^128, with 2^128 = -2^32 (mod p)
   return rf_sub(rf_reduce(acc), rf_mul(ov, (u64)1 << 32));
 }
-void ref_poseidon(u64 s[12]) {
+// partial_in (nullable): receives lane 0's S-box input of each of the 22 partial rounds in THIS (fast) formulation --
+// upstream's PoseidonGate stores exactly these as wires; tests check they equal the naive form's (ref_poseidon_trace).
+static void poseidon_fast(u64 s[12], u64* partial_in) {
   int r = 0;
   for (; r < 4; r++) {
     for (int i = 0; i < 12; i++) s[i] = pow7(rf_add(s[i], POSEIDON_RC[12 * r + i]));
@@ -67,6 +69,7 @@ void ref_poseidon(u64 s[12]) {
     memcpy(s + 1, t, sizeof(t));
   }
   for (int i = 0; i < 22; i++) {
+    if (partial_in) partial_in[i] = s[0];
     u64 s0 = rf_add(pow7(s[0]), pf::PF_SCALAR[i]);
     u128 acc = (u128)s0 * 25;  // m00 = MDS_CIRC[0] + MDS_DIAG[0]
     u32 ov = 0;
@@ -84,6 +87,9 @@ void ref_poseidon(u64 s[12]) {
     poseidon_mds(s);
   }
 }
+
+void ref_poseidon(u64 s[12]) { poseidon_fast(s, nullptr); }
+void ref_poseidon_fast_partial_inputs(u64 s[12], u64 partial_in[22]) { poseidon_fast(s, partial_in); }
 
 void ref_poseidon_naive(u64 s[12]) {
   for (int r = 0; r < 30; r++) {

@@ -17,7 +17,8 @@
 #include "ref_field.h"
 
 void ref_poseidon(u64 s[12]);        // optimised partial rounds (upstream's CPU form)
-void ref_poseidon_naive(u64 s[12]);  // the definition: 30 x {add constants, S-box, MDS}
+void ref_poseidon_naive(u64 s[12]);
+void ref_poseidon_fast_partial_inputs(u64 s[12], u64 partial_in[22]);  // fast form + its 22 partial-round S-box inputs  // the definition: 30 x {add constants, S-box, MDS}
 // Poseidon (v1), naive form, with the S-box-input trace upstream's PoseidonGate stores as wires (same layout as
 // the Poseidon2 gate, which was cloned from it): [0..36) full rounds 1..3, [36..58) partial rounds, [58..106) full
 // rounds 26..29.  trace may be null.

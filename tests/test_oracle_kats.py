@@ -95,3 +95,16 @@ def test_poseidon_fast_form_equals_definition(oracle):
     b = s.copy()
     oracle.lib.p25o_poseidon_permute_naive(b.ctypes.data, len(b))
     assert (a == b).all()
+
+
+def test_poseidon_gate_wires_same_in_fast_and_naive_form(oracle):
+    """upstream's PoseidonGate evaluates (and its generator fills) the partial rounds in the optimised form; this
+    library's PoseidonGate uses the defining form.  The S-box inputs -- the gate's wires -- are the same values in
+    both, so witnesses and constraint polynomials agree."""
+    from conftest import splitmix_field
+    for seed in range(5):
+        st = splitmix_field(12, seed=900 + seed)
+        out_n, tr = oracle.poseidon_trace(st)
+        out_f, pin = oracle.poseidon_fast_partial_inputs(st)
+        assert (out_n == out_f).all() and (out_n == oracle.poseidon_permute(st)[0]).all()
+        assert (tr[36:58] == pin).all()
