@@ -1,31 +1,33 @@
 #!/bin/bash
 # Collects the evidence bundle of a round on the GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh r01_d
-# Writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
+#   tools/collect_profiles.sh r02_z
+# Writes gpurun_out/<tag>_*; copy what should be judged into profiles/ (tools/make_traffic_json.py <tag> rewrites
+# profiles/pmc_hash_leaves.json from the FETCH/WRITE passes).
 set -u
 TAG=${1:-rXX}
 OUT=gpurun_out
 mkdir -p $OUT
-export TMPDIR=/tmp
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_pytest_gpu.txt
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -14 > $OUT/${TAG}_pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/${TAG}_pytest_gpu.txt 2>&1
-# PMC passes (each alone with --kernel-trace)
+# PMC passes (each alone with --kernel-trace): a batch of 4 = the kernels of the throughput path
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $C | cut -d' ' -f1)
   rm -rf $OUT/_pmc
-  # a batch of 4: the kernels of the throughput path (a lone proof switches some stages to latency-oriented forms)
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/_pmc -- python3 tools/prove_one.py 4 > $OUT/_pmc.log 2>&1
   python3 tools/pmc_summary.py $OUT/_pmc $OUT/${TAG}_pmc_${N}.json 4 > $OUT/${TAG}_pmc_${N}.txt
   rm -rf $OUT/_pmc
 done
-cp $OUT/${TAG}_pmc_SQ_INSTS_VALU.json profiles/ 2>/dev/null   # bench.py reads the VALU counts from profiles/
-python3 tools/make_traffic_json.py ${TAG} > /dev/null
-python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
-# rocprofv3 per-kernel summary of a bench run (the same command, smaller batch)
+( time python bench.py ) > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+# rocprofv3 per-kernel summary of the same command (smaller batch) + the dominant kernel's launches split into
+# "GPU to itself" (bench.py's single-proof passes = roofline.avg_launch_ms) and "in flight"
 rm -rf $OUT/_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_prof -- python3 bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_b64_rocprof.json 2> $OUT/_prof.err
 find $OUT/_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_rocprofv3_kernel_stats_bench_b64.csv
+find $OUT/_prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/rocprof_kernel_split.py {} > $OUT/${TAG}_rocprof_hash_leaves_split.txt
 rm -rf $OUT/_prof
-python tools/run_config5.py 20 > $OUT/${TAG}_config5.txt 2>&1
-tail -2 $OUT/${TAG}_pytest_gpu.txt
+python tools/aggregate.py 64 > $OUT/${TAG}_aggregate_64.json 2> $OUT/_agg.err
+python tools/kernel_bench.py > $OUT/${TAG}_kernel_bench.txt 2>&1
+tail -3 $OUT/${TAG}_pytest_gpu.txt
 cut -c1-160 $OUT/${TAG}_bench_default.json
+cat $OUT/${TAG}_rocprof_hash_leaves_split.txt

@@ -5,10 +5,10 @@ device-resident C-ABI primitives; reports time and algorithmic GB/s against the 
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 import __graft_entry__ as ge
-from conftest import splitmix_field
+from oracle_binding import splitmix_field
 p25 = ge.load_package(); p25.device_init(0)
 lib = p25.lib()
 from plonky25_amd.binding import _check as check

@@ -3,11 +3,10 @@
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import __graft_entry__ as ge
-import p3json
 p25 = ge.load_package(); p25.device_init(0)
-inputs, _ = p3json.load(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json"))
+inputs, _ = p25.p3_proof_from_json(open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")).read())
 c = p25.Circuit.build_p3_verifier(p25.P3Config.fib64())
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 c.prove(inputs, seeds=[0])

@@ -5,9 +5,9 @@ compares bytes with the oracle prover."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import __graft_entry__ as ge
-from conftest import Oracle
+from oracle_binding import Oracle
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 full_parity = "--parity" in sys.argv
