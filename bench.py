@@ -232,10 +232,17 @@ def main():
         tp = os.path.join(ROOT, "profiles", "pmc_hash_leaves.json")
         if os.path.exists(tp):
             try:
+                import hashlib
                 tj = json.load(open(tp))
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ (collected at "
-                                f"{tj.get('head', 'an earlier commit')}; the leaf kernel reads the LDE exactly once by construction)")
+                hh = hashlib.sha256()
+                for fn in ("kernels_hash.hip", "poseidon.h", "poseidon_p3r.h", "gl.h"):
+                    hh.update(open(os.path.join(ROOT, "plonky2.5_amd", "csrc", fn), "rb").read())
+                if tj.get("kernel_source_sha") == hh.hexdigest()[:16]:
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ (collected at "
+                                    f"{tj.get('head', '?')}; the kernel's sources are unchanged since)")
+                else:
+                    traffic_note = "profiles/pmc_hash_leaves.json was collected for other kernel sources: re-run the PMC passes"
             except Exception:
                 traffic = None
         total_proofs = world * B * args.steps

@@ -137,3 +137,26 @@ def test_recursion_of_recursion(p25, oracle, small_recursion):
     tampered[200] = (int(tampered[200]) + 1) % P
     assert o2.witness(tampered, seed=3)[1] == 4
     print("depth-2 circuit: 2^%d rows" % int(outer2.info.degree_bits))
+
+
+def test_recursive_verifier_single_selector_inner(p25, oracle):
+    """inner circuit with ONE selector polynomial (four gate types of degree <= 3: no UNUSED_SELECTOR factor in the
+    filters) and 2^2 rows -- the smallest shapes the verifier circuit has to handle (no FRI layer, LDE of 32 points,
+    Merkle paths of one sibling)."""
+    inner = p25.Circuit.build_gadget(8, 0)
+    assert int(inner.info.num_selectors) == 1
+    oi = oracle.load_circuit(inner.to_blob())
+    proof, st, _t, msg = oi.prove(np.array([7, 7, 49], dtype=np.uint64), seed=1)
+    assert st == 0, msg
+    dg, cap = oi.digest()
+    outer = inner.build_recursive_verifier(2, digest=dg, cs_cap=cap)      # two proofs of it at once
+    proof2, st, _t, msg = oi.prove(np.array([3, 3, 9], dtype=np.uint64), seed=2)
+    assert st == 0, msg
+    oo = oracle.load_circuit(outer.to_blob())
+    both = np.concatenate([proof, proof2])
+    wires, st, msg = oo.witness(both, seed=4)
+    assert st == 0, msg
+    assert oo.check_constraints(wires)[0] == 0
+    bad = both.copy()
+    bad[proof.size + 10] = (int(bad[proof.size + 10]) + 1) % P
+    assert oo.witness(bad, seed=4)[1] == 4

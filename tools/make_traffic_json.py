@@ -9,8 +9,15 @@ w = json.load(open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_WRITE_SIZE.json"
 K = "p25::k_hash_leaves_wide"
 fetch_kb, write_kb = f[K]["FETCH_SIZE"] / f[K]["calls"], w[K]["WRITE_SIZE"] / w[K]["calls"]
 n_big, width = 1 << 19, 135
-import subprocess
+import hashlib, subprocess
+def kernel_source_sha():
+    """sha256 over the sources of the dominant kernel: bench.py reports the PMC traffic only while these are unchanged."""
+    h = hashlib.sha256()
+    for f in ("kernels_hash.hip", "poseidon.h", "poseidon_p3r.h", "gl.h"):
+        h.update(open(os.path.join(ROOT, "plonky2.5_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 out = {
+    "kernel_source_sha": kernel_source_sha(),
     "head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) "
               "-- python3 tools/prove_one.py 4 (per-proof figures)   [tools/collect_profiles.sh " + tag + "]",
