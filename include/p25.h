@@ -267,6 +267,11 @@ p25_status p25_partial_products(p25_circuit* c, const uint64_t* wires, const uin
  * (values) + betas, gammas, alphas [NC] -> out[NC * 2^rate_bits][n]: coefficients of the quotient chunks. */
 p25_status p25_quotient(p25_circuit* c, const uint64_t* wires, const uint64_t* zs_pp, const uint64_t* betas,
                         const uint64_t* gammas, const uint64_t* alphas, uint64_t* out);
+/* upstream `OpeningSet::new` / `PolynomialCoeffs::eval` (a9): coeffs[n_polys][2^log_n] (base-field coefficients) evaluated at
+ * the extension point (point[0] + point[1] X) * scale -> out[n_polys][2].  scale = 1 for the openings at zeta, the
+ * subgroup generator for the next-row openings at g*zeta. */
+p25_status p25_eval_polys(const uint64_t* coeffs, size_t n_polys, unsigned log_n, const uint64_t* point, uint64_t scale,
+                          uint64_t* out);
 /* upstream fri/prover.rs `fri_proof` on one batched polynomial: coeffs[2][2^log_n] (the two components of its
  * extension-field coefficients), transcript initialised by observing seed[n_seed].  Commit phase (LDE on
  * 7*<w>, 2^arity-ary leaves, Merkle caps, fold by beta), final polynomial, PoW grind, num_queries (<= 64) query rounds.

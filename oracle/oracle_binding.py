@@ -154,6 +154,7 @@ class Oracle:
         L.p25o_prove_many_grouped.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp, vp, vp]
         L.p25o_prove_many_grouped.restype = C.c_double
         L.p25o_stage_shapes.argtypes = [vp, vp, vp]
+        L.p25o_eval_polys.argtypes = [vp, sz, sz, vp, u64, vp]
         L.p25o_eval_gate.argtypes = [ui, C.c_int, vp, vp, vp, C.c_int, vp]
         L.p25o_prove_filler.argtypes = [vp, vp, vp, vp, C.c_char_p, sz]
         L.p25o_num_random_fill.argtypes = [vp]
@@ -189,6 +190,13 @@ class Oracle:
         nch = np.array([k for _, k in segments], dtype=np.uint32)
         out = np.zeros(int(nch.sum()), dtype=np.uint64)
         self.lib.p25o_transcript(_p(obs), _p(lens), _p(nch), len(segments), _p(out))
+        return out
+
+    def eval_polys(self, coeffs, point, scale=1):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        pt = np.ascontiguousarray(point, dtype=np.uint64)
+        out = np.zeros((a.shape[0], 2), dtype=np.uint64)
+        self.lib.p25o_eval_polys(_p(a), a.shape[0], a.shape[1], _p(pt), int(scale), _p(out))
         return out
 
     def fri_prove(self, coeffs, rate_bits, cap_height, arity_bits, pow_bits, num_queries, seed):

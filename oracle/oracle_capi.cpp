@@ -254,6 +254,16 @@ void p25o_quotient(void* h, const u64* wires, const u64* zs_pp, const u64* betas
   auto q = ref_quotient_chunks(c, oc->pre->constants_sigmas, wb, zb, b, g, a);
   for (size_t k = 0; k < q.size(); k++) memcpy(out + k * n, q[k].data(), n * 8);
 }
+// coeffs[n_polys][n] at the extension point point*scale (Horner) -> out[n_polys][2]   (upstream PolynomialCoeffs::eval)
+void p25o_eval_polys(const u64* coeffs, size_t n_polys, size_t n, const u64* point, u64 scale, u64* out) {
+  RE2 z = re_muls(RE2{point[0], point[1]}, scale);
+  for (size_t p = 0; p < n_polys; p++) {
+    RE2 acc = re(0);
+    for (size_t k = n; k-- > 0;) acc = re_add(re_mul(acc, z), re(coeffs[p * n + k]));
+    out[2 * p] = acc.a;
+    out[2 * p + 1] = acc.b;
+  }
+}
 // FRI on one batched polynomial: coeffs[2][2^log_n] (extension components), transcript initialised by observing
 // `seed`.  out: CAP[n_layers] | betas E[n_layers] | final_poly E[..] | pow_witness | indices u64[num_queries] |
 // per query, per layer {evals E[2^arity], siblings H[..]}.  Returns words written (0 on failure).

@@ -7,7 +7,7 @@ import numpy as np
 __all__ = ["P25Error", "lib", "lib_path", "device_init", "poseidon_permute", "poseidon2_permute",
            "merkle_commit", "merkle_tree_words", "lde_commit", "EXPORTED_SYMBOLS", "P",
            "P3Config", "Circuit", "p3_proof_from_json", "Timings", "p3_prove_fibonacci", "p3_inputs_to_json",
-           "Air", "p3_prove_air", "transcript", "fri_prove"]
+           "Air", "p3_prove_air", "transcript", "fri_prove", "eval_polys"]
 
 P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -147,6 +147,7 @@ EXPORTED_SYMBOLS = {
     "p25_transcript": (i32, [vp, vp, vp, sz, vp]),
     "p25_partial_products": (i32, [vp, vp, vp, vp, vp]),
     "p25_quotient": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+    "p25_eval_polys": (i32, [vp, sz, ui, vp, C.c_uint64, vp]),
     "p25_fri_prove_words": (sz, [ui, ui, ui, vp, sz, ui]),
     "p25_fri_prove": (i32, [vp, ui, ui, ui, vp, sz, ui, ui, vp, sz, vp, sz, C.POINTER(i32)]),
     "p25_p3_proof_from_json": (i32, [C.c_char_p, sz, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
@@ -241,6 +242,16 @@ def transcript(segments):
     nch = np.array([k for _, k in segments], dtype=np.uint32)
     out = np.zeros(int(nch.sum()), dtype=np.uint64)
     _check(lib().p25_transcript(_ptr(obs), _ptr(lens), _ptr(nch), len(segments), _ptr(out)))
+    return out
+
+
+def eval_polys(coeffs, point, scale=1):
+    """Openings: coeffs[n_polys][2^log_n] evaluated at the extension point point*scale -> [n_polys][2]."""
+    a = _u64(coeffs)
+    n_polys, n = a.shape
+    pt = _u64(point)
+    out = np.zeros((n_polys, 2), dtype=np.uint64)
+    _check(lib().p25_eval_polys(_ptr(a), n_polys, int(n).bit_length() - 1, _ptr(pt), int(scale), _ptr(out)))
     return out
 
 

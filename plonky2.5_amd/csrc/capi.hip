@@ -575,6 +575,25 @@ p25_status p25_quotient(p25_circuit* c, const uint64_t* wires, const uint64_t* z
     return P25_OK;
   });
 }
+p25_status p25_eval_polys(const uint64_t* coeffs, size_t n_polys, unsigned log_n, const uint64_t* point, uint64_t scale,
+                          uint64_t* out) {
+  return guarded([&]() -> p25_status {
+    if (!coeffs || !point || !out) throw std::invalid_argument("null argument");
+    if (!n_polys || n_polys > (1u << 16) || log_n > 22) throw std::invalid_argument("p25_eval_polys: bad shape");
+    if (point[0] >= gl::P || point[1] >= gl::P || scale >= gl::P) throw std::invalid_argument("non-canonical point");
+    const size_t n = (size_t)1 << log_n;
+    for (size_t i = 0; i < n_polys * n; i++)
+      if (coeffs[i] >= gl::P) throw std::invalid_argument("non-canonical coefficient");
+    const size_t chunks = log_n > 16 ? ((size_t)1 << (log_n - 16)) : 1;
+    DevBuf d_c(n_polys * n), d_pt(2), d_scr(2 * 1026 + 2 * n_polys * chunks), d_out(2 * n_polys);
+    P25_HIP(hipMemcpy(d_c.p, coeffs, n_polys * n * 8, hipMemcpyHostToDevice));
+    P25_HIP(hipMemcpy(d_pt.p, point, 16, hipMemcpyHostToDevice));
+    p25::launch_eval_polys(d_c.p, (uint32_t)n_polys, log_n, d_pt.p, scale, d_scr.p, d_out.p, 0);
+    P25_HIP(hipGetLastError());
+    P25_HIP(hipMemcpy(out, d_out.p, 2 * n_polys * 8, hipMemcpyDeviceToHost));
+    return P25_OK;
+  });
+}
 static bool fri_shape_from_c(unsigned log_n, unsigned rate_bits, unsigned cap_height, const int32_t* arity_bits,
                              size_t n_layers, unsigned pow_bits, unsigned num_queries, p25::FriShape& sh) {
   if (log_n < 1 || log_n > 22 || rate_bits > 3 || cap_height > 16 || n_layers > 8 || (n_layers && !arity_bits) ||

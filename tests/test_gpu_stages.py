@@ -5,6 +5,7 @@ of as "first differing proof word".
   a6  Challenger                      p25_transcript        vs RChallenger
   a7  partial products + Z            p25_partial_products  vs ref_partial_products
   a8  quotient + every gate evaluator p25_quotient          vs ref_quotient_chunks
+  a9  openings f(zeta), Z(g zeta)     p25_eval_polys        vs Horner in F_p^2
   a10 FRI commit / PoW / queries      p25_fri_prove         vs ref_fri_prove
 """
 import numpy as np
@@ -116,3 +117,16 @@ def test_fri_bad_shapes_rejected(gpu, p25):
     bad[0, 0] = np.uint64(P)
     with pytest.raises(p25.P25Error):
         gpu.fri_prove(bad, 1, 2, [2], 4, 3, [1, 2, 3])
+
+
+@pytest.mark.parametrize("log_n,n_polys", [(4, 3), (10, 7), (16, 20), (18, 2)])
+def test_openings_vs_oracle(gpu, oracle, log_n, n_polys):
+    """a9: polynomial openings at an extension point -- the strided-Horner + LDS reduction kernel, including the chunked
+    form for polynomials longer than 2^16 (config 5) and the scaled point g*zeta of the next-row openings."""
+    coeffs = splitmix_field(n_polys << log_n, seed=70 + log_n).reshape(n_polys, 1 << log_n)
+    zeta = splitmix_field(2, seed=71)
+    g = pow(1753635133440165772, 1 << (32 - log_n), P)
+    for scale in (1, g):
+        got = gpu.eval_polys(coeffs, zeta, scale)
+        want = oracle.eval_polys(coeffs, zeta, scale)
+        assert (got == want).all(), (log_n, scale)

@@ -4,9 +4,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 ROOT="/root/repo"; sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import __graft_entry__ as ge
-import p3json
+
 p25 = ge.load_package(); p25.device_init(0)
-inputs, _ = p3json.load(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json"))
+inputs, _ = p25.p3_proof_from_json(open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")).read())
 c = p25.Circuit.build_p3_verifier(p25.P3Config.fib64())
 info = c.info; c.digest()
 B=256; pw=int(info.proof_words)
