@@ -149,6 +149,11 @@ Circuit circuit_from_blob(const uint8_t* data, size_t len) {
     if (c.num_gate_constraints != max_nc) bad("num_gate_constraints does not match the gate set");
     for (GateKind k : c.gates)
       if (gate_info(k).num_constants > c.cfg.num_constants) bad("a gate needs more constants than the circuit has");
+    // the evaluators index a row's wires by fixed column numbers
+    static const int MIN_WIRES[G_NUM_KINDS] = {0, 2, 4, 1 + BASE_SUM_LIMBS, 6 + 96, 6 + 128, 80, 78, 2 + 2 * EXP_POWER_BITS,
+                                               18 + 96, 135, 80, 135};
+    for (GateKind k : c.gates)
+      if (MIN_WIRES[k] > c.cfg.num_wires) bad("a gate needs more wires than the circuit has");
   }
   {
     int bits = c.degree_bits + c.cfg.rate_bits, deg = c.degree_bits;
