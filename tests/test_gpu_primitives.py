@@ -91,3 +91,33 @@ def test_handwritten_field_asm_matches_cpp_forms():
     assert os.path.exists(exe), "tools/build/asmcheck missing: run __graft_entry__.build()"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ASMCHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_full_size_lde_is_consistent_with_openings_and_linear(gpu):
+    """Size-independent properties at BASELINE's shape (135 columns x 2^16 -> LDE 2^19), no oracle involved:
+    (1) two different kernels agree -- the LDE value at leaf position rev(i) equals the Horner evaluation of the same
+    column's coefficients at 7*w^i (p25_lde_commit vs p25_eval_polys); (2) the transform is linear: commit(a + b) has
+    coefficients and LDE equal to commit(a) + commit(b)."""
+    from conftest import splitmix_field
+    log_n, rate, W = 16, 3, 135
+    n, big = 1 << log_n, 1 << (log_n + rate)
+    a = splitmix_field(W * n, seed=501).reshape(W, n)
+    ca, la, _ = gpu.lde_commit(a, rate, 4)
+    w_big = pow(1753635133440165772, 1 << (32 - log_n - rate), P)
+    rng = np.random.default_rng(9)
+    for i in [0, 1, big - 1] + [int(x) for x in rng.integers(0, big, size=5)]:
+        x = 7 * pow(w_big, i, P) % P
+        rev = int(format(i, f"0{log_n + rate}b")[::-1], 2)
+        direct = gpu.eval_polys(ca, np.array([x, 0], dtype=np.uint64))
+        assert (direct[:, 1] == 0).all() and (direct[:, 0] == la[:, rev]).all(), i
+    b = splitmix_field(W * n, seed=502).reshape(W, n)
+    cb, lb, _ = gpu.lde_commit(b, rate, 4)
+
+    def addmod(x, y):                       # canonical inputs; uint64 wrap-around handled explicitly
+        with np.errstate(over="ignore"):
+            t = x + y
+            return np.where((t < x) | (t >= np.uint64(P)), t - np.uint64(P), t)
+
+    cs, ls, _ = gpu.lde_commit(addmod(a, b), rate, 4)
+    assert (cs == addmod(ca, cb)).all()
+    assert (ls == addmod(la, lb)).all()
