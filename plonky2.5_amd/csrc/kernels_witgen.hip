@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__
 
 // Poseidon2 generators of one level, one 16-lane group per (generator, proof): used for small batches,
 // where a level's latency is that of a single permutation (poseidon2_gate.rs:447-523, cooperatively).
-__device__ __forceinline__ void witgen_p2_coop_body(uint32_t block, const u64* k_lds, const WitGen* __restrict__ gens,
+__device__ __forceinline__ void witgen_p2_coop_body(uint32_t block, const u64* k_lds, u64* tr_lds, const WitGen* __restrict__ gens,
                                                     const uint32_t* __restrict__ args, uint32_t g_begin,
                                                     uint32_t g_count, u64* __restrict__ vals, size_t B,
                                                     uint32_t n_proofs, uint32_t* __restrict__ status) {
@@ -248,11 +248,16 @@ __device__ __forceinline__ void witgen_p2_coop_body(uint32_t block, const u64* k
   u64 dn = coop::shfl64(s, base + ((rr + 12) & (coop::GROUP - 1)));
   if (rr < 4) emit(rr, gl::mul(swap, gl::sub(up, s)));
   if (swap == 1) s = rr < 4 ? up : (rr < 8 ? dn : s);
-  s = coop::poseidon2_permute(s, lane, k_lds, [&](int i, u64 v) { emit(4 + i, v); });
+  // The 106 trace words go to LDS while the permutation runs and are written out afterwards: emitting from inside
+  // the rounds put a global load (the output's slot index) and its wait into every step of the dependent chain.
+  u64* tr = tr_lds + (threadIdx.x / coop::GROUP) * 106;
+  s = coop::poseidon2_permute(s, lane, k_lds, [&](int i, u64 v) { tr[i] = v; });
+  __syncthreads();
+  for (int i = rr; i < 106; i += coop::GROUP) emit(4 + i, tr[i]);
   if (rr < 12) emit(4 + 106 + rr, s);
 }
 // The same for PoseidonGate generators (recursive verifier circuits; upstream PoseidonGenerator).
-__device__ __forceinline__ void witgen_p1_coop_body(uint32_t block, const u64* rc_lds, const WitGen* __restrict__ gens,
+__device__ __forceinline__ void witgen_p1_coop_body(uint32_t block, const u64* rc_lds, u64* tr_lds, const WitGen* __restrict__ gens,
                                                     const uint32_t* __restrict__ args, uint32_t g_begin,
                                                     uint32_t g_count, u64* __restrict__ vals, size_t B,
                                                     uint32_t n_proofs, uint32_t* __restrict__ status) {
@@ -275,7 +280,10 @@ __device__ __forceinline__ void witgen_p1_coop_body(uint32_t block, const u64* r
   u64 dn = coop::shfl64(s, base + ((rr + 12) & (coop::GROUP - 1)));
   if (rr < 4) emit(rr, gl::mul(swap, gl::sub(up, s)));
   if (swap == 1) s = rr < 4 ? up : (rr < 8 ? dn : s);
-  s = coop::poseidon_permute_trace(s, lane, rc_lds, [&](int i, u64 v) { emit(4 + i, v); });
+  u64* tr = tr_lds + (threadIdx.x / coop::GROUP) * 106;
+  s = coop::poseidon_permute_trace(s, lane, rc_lds, [&](int i, u64 v) { tr[i] = v; });
+  __syncthreads();
+  for (int i = rr; i < 106; i += coop::GROUP) emit(4 + i, tr[i]);
   if (rr < 12) emit(4 + 106 + rr, s);
 }
 // One launch per level for small batches (every launch costs ~12 us of a single proof's latency): blocks
@@ -289,14 +297,15 @@ __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __rest
                                                             const u64* __restrict__ filler, uint32_t n_filler,
                                                             uint32_t coop_kind) {
   __shared__ u64 k_lds[360];  // Poseidon round constants (360) or the Poseidon2 set (coop::P2_LDS_WORDS)
+  __shared__ u64 tr_lds[(256 / coop::GROUP) * 106];  // S-box-input traces of the block's 16 permutations
   if (blockIdx.x < nb_level) {
     witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, coop_kind, filler, n_filler);
   } else if (coop_kind == GEN_POSEIDON2) {
     coop::stage_poseidon2_rc(k_lds);
-    witgen_p2_coop_body(blockIdx.x - nb_level, k_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
+    witgen_p2_coop_body(blockIdx.x - nb_level, k_lds, tr_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
   } else {
     coop::stage_poseidon_rc(k_lds);
-    witgen_p1_coop_body(blockIdx.x - nb_level, k_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
+    witgen_p1_coop_body(blockIdx.x - nb_level, k_lds, tr_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
   }
 }
 
