@@ -11,6 +11,8 @@
 //! `prove_with_partition_witness` consumes it (both are public in plonky2 @ 3de92d9: plonky2/src/iop/generator.rs,
 //! plonky2/src/plonk/prover.rs).  If a later revision hides them, drop the filler file: the other two still pin
 //! the circuit and the verifier semantics.
+mod export_blob; // CircuitData -> libp25 circuit blob
+
 use anyhow::Result;
 use plonky2::iop::generator::generate_partial_witness;
 use plonky2::iop::target::Target;
@@ -95,6 +97,8 @@ fn main() -> Result<()> {
                                                           &mut TimingTree::default())?;
     std::fs::write("upstream_proof.json", serde_json::to_string(&proof)?)?;
     data.verify(proof)?;                                                      // src/p3/mod.rs:266
+    // the circuit as libp25 takes it (p25_circuit_import): prove it on the GPU, feed the proof back to data.verify
+    std::fs::write("upstream_circuit.p25blob", export_blob::export_p25_blob(&data, &proof_t.flat_targets()))?;   // flat_targets(): the add_virtual_to order, proof.rs:357-373
     println!("wrote upstream_circuit.json, upstream_proof.json, upstream_filler.json (n = 2^{})", common.degree_bits());
     Ok(())
 }
