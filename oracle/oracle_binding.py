@@ -68,8 +68,6 @@ class OracleCircuit:
 
     def partial_products(self, wires, betas, gammas):
         w = np.ascontiguousarray(wires, dtype=np.uint64)
-        info = (C.c_uint64 * 8)()
-        self.lib.p25o_circuit_info(self.h, info)
         nz = self._nz()
         out = np.zeros((nz, self.n), dtype=np.uint64)
         self.lib.p25o_partial_products(self.h, _p(w), _p(np.ascontiguousarray(betas, dtype=np.uint64)),
