@@ -104,3 +104,55 @@ def test_explicit_filler_equals_oracle_and_seed_path(gpu, fib_circuit, fib_oracl
     via_filler, st2 = fib_circuit.prove_filler(fib_inputs, wo[4:, cand[0]])
     assert st.tolist() == [0] and st2.tolist() == [0]
     assert (via_filler[0] == seed_proof[0]).all()
+
+
+def test_two_host_threads_two_circuits(gpu, oracle):
+    """include/p25.h: different circuits may be used from different host threads (the device chosen by
+    p25_device_init is re-applied in every call, whichever thread makes it).  Two threads prove concurrently on their
+    own circuits; results equal the oracle's."""
+    import threading
+    from gadget_cases import cases
+    picks = [c for c in cases(oracle) if c[0] in ("and", "compress")]
+    results = {}
+
+    def work(name, kind, param, vals):
+        c = gpu.Circuit.build_gadget(kind, param)
+        inp = np.array(vals, dtype=np.uint64)
+        out = []
+        for rep in range(3):
+            proofs, st = c.prove(np.stack([inp] * 5), seeds=[rep] * 5)
+            out.append((proofs[0].copy(), st.tolist()))
+        results[name] = (c, inp, out)
+
+    threads = [threading.Thread(target=work, args=p) for p in picks]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert len(results) == 2
+    for name, (c, inp, out) in results.items():
+        oc = oracle.load_circuit(c.to_blob())
+        for rep, (proof, st) in enumerate(out):
+            assert st == [0] * 5, name
+            po, sto, _t, msg = oc.prove(inp, seed=rep)
+            assert sto == 0 and (proof == po).all(), (name, rep)
+
+
+def test_circuit_create_destroy_does_not_leak_device_memory(gpu):
+    import torch
+    inp, cfg = gpu.p3_prove_fibonacci(3, 3, 4)
+
+    def cycle():
+        c = gpu.Circuit.build_p3_verifier(cfg)
+        proofs, st = c.prove(np.stack([inp] * 4), seeds=[1, 2, 3, 4])
+        assert st.tolist() == [0] * 4
+        c.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _total = torch.cuda.mem_get_info()
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _total = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 8 create/prove/destroy cycles"
