@@ -1,0 +1,20 @@
+"""GPU: the hand-written gfx950 sequences (field multiply / multiply-add, the MDS layer with folded constants, the fused
+permutation) against their plain C++ forms on the device, over edge cases and 10^6 random operands
+(tools/asmcheck.hip, built by __graft_entry__.build())."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hand_written_sequences_match_their_cpp_forms():
+    exe = os.path.join(ROOT, "tools", "build", "asmcheck")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ASMCHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+    assert "mul_nc_asm: 0 mismatches" in r.stdout and "mad_nc_asm: 0 mismatches" in r.stdout
