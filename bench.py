@@ -313,7 +313,8 @@ def main():
             "data": f"synthetic: {len(variants)} distinct plonky3 proofs of fibonacci(2^{args.log_n}) "
                     "(item 0 = the reference's artifacts/proof_fibonacci.json for log_n 6; the others from the native "
                     "p3 prover with other PoW witnesses) cycled through the batch, distinct filler seeds",
-            "config": {"workload": f"batch of {B} independent fib-64 plonky3-verifier proofs per GPU "
+            "config": {"workload": f"batch of {B} independent {'fib-64' if args.log_n == 6 else f'fibonacci(2^{args.log_n})'} "
+                                   "plonky3-verifier proofs per GPU "
                                    f"(n = 2^{int(info.degree_bits)} rows x 135 wires, LDE 2^{int(info.degree_bits) + 3}), "
                                    f"{world} GPU(s), replicas + RCCL gather"
                                    + ("" if args.dist_backend == "nccl" else " [TEST MODE: all ranks on GPU 0, gloo]"),
