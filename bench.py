@@ -30,7 +30,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
-N_SIMD, CLOCK_HZ = 1024, 2.4e9
+N_SIMD, NOMINAL_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; the clock is measured in the run (p25_shader_clock_hz)
 
 
 def parse_args():
@@ -45,10 +45,32 @@ def parse_args():
     ap.add_argument("--cpu-baseline", choices=("full", "one-thread", "none"), default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--cpu-cores", type=int, default=0, help="physical cores of the whole-host leg (0 = all)")
+    ap.add_argument("--total", type=int, default=0,
+                    help="strong-scaling mode (BASELINE config 4 literally: --total 2048): this many proofs per step in "
+                         "all, split across the ranks; overrides --batch")
+    ap.add_argument("--aggregate", type=int, default=-1,
+                    help="leaves of the aggregation-tree measurement after the timed region (recursive 2-to-1 verifier "
+                         "circuits down to ONE root proof); -1 = 64 on a single GPU, the gathered step otherwise is NOT "
+                         "folded (0 = off)")
+    ap.add_argument("--extra-configs", choices=("auto", "none"), default="auto",
+                    help="auto: also measure BASELINE configs 2 (single proof) and 5 (2^20-row inner STARK) and report "
+                         "them in the `configs` block (N = 1 only)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL over xGMI, one GPU per rank (the real thing); gloo = test mode: every rank on GPU 0, "
                          "collectives on host copies (exercises the multi-rank path on a one-GPU box)")
     return ap.parse_args()
+
+
+def fail(msg, code=2):
+    """One JSON line saying why there is no measurement (the driver reads stdout), then a non-zero exit."""
+    print(json.dumps({"metric": "recursive proofs/sec (fib-64 p3-in-p2 circuit)", "value": None, "unit": "proofs/s",
+                      "error": msg}), flush=True)
+    sys.exit(code)
+
+
+def visible_gpus():
+    import torch  # counting devices does not initialise HIP on this image
+    return torch.cuda.device_count()
 
 
 def spawn_ranks(args):
@@ -89,10 +111,86 @@ def cpu_model():
     return "unknown"
 
 
+def aggregation_tree(p25, circuit, leaves, verify_root):
+    """North star's "final aggregation step" taken literally: fold `leaves` (flat proofs of `circuit`, a power of two)
+    into ONE root proof with 2-to-1 recursive verifier circuits (upstream builder.verify_proof), every level a plain
+    batch prove on the GPU.  Returns the per-level record; the root is checked by `verify_root(circuit, proof)`."""
+    import numpy as np
+    level, circ, levels, tree_s, build_s = leaves, circuit, [], 0.0, 0.0
+    owned = []
+    while len(level) > 1:
+        t = time.perf_counter()
+        nxt = circ.build_recursive_verifier(2)
+        nxt.digest()
+        bs = time.perf_counter() - t
+        build_s += bs
+        owned.append(nxt)
+        pairs = np.stack([np.concatenate([level[2 * i], level[2 * i + 1]]) for i in range(len(level) // 2)])
+        nxt.prove(pairs[:min(16, len(pairs))], seeds=list(range(min(16, len(pairs)))))   # warm-up: this circuit's contexts
+        t = time.perf_counter()
+        level, st = nxt.prove(pairs, seeds=np.arange(len(pairs), dtype=np.uint64))
+        dt = time.perf_counter() - t
+        if not (st == 0).all():
+            raise RuntimeError(f"aggregation level {len(levels) + 1}: statuses {st.tolist()}")
+        tree_s += dt
+        levels.append({"level": len(levels) + 1, "circuit_rows_log2": int(nxt.info.degree_bits), "proofs": len(level),
+                       "prove_s": round(dt, 4), "circuit_build_s": round(bs, 2)})
+        circ = nxt
+    ok = verify_root(circ, level[0])
+    for c in owned:
+        c.close()
+    return {"levels": levels, "tree_prove_s": round(tree_s, 4), "tree_circuit_build_s_once_per_shape": round(build_s, 2),
+            "root_proof_words": int(level[0].size), "oracle_verifier_accepts_root": bool(ok)}
+
+
+def bench_config5(p25, np, torch, dev, host_threads, verify):
+    """BASELINE config 5: inner STARK = Fibonacci trace of 2^20 rows (outer circuit 2^19 rows, LDE 2^22), 1 GPU."""
+    t = time.perf_counter()
+    inp, cfg = p25.p3_prove_fibonacci(20, 100, 16, threads=host_threads)
+    alt, _ = p25.p3_prove_fibonacci(20, 100, 16, pow_start=1 << 24, threads=host_threads)
+    p3_s = time.perf_counter() - t
+    t = time.perf_counter()
+    circ = p25.Circuit.build_p3_verifier(cfg)
+    dg, cap = circ.digest()
+    build_s = time.perf_counter() - t
+    info = circ.info
+    B, pw = 16, int(info.proof_words)
+    host_in = np.stack([inp if i % 2 == 0 else alt for i in range(B)])
+    d_in = torch.from_numpy(host_in.view(np.int64)).to(dev)
+    d_seeds = torch.arange(B, dtype=torch.int64, device=dev)
+    d_proofs = torch.zeros((B, pw), dtype=torch.int64, device=dev)
+    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    steps = 2
+    for it in range(1 + steps):
+        if it == 1:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+        circ.prove_dev(d_in.data_ptr(), B, d_seeds.data_ptr(), d_proofs.data_ptr(), pw, d_status.data_ptr())
+        circ.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    ok = bool((d_status.cpu().numpy() == 0).all())
+    _p, _s, tm = circ.prove(inp, seeds=[0], timings=True)
+    acc = verify(circ, d_proofs[B - 1].cpu().numpy().view(np.uint64), dg, cap)
+    out = {"workload": f"batch of {B} plonky3-verifier proofs, inner Fibonacci trace 2^20 rows (outer n = 2^{int(info.degree_bits)} "
+                       f"rows x {int(info.num_wires)} wires, LDE 2^{int(info.degree_bits) + 3})",
+           "proofs_per_s": round(B * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 1), "steps": steps,
+           "all_statuses_ok": ok, "oracle_verifier_accepts": bool(acc),
+           "single_proof_latency_ms": round(tm.as_dict()["total_ms"], 2), "circuit_build_s": round(build_s, 2),
+           "native_p3_prover_s_two_proofs": round(p3_s, 2)}
+    circ.close()
+    return out
+
+
 def main():
     args = parse_args()
     if args.no_cpu_baseline:
         args.cpu_baseline = "none"
+    if args.dist_backend == "nccl" and visible_gpus() < args.gpus:
+        if int(os.environ.get("RANK", "0")) == 0:
+            fail(f"--gpus {args.gpus} but only {visible_gpus()} GPU(s) are visible")
+        sys.exit(2)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
 
@@ -121,18 +219,40 @@ def main():
 
     p25 = ge.load_package()
     p25.device_init(local_rank)
-    if args.log_n == 6:   # the reference's artifact, through the library's own reader (p25_p3_proof_from_json)
+    from plonky25_amd import dist as pdist
+    dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
+    host_threads = max(1, (os.cpu_count() or 1) // world)                 # host-side helpers: share the cores
+    # Per-proof inputs: plonky3 proofs of the Fibonacci AIR.  Generated ONCE, on rank 0 (item 0 for log_n = 6 is the
+    # reference's artifact through the library's own reader; further valid proofs of the same statement -- other
+    # PoW witnesses, hence other query indices -- come from the native plonky3 prover), then broadcast.
+    n_var = max(1, min(args.distinct, args.total if args.total else args.batch))
+    if args.log_n == 6:
         with open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")) as f:
             inputs, p3cfg = p25.p3_proof_from_json(f.read())
-    else:  # BASELINE config 5 and friends: inner STARK with 2^log_n rows from the native plonky3 prover
-        inputs, p3cfg = p25.p3_prove_fibonacci(args.log_n, 100, 16, threads=os.cpu_count() or 1)
-    # distinct batch items: further valid plonky3 proofs of the same statement (other PoW witnesses ->
-    # other query indices); the reference artifact is item 0 for log_n = 6
-    variants = [inputs]
-    for v in range(1, max(1, min(args.distinct, args.batch))):
-        alt, _ = p25.p3_prove_fibonacci(args.log_n, 100, 16, pow_start=(v << 24) + rank * (1 << 20),
-                                        threads=os.cpu_count() or 1)
-        variants.append(alt)
+    elif rank == 0:  # BASELINE config 5 and friends: inner STARK with 2^log_n rows
+        inputs, p3cfg = p25.p3_prove_fibonacci(args.log_n, 100, 16, threads=host_threads)
+    else:
+        inputs, p3cfg = None, None
+    if rank == 0:
+        variants = [inputs] + [p25.p3_prove_fibonacci(args.log_n, 100, 16, pow_start=v << 24, threads=host_threads)[0]
+                               for v in range(1, n_var)]
+        var_arr = np.stack(variants)
+    if distributed:
+        if args.log_n != 6:   # the shape of a 2^log_n-row proof: 9 int32 fields of p25_p3_config + the input length
+            meta = np.zeros(10, dtype=np.int64)
+            if rank == 0:
+                meta[:9] = [getattr(p3cfg, n) for n, _ in p3cfg._fields_]
+                meta[9] = var_arr.shape[1]
+            meta = pdist.broadcast_int64(meta if rank == 0 else None, (10,), cdev).view(np.int64)
+            if rank != 0:
+                p3cfg = p25.P3Config(*[int(x) for x in meta[:9]])
+            ni_b = int(meta[9])
+        else:
+            ni_b = int(inputs.size)
+        var_arr = pdist.broadcast_int64(var_arr if rank == 0 else None, (n_var, ni_b), cdev)
+        variants = [var_arr[i] for i in range(n_var)]
+        inputs = variants[0]
 
     # circuit: built once per shape by the host code, tables made resident on the GPU
     t0 = time.time()
@@ -140,29 +260,36 @@ def main():
     info = circuit.info
     digest, cs_cap = circuit.digest()  # forces the device-side tables (constants/sigmas commitment)
     build_s = time.time() - t0
-    B = args.batch
+    # weak scaling (default): --batch proofs per GPU per step.  strong scaling (--total): that many per step in all.
+    if args.total:
+        g_start, g_stop = pdist.shard_range(args.total, rank, world)
+        B, n_step_total = g_stop - g_start, args.total
+    else:
+        B, n_step_total = args.batch, args.batch * world
+        g_start = rank * B
     ni, pw = int(info.num_inputs), int(info.proof_words)
-    dev = torch.device("cuda", local_rank)
-    host_in = np.stack([variants[i % len(variants)] for i in range(B)])
-    host_seeds = np.arange(B, dtype=np.uint64) + np.uint64(rank * B)                        # distinct filler seeds
+    host_in = np.stack([variants[(g_start + i) % len(variants)] for i in range(max(B, 1))])[:B]
+    host_seeds = np.arange(B, dtype=np.uint64) + np.uint64(g_start)                          # distinct filler seeds
     d_inputs = torch.from_numpy(host_in.view(np.int64)).to(dev)                            # [B][ni]
     d_seeds = torch.from_numpy(host_seeds.view(np.int64)).to(dev)
     d_proofs = torch.zeros((B, pw), dtype=torch.int64, device=dev)
     d_status = torch.zeros(B, dtype=torch.int32, device=dev)
+    gatherer = pdist.ProofGatherer(n_step_total, pw, cdev) if distributed else None   # receive buffers allocated once
     torch.cuda.synchronize()  # inputs are resident in HBM before anything is timed
-    from plonky25_amd import dist as pdist
 
     gather_s = [0.0]
+    gathered = [None, None]
 
     def step():
-        circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), d_proofs.data_ptr(), pw, d_status.data_ptr())
+        if B:
+            circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), d_proofs.data_ptr(), pw, d_status.data_ptr())
         circuit.sync()
         if distributed:  # the final aggregation step: finished proofs gathered onto rank 0 over RCCL/xGMI
             g0 = time.perf_counter()
             if args.dist_backend == "nccl":
-                pdist.gather_proofs(d_proofs, d_status, world * B)
+                gathered[0], gathered[1] = gatherer.gather(d_proofs, d_status)
             else:
-                pdist.gather_proofs(d_proofs.cpu(), d_status.cpu(), world * B)
+                gathered[0], gathered[1] = gatherer.gather(d_proofs.cpu(), d_status.cpu())
             torch.cuda.synchronize()
             gather_s[0] += time.perf_counter() - g0
 
@@ -183,21 +310,20 @@ def main():
     elapsed = time.perf_counter() - t0
     per_rank = None
     if distributed:
-        cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([local_elapsed, gather_s[0]], dtype=torch.float64, device=cdev)
+        mine = torch.tensor([local_elapsed, gather_s[0], float(B)], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "proofs_per_s": round(B * args.steps / float(x[0]), 2),
+        per_rank = [{"rank": r, "proofs_per_step": int(x[2]), "proofs_per_s": round(float(x[2]) * args.steps / float(x[0]), 2),
                      "gather_ms_per_step": round(float(x[1]) / args.steps * 1e3, 3)} for r, x in enumerate(allr)]
     k_ms_busy, k_launches_busy = circuit.kernel_stats(enable=False, reset=True)
 
     statuses = d_status.cpu().numpy()
     ok = bool((statuses == 0).all())
     if distributed:
-        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if args.dist_backend == "nccl" else torch.device("cpu"))
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
@@ -207,19 +333,29 @@ def main():
         circuit.kernel_stats(enable=True, reset=True)
         alone = 8
         tm = None
+        gpu_proof0 = None
         for i in range(alone):
             _p, _s, tm = circuit.prove(variants[i % len(variants)], seeds=[i], timings=True)
+            if i == 0:
+                gpu_proof0 = _p[0].copy()   # inputs = item 0, filler seed 0: the proof the one-thread CPU leg reproduces
         k_ms_alone, k_launches_alone = circuit.kernel_stats(enable=False, reset=True)
         # correctness: the oracle verifier accepts proofs spread over the last batch
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from oracle_binding import Oracle           # the checker: verification and cpu_baseline only
         ora = Oracle()
         oc = ora.load_circuit(circuit.to_blob())
-        nver = max(1, min(args.verify, B))
-        ver_idx = sorted({int(round(k * (B - 1) / max(1, nver - 1))) for k in range(nver)})
+        # ... spread over the WHOLE step: with N > 1 the proofs checked are the gathered ones, every rank's block
+        if distributed:
+            all_blocks = [b.cpu().numpy().view(np.uint64) for b in gathered[0]]
+            all_p = np.concatenate(all_blocks) if all_blocks else np.zeros((0, pw), dtype=np.uint64)
+            gathered_ok = bool(all(int((g.cpu() != 0).sum()) == 0 for g in gathered[1])) and all_p.shape[0] == n_step_total
+        else:
+            all_p, gathered_ok = d_proofs.cpu().numpy().view(np.uint64), True
+        nver = max(1, min(args.verify, all_p.shape[0]))
+        ver_idx = sorted({int(round(k * (all_p.shape[0] - 1) / max(1, nver - 1))) for k in range(nver)})
         ver_fail = []
         for i in ver_idx:
-            code, msg = oc.verify(d_proofs[i].cpu().numpy().view(np.uint64), digest, cs_cap)
+            code, msg = oc.verify(all_p[i], digest, cs_cap)
             if code != 0:
                 ver_fail.append((i, msg))
         n_big = 1 << (int(info.degree_bits) + 3)
@@ -245,32 +381,55 @@ def main():
                     traffic_note = "profiles/pmc_hash_leaves.json was collected for other kernel sources: re-run the PMC passes"
             except Exception:
                 traffic = None
-        total_proofs = world * B * args.steps
+        total_proofs = n_step_total * args.steps
         # Integer-VALU view of the same run (the bound that actually binds): wave-level VALU instructions
         # per proof from the latest committed PMC pass (SQ_INSTS_VALU, profiles/*_pmc_SQ_INSTS_VALU.json,
         # written by tools/collect_profiles.sh) x proofs/s per GPU, against two ceilings.
         valu = None
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_SQ_INSTS_VALU.json")))
-        vp = cands[-1] if cands else ""
-        if vp and args.log_n == 6:
+        import hashlib
+        csrc = os.path.join(ROOT, "plonky2.5_amd", "csrc")
+        hh = hashlib.sha256()
+        for fn in sorted(os.listdir(csrc)):
+            if fn.endswith((".hip", ".h", ".inc")):
+                hh.update(open(os.path.join(csrc, fn), "rb").read())
+        csrc_sha = hh.hexdigest()[:16]
+        try:
+            clock_hz = p25.shader_clock_hz()     # measured in this run, under a full-chip Poseidon load
+        except Exception:
+            clock_hz = 0.0
+        clock_note = "measured in this run (in-kernel cycle counter vs the constant-rate wall clock, full-chip Poseidon load)"
+        if not (1.0e9 < clock_hz < 3.5e9):
+            clock_hz, clock_note = NOMINAL_CLOCK_HZ, "nominal (the in-run measurement failed)"
+        # only a PMC pass collected for exactly these kernel sources counts (tools/pmc_summary.py writes _meta.csrc_sha)
+        vp, per_kernel = "", None
+        for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_SQ_INSTS_VALU.json")), reverse=True):
             try:
-                per_kernel = json.load(open(vp))
-                instr_per_proof = sum(v.get("SQ_INSTS_VALU", 0.0) for v in per_kernel.values())
-                ach = instr_per_proof * (total_proofs / elapsed) / world
-                peak4, peak2 = N_SIMD * CLOCK_HZ / 4, N_SIMD * CLOCK_HZ / 2
-                valu = {"wave_instr_per_proof": instr_per_proof, "achieved_wave_instr_per_s": ach,
-                        "source": os.path.basename(vp),
-                        "frac_of_plain_issue_2cyc": ach / peak2, "frac_of_quarter_rate_4cyc": ach / peak4,
-                        "frac_of_measured_mix_ceiling": ach / (peak4 * 0.88),
-                        "leaf_hash_share": sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in per_kernel.items()
-                                               if "k_hash_leaves" in k) / instr_per_proof,
-                        "note": "ceilings: 1 wave-instruction / SIMD / 2 cycles is the guide's plain-VALU issue rate; every "
-                                "VOP3 / carry / v_mad_u64_u32 instruction (the whole mix here) measures 4.2-4.8 cycles "
-                                "(profiles/r01_instr_rates.txt), i.e. the 4-cycle class; v_mad_u64_u32 (60% of the mix) at "
-                                "4.7 cycles puts this mix's ceiling at 0.88 of the 4-cycle figure"}
+                pk = json.load(open(cand))
             except Exception:
-                valu = None
+                continue
+            if pk.get("_meta", {}).get("csrc_sha") == csrc_sha:
+                vp, per_kernel = cand, {k: v for k, v in pk.items() if k != "_meta"}
+                break
+        if per_kernel is None:
+            valu = {"stale": True, "note": "no profiles/*_pmc_SQ_INSTS_VALU.json was collected for the current kernel sources "
+                                           f"(csrc sha {csrc_sha}): re-run tools/collect_profiles.sh", "shader_clock_hz": clock_hz,
+                    "shader_clock_source": clock_note}
+        elif args.log_n == 6:
+            instr_per_proof = sum(v.get("SQ_INSTS_VALU", 0.0) for v in per_kernel.values())
+            ach = instr_per_proof * (total_proofs / elapsed) / world
+            peak4, peak2 = N_SIMD * clock_hz / 4, N_SIMD * clock_hz / 2
+            valu = {"wave_instr_per_proof": instr_per_proof, "achieved_wave_instr_per_s": ach,
+                    "source": os.path.basename(vp), "csrc_sha": csrc_sha,
+                    "shader_clock_hz": clock_hz, "shader_clock_source": clock_note,
+                    "frac_of_plain_issue_2cyc": ach / peak2, "frac_of_quarter_rate_4cyc": ach / peak4,
+                    "frac_of_measured_mix_ceiling": ach / (peak4 * 0.88),
+                    "leaf_hash_share": sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in per_kernel.items()
+                                           if "k_hash_leaves" in k) / instr_per_proof,
+                    "note": "ceilings: 1 wave-instruction / SIMD / 2 cycles is the guide's plain-VALU issue rate; every "
+                            "VOP3 / carry / v_mad_u64_u32 instruction (the whole mix here) measures 4.2-4.8 cycles "
+                            "(profiles/r01_instr_rates.txt), i.e. the 4-cycle class; v_mad_u64_u32 (60% of the mix) at "
+                            "4.7 cycles puts this mix's ceiling at 0.88 of the 4-cycle figure"}
         # HBM view per phase and overall: algorithmic bytes of each phase -- inputs read
         # once, outputs written once -- over that phase's device time for one proof alone on the GPU, and
         # all phases x proofs/s for the batch run.
@@ -307,18 +466,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total else "weak",
             "vs_baseline": None,
             "dtype": "u64 (Goldilocks, p = 2^64 - 2^32 + 1)",
             "data": f"synthetic: {len(variants)} distinct plonky3 proofs of fibonacci(2^{args.log_n}) "
                     "(item 0 = the reference's artifacts/proof_fibonacci.json for log_n 6; the others from the native "
                     "p3 prover with other PoW witnesses) cycled through the batch, distinct filler seeds",
-            "config": {"workload": f"batch of {B} independent {'fib-64' if args.log_n == 6 else f'fibonacci(2^{args.log_n})'} "
-                                   "plonky3-verifier proofs per GPU "
+            "config": {"workload": (f"batch of {n_step_total} independent " if args.total else f"batch of {B} independent ")
+                                   + f"{'fib-64' if args.log_n == 6 else f'fibonacci(2^{args.log_n})'} plonky3-verifier proofs "
+                                   + ("sharded over the GPUs " if args.total else "per GPU ") +
                                    f"(n = 2^{int(info.degree_bits)} rows x 135 wires, LDE 2^{int(info.degree_bits) + 3}), "
                                    f"{world} GPU(s), replicas + RCCL gather"
                                    + ("" if args.dist_backend == "nccl" else " [TEST MODE: all ranks on GPU 0, gloo]"),
-                       "proofs_per_gpu_per_step": B, "all_statuses_ok": ok,
+                       "proofs_per_gpu_per_step": B, "proofs_per_step_total": n_step_total,
+                       "all_statuses_ok": ok, "gathered_complete_and_ok": gathered_ok,
                        "oracle_verifier_accepts": not ver_fail, "oracle_verified_indices": ver_idx,
                        "circuit_build_s": round(build_s, 2), "head": head,
                        "single_proof_latency_ms": round(tmd["total_ms"], 3),
@@ -340,15 +501,55 @@ def main():
             out["per_rank"] = per_rank
         if ver_fail:
             out["config"]["oracle_verifier_failures"] = [f"{i}: {m}" for i, m in ver_fail]
+        def verify_with_oracle(circ, proof, dg=None, cap=None):
+            o2 = ora.load_circuit(circ.to_blob())
+            if dg is None:
+                dg, cap = circ.digest()
+            return o2.verify(proof, dg, cap)[0] == 0
+
+        # --- the batch folded to ONE proof (recursive verifier circuits), outside the timed region --------------
+        n_agg = args.aggregate if args.aggregate >= 0 else (64 if world == 1 else 0)
+        n_agg = min(n_agg, all_p.shape[0])
+        while n_agg & (n_agg - 1):
+            n_agg &= n_agg - 1          # largest power of two
+        if n_agg >= 2 and ok:
+            try:
+                agg = aggregation_tree(p25, circuit, all_p[:n_agg], verify_with_oracle)
+                leaf_s = n_agg / (total_proofs / elapsed)   # the leaves at the measured whole-job rate
+                agg.update({"leaves": n_agg, "leaf_prove_s_at_measured_rate": round(leaf_s, 4),
+                            "leaf_equivalent_proofs_per_s_including_aggregation": round(n_agg / (leaf_s + agg["tree_prove_s"]), 2),
+                            "note": "leaves = the first proofs of the last timed step (gathered ones when N > 1); tree on rank 0's "
+                                    "GPU; every level is a 2-to-1 recursive verifier circuit proved as a batch; circuit builds are "
+                                    "once per shape and excluded like the reference's build()"})
+                out["aggregation"] = agg
+            except Exception as e:  # never lose the headline line to the optional block
+                out["aggregation"] = {"error": str(e)[:300]}
+        # --- the other single-GPU BASELINE configs in the same record ----------------------------------------------
+        if args.extra_configs == "auto" and world == 1 and args.log_n == 6 and not args.total:
+            cfgs = {"config2_single_proof": {"workload": "one fib-64 verifier proof alone on the GPU (latency-oriented kernel forms)",
+                                             "latency_ms": round(tmd["total_ms"], 3),
+                                             "phase_ms": {k: round(v, 3) for k, v in tmd.items()}},
+                    "config3_batch256": {"proofs_per_s": round(total_proofs / elapsed, 3), "this_record": True}}
+            try:
+                circuit.close()   # free the fib-64 contexts (26 GB) before the 2^19-row circuit's (13 GB each)
+                cfgs["config5_inner_2pow20"] = bench_config5(p25, np, torch, dev, host_threads,
+                                                             lambda c, pr, dg, cap: verify_with_oracle(c, pr, dg, cap))
+            except Exception as e:
+                cfgs["config5_inner_2pow20"] = {"error": str(e)[:300]}
+            out["configs"] = cfgs
         if args.cpu_baseline != "none" and world == 1:  # reported baseline: rank 0, N = 1 only
             oc.digest()  # constants/sigmas commitment is per-circuit, excluded like the reference's build()
             model = cpu_model()
             # (i) BASELINE config 1: the reference's prover is single-threaded (Cargo.toml:15-18 no `parallel`)
-            _pr, st1, per1, wall1 = oc.prove_many(inputs[None, :], np.array([0], dtype=np.uint64), threads=1,
-                                                  want_proofs=False)
+            pr1, st1, per1, wall1 = oc.prove_many(inputs[None, :], np.array([0], dtype=np.uint64), threads=1,
+                                                  want_proofs=True)
+            bit_exact = bool(gpu_proof0 is not None and (pr1[0] == gpu_proof0).all())
             cb = {"value": 1.0 / wall1, "unit": "proofs/s", "cores": 1, "kind": "port", "cpu": model,
                   "sample": f"1 full fib-64 proof (witness generation + prove) by the oracle C++ restatement on ONE pinned "
-                            f"thread: {wall1:.1f} s, status {int(st1[0])}"}
+                            f"thread: {wall1:.1f} s, status {int(st1[0])}",
+                  "gpu_proof_bit_exact_vs_this_cpu_proof": bit_exact}
+            if "configs" in out:
+                out["configs"]["config2_single_proof"]["bit_exact_vs_cpu_port"] = bit_exact
             if args.cpu_baseline == "full":
                 # (ii) the whole host: G proofs in flight, each on T threads of the oracle's persistent pool,
                 # G x T = the physical cores.  (One single-threaded proof per core was measured too: 128 working sets

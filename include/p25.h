@@ -242,6 +242,9 @@ p25_status p25_circuit_sync(p25_circuit* c);
  * bracket every launch of the dominant kernel (the Poseidon leaf sponge over the 135-column wires
  * LDE).  Returns accumulated device milliseconds and launch count; reset != 0 clears them. */
 p25_status p25_circuit_kernel_stats(p25_circuit* c, int enable, int reset, double* ms_out, uint64_t* launches_out);
+/* Measurement hook: the shader clock (Hz) under a full-chip Poseidon load, from the in-kernel cycle counter against
+ * the constant-rate wall-clock counter; bench.py prices its VALU-instruction view with it instead of a nominal clock. */
+p25_status p25_shader_clock_hz(double* hz_out);
 /* Witness only (parity tests): wires_out[num_wires][2^degree_bits], column-major. */
 p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, uint64_t* wires_out,
                        p25_status* proof_status);

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-__all__ = ["P25Error", "lib", "lib_path", "device_init", "poseidon_permute", "poseidon2_permute",
+__all__ = ["P25Error", "lib", "lib_path", "device_init", "shader_clock_hz", "poseidon_permute", "poseidon2_permute",
            "merkle_commit", "merkle_tree_words", "lde_commit", "EXPORTED_SYMBOLS", "P",
            "P3Config", "Circuit", "p3_proof_from_json", "Timings", "p3_prove_fibonacci", "p3_inputs_to_json",
            "Air", "p3_prove_air", "transcript", "fri_prove", "eval_polys"]
@@ -118,6 +118,7 @@ vp, sz, ui, i32 = C.c_void_p, C.c_size_t, C.c_uint, C.c_int32
 # name -> (restype, argtypes); every symbol include/p25.h declares
 EXPORTED_SYMBOLS = {
     "p25_last_error": (C.c_char_p, []),
+    "p25_shader_clock_hz": (i32, [C.POINTER(C.c_double)]),
     "p25_version": (C.c_char_p, []),
     "p25_device_init": (i32, [C.c_int]),
     "p25_poseidon_permute": (i32, [vp, sz]),
@@ -191,6 +192,12 @@ def _ptr(a):
 
 def device_init(index=0):
     _check(lib().p25_device_init(index))
+
+
+def shader_clock_hz():
+    hz = C.c_double(0)
+    _check(lib().p25_shader_clock_hz(C.byref(hz)))
+    return hz.value
 
 
 def poseidon_permute(states):

@@ -125,6 +125,14 @@ p25_status p25_device_init(int device_index) {
   return P25_OK;
 }
 
+p25_status p25_shader_clock_hz(double* hz_out) {
+  return guarded([&]() -> p25_status {
+    if (!hz_out) throw std::invalid_argument("hz_out is null");
+    *hz_out = measure_shader_clock_hz(0);
+    return P25_OK;
+  });
+}
+
 p25_status p25_poseidon_permute(uint64_t* states, size_t n) {
   return guarded([&]() -> p25_status {
     if (!states && n) throw std::invalid_argument("states is null");

@@ -56,6 +56,8 @@ struct NttPass {
   uint32_t n_tiles, n_cosets, xcd_map;  // set by launch_ntt_pass
 };
 void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st);
+// Shader clock (Hz) under a full-chip Poseidon load, from in-kernel cycle and wall-clock counters (kernels_hash.hip).
+double measure_shader_clock_hz(hipStream_t st);
 
 class NttTables {
  public:

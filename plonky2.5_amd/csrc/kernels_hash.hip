@@ -110,6 +110,50 @@ static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st, boo
   }
 }
 
+// Shader clock under the hashing load (bench.py's VALU view prices instructions in cycles): every wave runs
+// `reps` permutations and one wave per 1024 blocks reports its elapsed shader cycles (s_memtime) and wall-clock
+// ticks (the constant-rate counter, hipDeviceAttributeWallClockRate kHz).
+__global__ __launch_bounds__(64) void k_clock_probe(u64* sink, int reps, unsigned long long* clk) {
+  size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = l * 12 + i;
+  unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+  for (int r = 0; r < reps; r++) {
+    s[0] ^= (u64)r;
+    poseidon::permute(s);
+  }
+  unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+  if (s[0] == 0x123456789ull) sink[l & 63] = s[1];  // keeps the loop alive
+  if (threadIdx.x == 0 && (blockIdx.x & 1023) == 0) {
+    clk[2 * (blockIdx.x >> 10)] = c1 - c0;
+    clk[2 * (blockIdx.x >> 10) + 1] = w1 - w0;
+  }
+}
+double measure_shader_clock_hz(hipStream_t st) {
+  const unsigned blocks = 8192, probes = blocks / 1024;
+  u64* d = nullptr;
+  P25_HIP(hipMalloc(&d, (64 + 2 * probes) * 8));
+  unsigned long long* clk = (unsigned long long*)(d + 64);
+  int dev = 0, khz = 0;
+  P25_HIP(hipGetDevice(&dev));
+  P25_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+  unsigned long long h[2 * probes];
+  for (int it = 0; it < 2; it++)  // first pass warms the clocks up
+    hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(64), 0, st, d, 64, clk);
+  hipError_t e = hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  P25_HIP(e);
+  double cyc = 0, ticks = 0;
+  for (unsigned i = 0; i < probes; i++) {
+    cyc += (double)h[2 * i];
+    ticks += (double)h[2 * i + 1];
+  }
+  if (ticks <= 0 || khz <= 0) return 0.0;
+  return cyc / (ticks / ((double)khz * 1e3));
+}
+
 void launch_poseidon_permute(u64* d_states, size_t n, hipStream_t st) {
   if (!n) return;
   hipLaunchKernelGGL(k_poseidon_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_states, n);

@@ -362,9 +362,12 @@ void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u6
     uint32_t b = wp.level_start[l], cnt = wp.level_start[l + 1] - b;
     if (!cnt) continue;
     size_t th = (size_t)cnt * n_proofs;
-    // small batches: the level's Poseidon2 generators run cooperatively (latency), the rest per lane
+    // The level's permutation generators run cooperatively (16 lanes each, trace staged in LDS), the rest per lane.
+    // A pass holds at most 64 proofs and a level ~50 permutations per proof, i.e. fewer waves than the chip has
+    // SIMDs either way, so what a level costs is the latency of ONE generator: ~25 us cooperatively against
+    // ~480 us for the per-lane form (118 dependent slot-index loads + stores per permutation).
     const uint32_t p2c = l < wp.level_p2_count.size() ? wp.level_p2_count[l] : 0;
-    const int coop_p2 = (n_proofs < 16 && p2c > 0) ? 1 : 0;
+    const int coop_p2 = p2c > 0 ? 1 : 0;
     if (!coop_p2) {
       hipLaunchKernelGGL(k_witgen_level, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, wp.d_gens, wp.d_args,
                          b, cnt, d_vals, B, n_proofs, d_seeds, d_status, 0xFFFFFFFFu, d_filler, wp.num_random_fill);

@@ -99,13 +99,13 @@ class DeviceCircuit {
 
  private:
   struct Ctx;  // per-proof working set
-  void prove_one(Ctx& cx, const u64* d_vals, size_t B, uint32_t p, u64* d_proof, uint32_t* d_status, PhaseTimes* t);
+  void prove_one(Ctx& cx, int buf, size_t B, uint32_t p, u64* d_proof, uint32_t* d_status, PhaseTimes* t);
   void enqueue_partial_products(Ctx& cx, hipStream_t st);
   void enqueue_quotient(Ctx& cx, hipStream_t st);
   void set_challenges(Ctx& cx, const u64* betas, const u64* gammas, const u64* alphas);
   size_t ctx_bytes() const;
   void ensure_ctx(size_t count);
-  void ensure_vals(size_t batch);
+  void ensure_vals(int buf, size_t batch);
 
   Circuit c_;
   ProofLayout layout_;
@@ -117,10 +117,11 @@ class DeviceCircuit {
   QuotientArgs qa_proto_;
   hipStream_t stream_ = nullptr;
   std::vector<std::unique_ptr<Ctx>> ctxs_;   // proofs in flight: one working set + HIP stream each
-  hipEvent_t ev_witness_ = nullptr;
+  hipEvent_t ev_witness_[2] = {nullptr, nullptr};  // witness pass into vals_[b] finished
   bool single_proof_ = false;  // set per prove call: one proof in flight -> latency-oriented kernel forms
-  DevMem vals_;
-  size_t vals_batch_ = 0;
+  DevMem vals_[2];             // witness values of a pass, slot-major [slot][proof of the pass]; double-buffered
+  size_t vals_batch_[2] = {0, 0};
+  size_t pass_counter_ = 0;    // witness passes issued so far (parity = buffer)
   std::vector<DevMem> owned_;
   bool kstats_on_ = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kstats_pending_, kstats_free_;

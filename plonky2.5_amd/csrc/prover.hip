@@ -168,12 +168,14 @@ struct DeviceCircuit::Ctx {
   DevMem proof, status;
   hipEvent_t ev[12];
   hipStream_t st = nullptr;
-  hipEvent_t done = nullptr;  // recorded after the context's last read of the shared witness values
+  // done[b]: recorded after the context's latest read of witness-value buffer b (DeviceCircuit::vals_[b])
+  hipEvent_t done[2] = {nullptr, nullptr};
   bool have_events = false;
   ~Ctx() {
     if (have_events)
       for (auto& e : ev) (void)hipEventDestroy(e);
-    if (done) (void)hipEventDestroy(done);
+    for (auto& e : done)
+      if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
   }
 };
@@ -295,7 +297,8 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
 
 DeviceCircuit::~DeviceCircuit() {
   ctxs_.clear();
-  if (ev_witness_) (void)hipEventDestroy(ev_witness_);
+  for (auto& e : ev_witness_)
+    if (e) (void)hipEventDestroy(e);
   for (auto* v : {&kstats_pending_, &kstats_free_})
     for (auto& pr : *v) {
       (void)hipEventDestroy(pr.first);
@@ -305,12 +308,13 @@ DeviceCircuit::~DeviceCircuit() {
 }
 
 void DeviceCircuit::ensure_ctx(size_t count) {
-  if (!ev_witness_) P25_HIP(hipEventCreateWithFlags(&ev_witness_, hipEventDisableTiming));
+  for (auto& e : ev_witness_)
+    if (!e) P25_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   while (ctxs_.size() < count) {
   ctxs_.emplace_back(new Ctx());
   Ctx& x = *ctxs_.back();
   P25_HIP(hipStreamCreate(&x.st));
-  P25_HIP(hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
+  for (auto& e : x.done) P25_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const size_t n = c_.degree(), B = big();
   const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;
   const int nz = NC * (1 + NP), nq = NC * c_.cfg.max_quotient_degree_factor;
@@ -352,11 +356,12 @@ void DeviceCircuit::ensure_ctx(size_t count) {
   }
 }
 
-void DeviceCircuit::ensure_vals(size_t batch) {
-  if (batch <= vals_batch_) return;
-  vals_ = DevMem();
-  vals_ = DevMem((size_t)wp_.num_slots * batch);
-  vals_batch_ = batch;
+void DeviceCircuit::ensure_vals(int buf, size_t batch) {
+  if (batch <= vals_batch_[buf]) return;
+  sync();  // nothing in flight may still read the old allocation
+  vals_[buf] = DevMem();
+  vals_[buf] = DevMem((size_t)wp_.num_slots * batch);
+  vals_batch_[buf] = batch;
 }
 
 void DeviceCircuit::sync() {
@@ -383,8 +388,9 @@ void DeviceCircuit::kernel_stats(double* ms, u64* launches, bool reset) {
 }
 
 // One proof, fully enqueued on the stream; no host synchronisation inside.
-void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_t p, u64* d_proof,
+void DeviceCircuit::prove_one(Ctx& x, int buf, size_t Bstride, uint32_t p, u64* d_proof,
                               uint32_t* d_status, PhaseTimes* t) {
+  const u64* d_vals = vals_[buf].p;
   hipStream_t st = x.st;
   const size_t n = c_.degree(), B = big();
   const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;
@@ -406,7 +412,7 @@ void DeviceCircuit::prove_one(Ctx& x, const u64* d_vals, size_t Bstride, uint32_
   mark();  // 0
   // "compute full witness" + "compute wire polynomials"
   launch_fill_wires(wp_, d_vals, Bstride, p, x.wires_vals.p, st);
-  P25_HIP(hipEventRecord(x.done, st));  // last read of the shared witness-value array by this proof
+  P25_HIP(hipEventRecord(x.done[buf], st));  // last read of this witness-value buffer by this proof
   mark();  // 1
   // "compute wires commitment"
   ntt_inverse(tables_, x.wires_vals.p, n, false, x.tmp.p, n, x.wires_coeffs.p, n, db, W, 1, st);
@@ -737,7 +743,9 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
       const size_t pass = n_proofs < 64 ? n_proofs : 64;
-      const size_t vals_need = pass > vals_batch_ ? (size_t)wp_.num_slots * pass * 8 : 0;
+      size_t vals_need = 0;
+      for (int b = 0; b < (n_proofs > 64 ? 2 : 1); b++)
+        if (pass > vals_batch_[b]) vals_need += (size_t)wp_.num_slots * pass * 8;
       const size_t reserve = total_b / 20;
       const size_t avail = free_b > vals_need + reserve ? free_b - vals_need - reserve : 0;
       size_t fit = ctxs_.size() + avail / ctx_bytes();
@@ -747,12 +755,17 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
   }
   ensure_ctx(K);
   single_proof_ = K == 1;  // a lone proof in flight: latency-oriented kernel forms
+  // Witness generation runs for up to 64 proofs per pass on the main stream into one of TWO value buffers, so the
+  // pass for proofs [k+64, k+128) runs underneath the proving pipelines of [k, k+64): a context stream only waits for
+  // the witness event of its own pass, and the main stream only waits -- before it overwrites buffer b -- for the
+  // contexts' latest reads of buffer b (two passes back).  No point of the batch drains the proving streams.
   const size_t MAXB = 64;
-  for (size_t base = 0; base < n_proofs; base += MAXB) {
+  size_t pass = 0;
+  for (size_t base = 0; base < n_proofs; base += MAXB, pass++) {
     size_t bsz = n_proofs - base < MAXB ? n_proofs - base : MAXB;
-    ensure_vals(bsz);
-    // the previous pass's proofs must be done reading vals_ before it is overwritten
-    for (auto& c : ctxs_) P25_HIP(hipStreamWaitEvent(stream_, c->done, 0));
+    const int buf = (int)((pass_counter_ + pass) & 1);
+    ensure_vals(buf, bsz);
+    for (auto& c : ctxs_) P25_HIP(hipStreamWaitEvent(stream_, c->done[buf], 0));
     P25_HIP(hipMemsetAsync(d_status + base, 0, bsz * 4, stream_));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (times) {
@@ -760,9 +773,9 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
       P25_HIP(hipEventCreate(&e1));
       P25_HIP(hipEventRecord(e0, stream_));
     }
-    launch_witgen(wp_, d_inputs + base * wp_.n_inputs, d_seeds + base, vals_.p, bsz, (uint32_t)bsz, d_status + base, stream_,
-                  d_filler ? d_filler + base * wp_.num_random_fill : nullptr);
-    P25_HIP(hipEventRecord(ev_witness_, stream_));
+    launch_witgen(wp_, d_inputs + base * wp_.n_inputs, d_seeds + base, vals_[buf].p, bsz, (uint32_t)bsz, d_status + base,
+                  stream_, d_filler ? d_filler + base * wp_.num_random_fill : nullptr);
+    P25_HIP(hipEventRecord(ev_witness_[buf], stream_));
     if (times) {
       P25_HIP(hipEventRecord(e1, stream_));
       P25_HIP(hipEventSynchronize(e1));
@@ -773,10 +786,11 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
     }
-    for (size_t k = 0; k < K && k < bsz; k++) P25_HIP(hipStreamWaitEvent(ctxs_[k]->st, ev_witness_, 0));
+    for (size_t k = 0; k < K && k < bsz; k++) P25_HIP(hipStreamWaitEvent(ctxs_[k]->st, ev_witness_[buf], 0));
     for (size_t p = 0; p < bsz; p++)
-      prove_one(*ctxs_[p % K], vals_.p, bsz, (uint32_t)p, d_proofs + (base + p) * proof_stride, d_status + base + p, times);
+      prove_one(*ctxs_[p % K], buf, bsz, (uint32_t)p, d_proofs + (base + p) * proof_stride, d_status + base + p, times);
   }
+  pass_counter_ += pass;
   P25_HIP(hipGetLastError());
 }
 
@@ -811,7 +825,7 @@ void DeviceCircuit::prove_batch(const u64* inputs, size_t n_proofs, const u64* s
 int32_t DeviceCircuit::witness(const u64* inputs, u64 seed, u64* wires_out) {
   ensure_ctx(1);
   sync();
-  ensure_vals(1);
+  ensure_vals(0, 1);
   Ctx* ctx_ = ctxs_[0].get();
   const size_t ni = wp_.n_inputs;
   for (size_t i = 0; i < ni; i++)
@@ -821,8 +835,8 @@ int32_t DeviceCircuit::witness(const u64* inputs, u64 seed, u64* wires_out) {
   P25_HIP(hipMemcpyAsync(d_seed.p, &seed, 8, hipMemcpyHostToDevice, stream_));
   uint32_t* d_status = (uint32_t*)ctx_->status.p;
   P25_HIP(hipMemsetAsync(d_status, 0, 4, stream_));
-  launch_witgen(wp_, d_in.p, d_seed.p, vals_.p, 1, 1, d_status, stream_);
-  launch_fill_wires(wp_, vals_.p, 1, 0, ctx_->wires_vals.p, stream_);
+  launch_witgen(wp_, d_in.p, d_seed.p, vals_[0].p, 1, 1, d_status, stream_);
+  launch_fill_wires(wp_, vals_[0].p, 1, 0, ctx_->wires_vals.p, stream_);
   uint32_t hs = 0;
   P25_HIP(hipMemcpyAsync(&hs, d_status, 4, hipMemcpyDeviceToHost, stream_));
   P25_HIP(hipMemcpyAsync(wires_out, ctx_->wires_vals.p, wp_.n_wire_elems * 8, hipMemcpyDeviceToHost, stream_));

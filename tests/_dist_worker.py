@@ -37,6 +37,17 @@ def main_standin(n_total):
     proofs, st = pd.gather_proofs(local, status, n_total)
     t = pd.max_over_ranks(1.0 + rank, torch.device("cpu"))
     assert t == float(world)
+    # the bench's form: receive buffers allocated once, used for several steps (results must not leak between steps)
+    g = pd.ProofGatherer(n_total, words, torch.device("cpu"))
+    for step in range(3):
+        blocks, sts = g.gather(local + step, status)
+        if rank == 0:
+            assert torch.equal(torch.cat(blocks), fake_prove(all_inputs, words) + step)
+            assert [b.shape[0] for b in blocks] == pd.shard_sizes(n_total, world)
+    # inputs generated on rank 0 only and broadcast (bench.py's plonky3 proof variants)
+    src = np.arange(12, dtype=np.uint64).reshape(3, 4) * np.uint64(0x1000000000000001) if rank == 0 else None
+    got = pd.broadcast_int64(src, (3, 4), torch.device("cpu"))
+    assert got.dtype == np.uint64 and (got == np.arange(12, dtype=np.uint64).reshape(3, 4) * np.uint64(0x1000000000000001)).all()
     if rank == 0:
         expect = fake_prove(all_inputs, words)
         assert proofs.shape == (n_total, words) and torch.equal(proofs, expect)

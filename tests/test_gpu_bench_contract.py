@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "16", "--steps", "1", "--warmup", "1",
-                        "--cpu-cores", "4"],
+                        "--cpu-cores", "4", "--aggregate", "4", "--extra-configs", "none"],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -37,6 +37,14 @@ def test_bench_json_contract():
     # the roofline line is the kernel with the GPU to itself; the in-flight figure is reported beside it
     assert rf["launches"] == 8 and rf["avg_launch_ms"] > 0 and rf["avg_launch_ms_timed_region"] >= 0.9 * rf["avg_launch_ms"]
     assert len(d["config"]["oracle_verified_indices"]) == 8
+    # the batch folded to one root proof by the recursive verifier circuits, root accepted by the oracle's verifier
+    ag = d["aggregation"]
+    assert ag["leaves"] == 4 and len(ag["levels"]) == 2 and ag["oracle_verifier_accepts_root"] is True
+    assert ag["leaf_equivalent_proofs_per_s_including_aggregation"] > 0
+    # VALU view: priced with the clock measured in the run, and only from a PMC pass of these very kernel sources
+    v = rf["valu"]
+    assert 1.0e9 < v["shader_clock_hz"] < 3.5e9 and ("stale" in v or v["csrc_sha"])
+    assert d["cpu_baseline"]["gpu_proof_bit_exact_vs_this_cpu_proof"] is True
 
 
 def test_bench_multi_rank_path_bare_launch():
@@ -55,3 +63,18 @@ def test_bench_multi_rank_path_bare_launch():
     assert d["config"]["oracle_verifier_accepts"] and "cpu_baseline" not in d
     assert len(d["per_rank"]) == 2 and all(p["proofs_per_s"] > 0 for p in d["per_rank"])
     assert abs(d["value"] - 2 * 8 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_strong_scaling_mode_two_ranks():
+    """--total T (BASELINE config 4 literally: T proofs per step split across the ranks), uneven shards (9 = 5 + 4)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total", "9", "--steps", "1",
+                        "--warmup", "1", "--dist-backend", "gloo", "--verify", "9"], capture_output=True, text=True,
+                       timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["proofs_per_step_total"] == 9
+    assert [p["proofs_per_step"] for p in d["per_rank"]] == [5, 4]
+    assert d["config"]["all_statuses_ok"] and d["config"]["gathered_complete_and_ok"] and d["config"]["oracle_verifier_accepts"]
+    assert d["config"]["oracle_verified_indices"] == list(range(9))      # every gathered proof, both ranks' blocks
+    assert abs(d["value"] - 9 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

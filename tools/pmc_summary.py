@@ -29,4 +29,15 @@ for k, v in rows:
 tot = {n: sum(v[n] for _, v in rows) for n in names}
 print("TOTAL (millions):", {n: round(t / 1e6, 1) for n, t in tot.items()}, "dur_ms", round(sum(v["dur_ns"] for _, v in rows) / 1e6, 3))
 if len(sys.argv) > 2:
-    json.dump({k: dict(v) for k, v in rows}, open(sys.argv[2], "w"), indent=1)
+    # _meta ties the counts to the kernel sources they were collected for (bench.py's VALU view checks it)
+    import hashlib, subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(ROOT, "plonky2.5_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h", ".inc")):
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+    out = {k: dict(v) for k, v in rows}
+    out["_meta"] = {"csrc_sha": h.hexdigest()[:16], "proofs_in_timed_call": n_proofs,
+                    "head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()}
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
