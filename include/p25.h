@@ -185,6 +185,9 @@ typedef struct {
   uint64_t degree_bits, num_rows_used, num_wires, num_routed_wires, num_inputs, num_generators;
   uint64_t num_gate_types, num_selectors, num_constants_sigmas, num_gate_constraints;
   uint64_t proof_words, witness_levels, witness_slots, num_random_fill;
+  /* sizes of the stage entry points' outputs: p25_partial_products writes num_challenges * (1 + num_partial_products)
+   * rows, p25_quotient num_challenges * quotient_degree_factor rows, of 2^degree_bits words each */
+  uint64_t num_challenges, num_partial_products, quotient_degree_factor;
 } p25_circuit_info_t;
 p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out);
 /* Rows per gate type, in sorted-gate order; ids_out receives up to cap gate-id strings joined by '\n'. */
@@ -220,10 +223,11 @@ typedef struct {
   float witness_ms, wires_commit_ms, partial_products_ms, zs_commit_ms, quotient_ms, quotient_commit_ms,
       openings_ms, fri_ms, total_ms;
 } p25_timings;
-/* Threading: a p25_circuit owns its streams and per-proof contexts, so calls on ONE circuit must not overlap
- * (upstream's `prove(&self)` is re-entrant; here use one p25_circuit per host thread, or serialise).  Different
- * circuits may be used from different threads.  With `timings` != NULL, or a batch of one, the proofs run one
- * at a time with latency-oriented kernel forms; otherwise up to P25_STREAMS (16) proofs are in flight. */
+/* Threading: like upstream's `prove(&self)`, every entry point may be called from any host thread, also concurrently
+ * on ONE p25_circuit (a Rust host with a rayon pool): a circuit owns its streams and per-proof contexts, so such
+ * calls are serialised inside the library (one mutex per circuit; use the batch forms, or one circuit per thread,
+ * for parallelism).  Different circuits never contend.  With `timings` != NULL, or a batch of one, the proofs run one
+ * at a time with latency-oriented kernel forms; otherwise up to 16 proofs are in flight (p25_circuit_set_streams). */
 p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* seeds,
                            uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status,
                            p25_timings* timings);
@@ -238,6 +242,9 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
                                uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status,
                                p25_timings* timings);
 p25_status p25_circuit_sync(p25_circuit* c);
+/* Proofs kept in flight by the batch entry points: one HIP stream and one per-proof working set (~1.6 GB for the
+ * fib-64 circuit) each; 1..16, default 16.  A library setting, not an environment variable. */
+p25_status p25_circuit_set_streams(p25_circuit* c, int32_t n_streams);
 /* Measurement hook for bench.py's roofline line: when enabled, HIP events on the proving stream
  * bracket every launch of the dominant kernel (the Poseidon leaf sponge over the 135-column wires
  * LDE).  Returns accumulated device milliseconds and launch count; reset != 0 clears them. */

@@ -11,8 +11,9 @@ __all__ = ["P25Error", "lib", "lib_path", "device_init", "shader_clock_hz", "pos
 
 P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# P25_LIB: load another build of the same library (tools/qmask.sh uses a profiling build); there is no fallback
-lib_path = os.environ.get("P25_LIB") or os.path.join(_HERE, "libp25.so")
+# The product library, in-tree, and nothing else: no environment override, no fallback.  (Profiling tools that need
+# another build -- tools/qmask.sh's gate-mask library -- assign `binding.lib_path` explicitly before the first call.)
+lib_path = os.path.join(_HERE, "libp25.so")
 
 STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "NO_DEVICE", 3: "HIP", 4: "WITNESS_CONFLICT",
                 5: "GENERATORS_NOT_RUN", 6: "OPENING_IN_SUBGROUP", 7: "INTERNAL", 8: "PARSE"}
@@ -101,7 +102,8 @@ class CircuitInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("degree_bits", "num_rows_used", "num_wires", "num_routed_wires",
                                           "num_inputs", "num_generators", "num_gate_types", "num_selectors",
                                           "num_constants_sigmas", "num_gate_constraints", "proof_words",
-                                          "witness_levels", "witness_slots", "num_random_fill")]
+                                          "witness_levels", "witness_slots", "num_random_fill",
+                                          "num_challenges", "num_partial_products", "quotient_degree_factor")]
 
 
 class Timings(C.Structure):
@@ -119,6 +121,7 @@ vp, sz, ui, i32 = C.c_void_p, C.c_size_t, C.c_uint, C.c_int32
 EXPORTED_SYMBOLS = {
     "p25_last_error": (C.c_char_p, []),
     "p25_shader_clock_hz": (i32, [C.POINTER(C.c_double)]),
+    "p25_circuit_set_streams": (i32, [vp, i32]),
     "p25_version": (C.c_char_p, []),
     "p25_device_init": (i32, [C.c_int]),
     "p25_poseidon_permute": (i32, [vp, sz]),
@@ -167,9 +170,10 @@ def lib():
     """Load libp25.so (fails loudly if it was not built: there is no fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(lib_path):
-            raise P25Error(7, f"{lib_path} not found -- run `python -c 'import __graft_entry__ as g; g.build()'`")
-        _lib = C.CDLL(lib_path)
+        path = globals()["lib_path"]
+        if not os.path.exists(path):
+            raise P25Error(7, f"{path} not found -- run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib = C.CDLL(path)
         for name, (res, args) in EXPORTED_SYMBOLS.items():
             fn = getattr(_lib, name)
             fn.restype = res
@@ -439,8 +443,8 @@ class Circuit:
         w, b, g = _u64(wires), _u64(betas), _u64(gammas)
         n = 1 << int(self.info.degree_bits)
         assert w.shape == (int(self.info.num_wires), n) and b.size == 2 and g.size == 2
-        npp = -(-int(self.info.num_routed_wires) // 8) - 1
-        out = np.zeros((2 * (1 + npp), n), dtype=np.uint64)
+        rows = int(self.info.num_challenges) * (1 + int(self.info.num_partial_products))   # what the C side writes
+        out = np.zeros((rows, n), dtype=np.uint64)
         _check(lib().p25_partial_products(self._h, _ptr(w), _ptr(b), _ptr(g), _ptr(out)))
         return out
 
@@ -448,8 +452,10 @@ class Circuit:
         """Quotient chunk coefficients [NC*8][n] from witness and Z/partial-product values."""
         w, z, b, g, a = _u64(wires), _u64(zs_pp), _u64(betas), _u64(gammas), _u64(alphas)
         n = 1 << int(self.info.degree_bits)
-        assert w.shape == (int(self.info.num_wires), n) and z.shape[1] == n
-        out = np.zeros((16, n), dtype=np.uint64)
+        nc, npp, qdf = (int(self.info.num_challenges), int(self.info.num_partial_products),
+                        int(self.info.quotient_degree_factor))
+        assert w.shape == (int(self.info.num_wires), n) and z.shape == (nc * (1 + npp), n)
+        out = np.zeros((nc * qdf, n), dtype=np.uint64)
         _check(lib().p25_quotient(self._h, _ptr(w), _ptr(z), _ptr(b), _ptr(g), _ptr(a), _ptr(out)))
         return out
 
@@ -486,6 +492,10 @@ class Circuit:
 
     def sync(self):
         _check(lib().p25_circuit_sync(self._h))
+
+    def set_streams(self, n):
+        """Proofs kept in flight by the batch entry points (1..16)."""
+        _check(lib().p25_circuit_set_streams(self._h, n))
 
     def kernel_stats(self, enable=True, reset=False):
         """(ms, launches) of the dominant kernel (wires leaf sponge), measured with HIP events."""

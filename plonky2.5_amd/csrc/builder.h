@@ -74,6 +74,7 @@ const GateInfo& gate_info(GateKind k);
 // limits of the device kernels, enforced when a circuit enters the library (circuit_io.cpp)
 constexpr int ALPHA_POWS = 192;   // alpha-power table of the quotient kernel: max constraints per gate
 constexpr int MAX_ROUTED = 128;   // routed wires the permutation argument kernels hold
+constexpr int MAX_CHUNKS = 16;    // partial-product chunks per challenge (num_partial_products + 1) they hold per row
 constexpr int BASE_SUM_LIMBS = 63;
 constexpr int EXP_POWER_BITS = 66;
 

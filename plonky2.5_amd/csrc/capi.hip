@@ -260,15 +260,22 @@ struct p25_circuit {
   std::unique_ptr<p25::DeviceCircuit> dev;
   std::unique_ptr<p25::WitnessProgram> wp_info;
   bool moved = false;
+  int streams = 16;  // proofs in flight (p25_circuit_set_streams)
+  // Entry points that touch the device state of ONE circuit are serialised: upstream's `prove(&self)` is re-entrant,
+  // so a host with a thread pool may call into the same circuit concurrently; here those calls queue up instead of
+  // racing for the circuit's streams and contexts.  Different circuits never contend.
+  std::recursive_mutex mu;
   const p25::Circuit& c() const { return dev ? dev->circuit() : circuit; }
   p25::DeviceCircuit& device() {
     if (!dev) {
       dev.reset(new p25::DeviceCircuit(std::move(circuit)));
+      dev->set_streams(streams);
       moved = true;
     }
     return *dev;
   }
 };
+#define P25_LOCK(c) std::lock_guard<std::recursive_mutex> p25_lock_((c)->mu)
 
 template <class F>
 static p25_status host_guarded(F&& f) {
@@ -459,6 +466,9 @@ p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out) {
     out->witness_levels = c->wp_info->level_start.size() - 1;
     out->witness_slots = c->wp_info->num_slots;
     out->num_random_fill = c->wp_info->num_random_fill;
+    out->num_challenges = k.cfg.num_challenges;
+    out->num_partial_products = k.num_partial_products;
+    out->quotient_degree_factor = k.cfg.max_quotient_degree_factor;
     return P25_OK;
   });
 }
@@ -482,6 +492,7 @@ p25_status p25_circuit_gate_counts(const p25_circuit* c, uint64_t* counts_out, s
 p25_status p25_circuit_digest(p25_circuit* c, uint64_t* digest4, uint64_t* cs_cap) {
   return guarded([&]() -> p25_status {
     if (!c || !digest4) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     p25::DeviceCircuit& d = c->device();
     memcpy(digest4, d.digest(), 32);
     if (cs_cap) memcpy(cs_cap, d.cs_cap().data(), d.cs_cap().size() * 8);
@@ -501,6 +512,7 @@ p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proo
                            p25_timings* timings) {
   return guarded([&]() -> p25_status {
     if (!c || !inputs || !proofs_out || !per_proof_status) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     if (!n_proofs) return P25_OK;
     p25::PhaseTimes pt;
     c->device().prove_batch(inputs, n_proofs, seeds, proofs_out, proof_stride_words, per_proof_status, timings ? &pt : nullptr);
@@ -512,6 +524,7 @@ p25_status p25_prove_batch_filler(p25_circuit* c, const uint64_t* inputs, size_t
                                   uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status) {
   return guarded([&]() -> p25_status {
     if (!c || !inputs || !filler || !proofs_out || !per_proof_status) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     if (!n_proofs) return P25_OK;
     c->device().prove_batch(inputs, n_proofs, nullptr, proofs_out, proof_stride_words, per_proof_status, nullptr, filler);
     return P25_OK;
@@ -521,6 +534,7 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
                                uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status, p25_timings* timings) {
   return guarded([&]() -> p25_status {
     if (!c || !d_inputs || !d_seeds || !d_proofs || !d_status) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     p25::DeviceCircuit& d = c->device();
     if (proof_stride_words < d.layout().total) throw std::invalid_argument("proof_stride smaller than the proof");
     p25::PhaseTimes pt;
@@ -529,9 +543,20 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
     return P25_OK;
   });
 }
+p25_status p25_circuit_set_streams(p25_circuit* c, int32_t n_streams) {
+  return host_guarded([&]() -> p25_status {
+    if (!c) throw std::invalid_argument("null argument");
+    if (n_streams < 1 || n_streams > 16) throw std::invalid_argument("n_streams must be in 1..16");
+    P25_LOCK(c);
+    c->streams = n_streams;
+    if (c->dev) c->dev->set_streams(n_streams);
+    return P25_OK;
+  });
+}
 p25_status p25_circuit_sync(p25_circuit* c) {
   return guarded([&]() -> p25_status {
     if (!c) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     c->device().sync();
     return P25_OK;
   });
@@ -539,6 +564,7 @@ p25_status p25_circuit_sync(p25_circuit* c) {
 p25_status p25_circuit_kernel_stats(p25_circuit* c, int enable, int reset, double* ms_out, uint64_t* launches_out) {
   return guarded([&]() -> p25_status {
     if (!c) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     p25::DeviceCircuit& d = c->device();
     d.kernel_stats_enable(enable != 0);
     u64 n = 0;
@@ -550,6 +576,7 @@ p25_status p25_circuit_kernel_stats(p25_circuit* c, int enable, int reset, doubl
 p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, uint64_t* wires_out, p25_status* proof_status) {
   return guarded([&]() -> p25_status {
     if (!c || !inputs || !wires_out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     int32_t st = c->device().witness(inputs, seed, wires_out);
     if (proof_status) *proof_status = st;
     return P25_OK;
@@ -571,6 +598,7 @@ p25_status p25_partial_products(p25_circuit* c, const uint64_t* wires, const uin
                                 uint64_t* out) {
   return guarded([&]() -> p25_status {
     if (!c || !wires || !betas || !gammas || !out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     c->device().partial_products(wires, betas, gammas, out);
     return P25_OK;
   });
@@ -579,6 +607,7 @@ p25_status p25_quotient(p25_circuit* c, const uint64_t* wires, const uint64_t* z
                         const uint64_t* gammas, const uint64_t* alphas, uint64_t* out) {
   return guarded([&]() -> p25_status {
     if (!c || !wires || !zs_pp || !betas || !gammas || !alphas || !out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     c->device().quotient(wires, zs_pp, betas, gammas, alphas, out);
     return P25_OK;
   });

@@ -124,6 +124,10 @@ Circuit circuit_from_blob(const uint8_t* data, size_t len) {
       (c.cfg.num_routed_wires + c.cfg.max_quotient_degree_factor - 1) / c.cfg.max_quotient_degree_factor - 1)
     bad("num_partial_products does not match ceil(num_routed / max_quotient_degree_factor) - 1");
   if (c.num_gate_constraints < 0 || c.num_gate_constraints > ALPHA_POWS) bad("too many gate constraints");
+  // the permutation-argument kernels keep one value per chunk in registers and the quotient kernel folds with alpha
+  // powers up to NC * (2 + NP): limits of the device code, not of the format
+  if (c.num_partial_products + 1 > MAX_CHUNKS) bad("more partial-product chunks than the kernels hold (MAX_CHUNKS)");
+  if (c.cfg.num_challenges * (2 + c.num_partial_products) >= ALPHA_POWS) bad("vanishing-polynomial terms exceed the alpha-power table");
   if (n_arity > 8) bad("too many FRI layers");
   if (c.pi_row != -1 && (c.pi_row < 0 || (size_t)c.pi_row >= ((size_t)1 << c.degree_bits))) bad("bad public-input row");
   {
@@ -149,6 +153,15 @@ Circuit circuit_from_blob(const uint8_t* data, size_t len) {
     if (c.num_gate_constraints != max_nc) bad("num_gate_constraints does not match the gate set");
     for (GateKind k : c.gates)
       if (gate_info(k).num_constants > c.cfg.num_constants) bad("a gate needs more constants than the circuit has");
+    // A quotient of degree factor 2^rate_bits only exists if every FILTERED gate constraint fits in it: upstream
+    // selectors.rs groups gates so that (gates in the group) + degree <= max_quotient_degree_factor + 1 (one more
+    // when there is a single group and hence no "unused" selector value).
+    for (size_t i = 0; i < c.gates.size(); i++) {
+      const auto& gr = c.groups[c.selector_index[i]];
+      if ((size_t)gr.first > i || (size_t)gr.second <= i) bad("gate outside its selector group");
+      if ((gr.second - gr.first) + gate_info(c.gates[i]).degree > c.cfg.max_quotient_degree_factor + 1 + (c.num_selectors == 1 ? 1 : 0))
+        bad("a filtered gate constraint exceeds the quotient degree (rate_bits too small for this gate set)");
+    }
     // the evaluators index a row's wires by fixed column numbers
     static const int MIN_WIRES[G_NUM_KINDS] = {0, 2, 4, 1 + BASE_SUM_LIMBS, 6 + 96, 6 + 128, 80, 78, 2 + 2 * EXP_POWER_BITS,
                                                18 + 96, 135, 80, 135};

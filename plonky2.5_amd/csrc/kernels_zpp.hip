@@ -16,7 +16,6 @@
 
 namespace p25 {
 
-constexpr int MAX_CHUNKS = 16;
 
 __global__ __launch_bounds__(256) void k_zpp_chunks(ZppArgs a) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;

@@ -86,6 +86,8 @@ class DeviceCircuit {
   void prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs, size_t proof_stride,
                        uint32_t* d_status, PhaseTimes* times, const u64* d_filler = nullptr);
   void sync();
+  // proofs kept in flight by prove_batch* (one HIP stream + working set each), 1..16
+  void set_streams(int k) { streams_ = k < 1 ? 1 : (k > 16 ? 16 : k); }
   hipStream_t stream() const { return stream_; }
   // Isolated stages (host buffers; parity tests of SURVEY 8a7 / 8a8 through p25_partial_products / p25_quotient):
   // wires[num_wires][n] -> out[NC*(1+NP)][n];  wires + zs_pp values -> out[NC*8][n] quotient chunk coefficients
@@ -118,6 +120,7 @@ class DeviceCircuit {
   hipStream_t stream_ = nullptr;
   std::vector<std::unique_ptr<Ctx>> ctxs_;   // proofs in flight: one working set + HIP stream each
   hipEvent_t ev_witness_[2] = {nullptr, nullptr};  // witness pass into vals_[b] finished
+  int streams_ = 16;
   bool single_proof_ = false;  // set per prove call: one proof in flight -> latency-oriented kernel forms
   DevMem vals_[2];             // witness values of a pass, slot-major [slot][proof of the pass]; double-buffered
   size_t vals_batch_[2] = {0, 0};

@@ -184,6 +184,10 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
   if (c_.cfg.num_challenges != 2 || c_.cfg.rate_bits > 3 || c_.gates.size() > 16)
     throw std::invalid_argument("unsupported circuit configuration");
   if (c_.fri_reduction_arity_bits.size() > 8) throw std::invalid_argument("too many FRI layers");
+  // register / LDS capacities of k_zpp_* and k_quotient (also enforced when a blob is imported)
+  if (c_.num_partial_products + 1 > MAX_CHUNKS || c_.cfg.num_routed_wires > MAX_ROUTED ||
+      c_.cfg.num_challenges * (2 + c_.num_partial_products) >= ALPHA_POWS || c_.num_gate_constraints > ALPHA_POWS)
+    throw std::invalid_argument("circuit exceeds the permutation-argument / quotient kernels' capacities");
   P25_HIP(hipStreamCreate(&stream_));
   layout_ = make_proof_layout(c_);
   const size_t n = c_.degree();
@@ -713,12 +717,6 @@ void fri_prove_standalone(NttTables& tables, const u64* coeffs, const FriShape& 
   memcpy(o, pr.data() + fo.queries, per_q * sh.num_queries * 8);
 }
 
-static size_t streams_in_flight() {
-  const char* e = getenv("P25_STREAMS");
-  int k = e ? atoi(e) : 16;
-  return (size_t)(k < 1 ? 1 : (k > 16 ? 16 : k));
-}
-
 // Batch schedule: witness generation for up to 64 proofs at a time on the main stream (it is
 // parallel ACROSS proofs), then each proof's commit/quotient/FRI pipeline on one of K streams so that
 // the latency-bound stretches of one proof (transcript, Merkle-cap levels, FRI tail) overlap with the
@@ -734,7 +732,7 @@ size_t DeviceCircuit::ctx_bytes() const {
 
 void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs,
                                     size_t proof_stride, uint32_t* d_status, PhaseTimes* times, const u64* d_filler) {
-  size_t K = times ? 1 : streams_in_flight();
+  size_t K = times ? 1 : (size_t)streams_;
   if (K > n_proofs) K = n_proofs ? n_proofs : 1;
   if (K > ctxs_.size()) {
     // New contexts must fit in what is actually FREE on the device (other circuits, the caller's tensors and

@@ -72,3 +72,24 @@ def test_no_device_means_error_not_fallback(p25):
         c.build_recursive_verifier(1)          # needs the device for the inner digest unless it is passed in
     with pytest.raises(p25.P25Error):
         p25.transcript([([1, 2, 3], 1)])
+
+
+def test_blob_beyond_kernel_capacities_is_rejected(p25):
+    """A blob the header checks alone would accept but the device kernels cannot hold: rate_bits = 2 with
+    80 routed wires means 20 partial-product chunks per challenge (k_zpp_chunks holds MAX_CHUNKS = 16 in registers) and
+    gate constraints of degree above the quotient's -- refused at import, before any kernel sees it."""
+    import struct
+    blob = bytearray(p25.Circuit.build_gadget(0, 0).to_blob())
+    hdr = list(struct.unpack_from("<32Q", blob, 8))
+    assert hdr[5] == 8 and hdr[6] == 3 and hdr[2] == 80 and hdr[13] == 9   # qdf, rate_bits, routed wires, NP
+    hdr[5], hdr[6], hdr[13] = 4, 2, 19                                      # consistent among themselves
+    struct.pack_into("<32Q", blob, 8, *hdr)
+    with pytest.raises(p25.P25Error) as e:
+        p25.Circuit.from_blob(bytes(blob))
+    assert e.value.status == 1 and "MAX_CHUNKS" in str(e.value)
+    # rate_bits 2 with few enough routed wires for the chunk arrays still fails: the gate set's degree needs rate_bits 3
+    hdr[2], hdr[13] = 64, 15
+    struct.pack_into("<32Q", blob, 8, *hdr)
+    with pytest.raises(p25.P25Error) as e:
+        p25.Circuit.from_blob(bytes(blob))
+    assert e.value.status == 1

@@ -138,6 +138,45 @@ def test_two_host_threads_two_circuits(gpu, oracle):
             assert sto == 0 and (proof == po).all(), (name, rep)
 
 
+def test_host_threads_share_one_circuit(gpu, oracle):
+    """include/p25.h "Threading": upstream's `prove(&self)` is re-entrant, so a host thread pool may call into ONE
+    circuit concurrently; the library serialises those calls.  Four threads prove different batches on the same
+    circuit at once (with different stream counts set beforehand); every proof equals the oracle's."""
+    import threading
+    from gadget_cases import cases
+    name, kind, param, vals = [c for c in cases(oracle) if c[0] == "compress"][0]
+    c = gpu.Circuit.build_gadget(kind, param)
+    c.set_streams(3)
+    inp = np.array(vals, dtype=np.uint64)
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            out = []
+            for rep in range(3):
+                n = 2 + tid
+                proofs, st = c.prove(np.stack([inp] * n), seeds=[100 * tid + rep] * n)
+                out.append((proofs[n - 1].copy(), st.tolist()))
+            results[tid] = out
+        except Exception as e:  # surfaced below: an assert in a thread would go unnoticed
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    oc = oracle.load_circuit(c.to_blob())
+    for tid, out in results.items():
+        for rep, (proof, st) in enumerate(out):
+            assert st == [0] * (2 + tid)
+            po, sto, _t, msg = oc.prove(inp, seed=100 * tid + rep)
+            assert sto == 0 and (proof == po).all(), (tid, rep)
+    with pytest.raises(gpu.P25Error):
+        c.set_streams(0)
+
+
 def test_circuit_create_destroy_does_not_leak_device_memory(gpu):
     import torch
     inp, cfg = gpu.p3_prove_fibonacci(3, 3, 4)

@@ -5,7 +5,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import __graft_entry__ as ge
-p25 = ge.load_package(); p25.device_init(0)
+p25 = ge.load_package()
+if "--lib" in sys.argv:   # profiling builds only (tools/qmask.sh): an explicit path, never an environment variable
+    i = sys.argv.index("--lib")
+    sys.modules["plonky25_amd.binding"].lib_path = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+p25.device_init(0)
 inputs, _ = p25.p3_proof_from_json(open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")).read())
 c = p25.Circuit.build_p3_verifier(p25.P3Config.fib64())
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
