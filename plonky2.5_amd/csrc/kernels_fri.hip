@@ -8,6 +8,7 @@
 // SURVEY.md App. A.7-A.8.  Extension-field vectors are stored as two component arrays (a[], b[]).
 #include "kernels.h"
 #include "coop.h"
+#include "coop_lat.h"
 #include "poseidon.h"
 #include "prover_kernels.h"
 
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64* __restric
     const uint32_t m = words - off < 8 ? words - off : 8;
     const uint32_t wd = off + (uint32_t)rr;
     if ((uint32_t)rr < m) s = ((wd & 1) ? vb : va)[g * arity + (wd >> 1)];
-    s = coop::poseidon_permute(s, threadIdx.x & 63, rc_lds);
+    s = coop::poseidon_permute_lat(s, threadIdx.x & 63, rc_lds);
   }
   if (valid && rr < 4) digests[4 * g + rr] = s;
 }

@@ -14,6 +14,7 @@
 #include "poseidon.h"
 #include "poseidon2.h"
 #include "coop.h"
+#include "coop_lat.h"
 
 namespace p25 {
 
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__
   const bool valid = g < n_parents;
   if (!valid) g = n_parents - 1;  // keep every lane in the shuffles
   u64 s = rr < 8 ? children[8 * g + rr] : 0;
-  s = coop::poseidon_permute(s, threadIdx.x & 63, rc_lds);
+  s = coop::poseidon_permute_lat(s, threadIdx.x & 63, rc_lds);
   if (valid && rr < 4) parents[4 * g + rr] = s;
 }
 // Levels with at most this many parents use the cooperative kernel.  512 when many proofs are in flight

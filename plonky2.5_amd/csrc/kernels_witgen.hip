@@ -15,6 +15,7 @@
 #include "poseidon.h"
 #include "poseidon2.h"
 #include "coop.h"
+#include "coop_lat.h"
 #include "prover_kernels.h"
 
 namespace p25 {
@@ -225,72 +226,65 @@ __global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__
 
 // Poseidon2 generators of one level, one 16-lane group per (generator, proof): used for small batches,
 // where a level's latency is that of a single permutation (poseidon2_gate.rs:447-523, cooperatively).
-__device__ __forceinline__ void witgen_p2_coop_body(uint32_t block, const u64* k_lds, u64* tr_lds, const WitGen* __restrict__ gens,
-                                                    const uint32_t* __restrict__ args, uint32_t g_begin,
-                                                    uint32_t g_count, u64* __restrict__ vals, size_t B,
-                                                    uint32_t n_proofs, uint32_t* __restrict__ status) {
+// The permutation generators of a level are contiguous in `gens` and their argument lists are laid out back to
+// back with a fixed stride (13 dependencies + 122 outputs), so a group finds its slot indices at
+// arg_base + k * COOP_ARG_STRIDE without loading its WitGen record first -- one dependent global load less in a
+// kernel whose whole duration is a chain of them around one permutation.
+constexpr uint32_t COOP_N_DEPS = 13, COOP_N_OUTS = 4 + 106 + 12, COOP_ARG_STRIDE = COOP_N_DEPS + COOP_N_OUTS;
+template <bool P2>
+__device__ __forceinline__ void witgen_perm_coop_body(uint32_t block, const u64* k_lds, u64* tr_lds,
+                                                      const uint32_t* __restrict__ args, uint32_t arg_base,
+                                                      uint32_t g_count, u64* __restrict__ vals, size_t B,
+                                                      uint32_t n_proofs, uint32_t* __restrict__ status) {
   size_t grp = ((size_t)block * blockDim.x + threadIdx.x) / coop::GROUP;
   const size_t n_groups = (size_t)g_count * n_proofs;
   const bool valid = grp < n_groups;
-  if (!valid) grp = n_groups - 1;  // every lane takes part in the shuffles
+  if (!valid) grp = n_groups - 1;  // every lane takes part in the cross-lane operations
   const int lane = threadIdx.x & 63, rr = threadIdx.x & (coop::GROUP - 1), base = lane & ~(coop::GROUP - 1);
-  const uint32_t gi = g_begin + (uint32_t)(grp / n_proofs);
   const uint32_t p = (uint32_t)(grp % n_proofs);
-  const WitGen g = gens[gi];
-  const uint32_t* dep = args + g.arg_off;
-  Emitter em{vals, dep + g.n_deps, B, p, status};
-  auto emit = [&](int k, u64 v) {
-    if (valid) em(k, v);
+  const uint32_t* dep = args + arg_base + (size_t)(grp / n_proofs) * COOP_ARG_STRIDE;
+  const uint32_t* outs = dep + COOP_N_DEPS;
+  // every index this lane will need, requested up front: its input word, the swap flag, and the slots of the
+  // outputs it writes afterwards (delta / state word, up to 7 trace words)
+  const uint32_t in_slot = dep[rr < 12 ? rr : 0], swap_slot = dep[12];
+  uint32_t o_slot[7];
+#pragma unroll
+  for (int t = 0; t < 7; t++) o_slot[t] = rr + 16 * t < 106 ? outs[4 + rr + 16 * t] : 0;
+  const uint32_t o_delta = outs[rr < 4 ? rr : 0], o_state = outs[4 + 106 + (rr < 12 ? rr : 0)];
+  auto put = [&](uint32_t a, u64 v) {  // Emitter::operator() with the slot word already in a register
+    if (!valid) return;
+    const size_t idx = (size_t)(a & 0x7FFFFFFFu) * B + p;
+    if (a & WIT_CHECK_FLAG) {
+      if (vals[idx] != v) set_status(status + p, 4);  // P25_ERR_WITNESS_CONFLICT
+    } else {
+      vals[idx] = v;
+    }
   };
-  u64 s = rr < 12 ? vals[(size_t)dep[rr] * B + p] : 0;
-  const u64 swap = vals[(size_t)dep[12] * B + p];
+  u64 s = rr < 12 ? vals[(size_t)in_slot * B + p] : 0;
+  const u64 swap = vals[(size_t)swap_slot * B + p];
+  __syncthreads();  // the constants staged by the caller (their loads were in flight beside the ones above)
   u64 up = coop::shfl64(s, base + ((rr + 4) & (coop::GROUP - 1)));
   u64 dn = coop::shfl64(s, base + ((rr + 12) & (coop::GROUP - 1)));
-  if (rr < 4) emit(rr, gl::mul(swap, gl::sub(up, s)));
+  if (rr < 4) put(o_delta, gl::mul(swap, gl::sub(up, s)));
   if (swap == 1) s = rr < 4 ? up : (rr < 8 ? dn : s);
   // The 106 trace words go to LDS while the permutation runs and are written out afterwards: emitting from inside
-  // the rounds put a global load (the output's slot index) and its wait into every step of the dependent chain.
+  // the rounds put a global store and its address arithmetic into every step of the dependent chain.
   u64* tr = tr_lds + (threadIdx.x / coop::GROUP) * 106;
-  s = coop::poseidon2_permute(s, lane, k_lds, [&](int i, u64 v) { tr[i] = v; });
+  if constexpr (P2)
+    s = coop::poseidon2_permute_lat(s, lane, k_lds, [&](int i, u64 v) { tr[i] = v; });
+  else
+    s = coop::poseidon_permute_trace_lat(s, lane, k_lds, [&](int i, u64 v) { tr[i] = v; });
   __syncthreads();
-  for (int i = rr; i < 106; i += coop::GROUP) emit(4 + i, tr[i]);
-  if (rr < 12) emit(4 + 106 + rr, s);
-}
-// The same for PoseidonGate generators (recursive verifier circuits; upstream PoseidonGenerator).
-__device__ __forceinline__ void witgen_p1_coop_body(uint32_t block, const u64* rc_lds, u64* tr_lds, const WitGen* __restrict__ gens,
-                                                    const uint32_t* __restrict__ args, uint32_t g_begin,
-                                                    uint32_t g_count, u64* __restrict__ vals, size_t B,
-                                                    uint32_t n_proofs, uint32_t* __restrict__ status) {
-  size_t grp = ((size_t)block * blockDim.x + threadIdx.x) / coop::GROUP;
-  const size_t n_groups = (size_t)g_count * n_proofs;
-  const bool valid = grp < n_groups;
-  if (!valid) grp = n_groups - 1;  // every lane takes part in the shuffles
-  const int lane = threadIdx.x & 63, rr = threadIdx.x & (coop::GROUP - 1), base = lane & ~(coop::GROUP - 1);
-  const uint32_t gi = g_begin + (uint32_t)(grp / n_proofs);
-  const uint32_t p = (uint32_t)(grp % n_proofs);
-  const WitGen g = gens[gi];
-  const uint32_t* dep = args + g.arg_off;
-  Emitter em{vals, dep + g.n_deps, B, p, status};
-  auto emit = [&](int k, u64 v) {
-    if (valid) em(k, v);
-  };
-  u64 s = rr < 12 ? vals[(size_t)dep[rr] * B + p] : 0;
-  const u64 swap = vals[(size_t)dep[12] * B + p];
-  u64 up = coop::shfl64(s, base + ((rr + 4) & (coop::GROUP - 1)));
-  u64 dn = coop::shfl64(s, base + ((rr + 12) & (coop::GROUP - 1)));
-  if (rr < 4) emit(rr, gl::mul(swap, gl::sub(up, s)));
-  if (swap == 1) s = rr < 4 ? up : (rr < 8 ? dn : s);
-  u64* tr = tr_lds + (threadIdx.x / coop::GROUP) * 106;
-  s = coop::poseidon_permute_trace(s, lane, rc_lds, [&](int i, u64 v) { tr[i] = v; });
-  __syncthreads();
-  for (int i = rr; i < 106; i += coop::GROUP) emit(4 + i, tr[i]);
-  if (rr < 12) emit(4 + 106 + rr, s);
+#pragma unroll
+  for (int t = 0; t < 7; t++)
+    if (rr + 16 * t < 106) put(o_slot[t], tr[rr + 16 * t]);
+  if (rr < 12) put(o_state, s);
 }
 // One launch per level for small batches (every launch costs ~12 us of a single proof's latency): blocks
 // [0, nb_level) run the per-lane generators of the level, the rest its Poseidon2 generators cooperatively.
 __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __restrict__ gens,
                                                             const uint32_t* __restrict__ args, uint32_t g_begin,
-                                                            uint32_t g_count, uint32_t p2_begin, uint32_t p2_count,
+                                                            uint32_t g_count, uint32_t perm_arg_base, uint32_t p2_count,
                                                             uint32_t nb_level, u64* __restrict__ vals, size_t B,
                                                             uint32_t n_proofs, const u64* __restrict__ seeds,
                                                             uint32_t* __restrict__ status,
@@ -301,11 +295,12 @@ __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __rest
   if (blockIdx.x < nb_level) {
     witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, coop_kind, filler, n_filler);
   } else if (coop_kind == GEN_POSEIDON2) {
-    coop::stage_poseidon2_rc(k_lds);
-    witgen_p2_coop_body(blockIdx.x - nb_level, k_lds, tr_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
+    for (int i = threadIdx.x; i < coop::P2_LDS_WORDS; i += blockDim.x)   // = coop::stage_poseidon2_rc without its barrier
+      k_lds[i] = i < 96 ? poseidon2::P2_RC[i] : (i < 118 ? poseidon2::P2_RC_MID[i - 96] : poseidon2::P2_MAT_DIAG_M_1[i - 118] - 1);
+    witgen_perm_coop_body<true>(blockIdx.x - nb_level, k_lds, tr_lds, args, perm_arg_base, p2_count, vals, B, n_proofs, status);
   } else {
-    coop::stage_poseidon_rc(k_lds);
-    witgen_p1_coop_body(blockIdx.x - nb_level, k_lds, tr_lds, gens, args, p2_begin, p2_count, vals, B, n_proofs, status);
+    for (int i = threadIdx.x; i < 360; i += blockDim.x) k_lds[i] = poseidon::RC[i];
+    witgen_perm_coop_body<false>(blockIdx.x - nb_level, k_lds, tr_lds, args, perm_arg_base, p2_count, vals, B, n_proofs, status);
   }
 }
 
@@ -375,7 +370,7 @@ void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u6
       const unsigned nb1 = p2c < cnt ? (unsigned)((th + 255) / 256) : 0;
       const size_t th2 = (size_t)p2c * n_proofs * coop::GROUP;
       hipLaunchKernelGGL(k_witgen_level_fused, dim3(nb1 + (unsigned)((th2 + 255) / 256)), dim3(256), 0, st, wp.d_gens,
-                         wp.d_args, b, cnt, wp.level_p2_begin[l], p2c, nb1, d_vals, B, n_proofs, d_seeds, d_status, d_filler,
+                         wp.d_args, b, cnt, wp.level_perm_arg_base[l], p2c, nb1, d_vals, B, n_proofs, d_seeds, d_status, d_filler,
                          wp.num_random_fill, wp.level_coop_kind[l]);
     }
   }

@@ -226,6 +226,13 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
     wp_.level_p2_begin.push_back(pb);
     wp_.level_p2_count.push_back(pc);
     wp_.level_coop_kind.push_back(kind);
+    // the cooperative kernel addresses the arguments of permutation k of the level at base + k * 135: check the layout
+    for (uint32_t k = 0; k < pc; k++) {
+      const WitGen& g = wp.gens[pb + k];
+      if (g.kind != kind || g.n_deps != 13 || g.n_outs != 4 + 106 + 12 || g.arg_off != wp.gens[pb].arg_off + k * 135u)
+        throw std::logic_error("witness program: permutation generators of a level are not laid out contiguously");
+    }
+    wp_.level_perm_arg_base.push_back(pc ? wp.gens[pb].arg_off : 0);
   }
   wp_.n_inputs = (uint32_t)wp.input_slots.size();
   wp_.num_slots = wp.num_slots;

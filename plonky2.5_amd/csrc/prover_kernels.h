@@ -16,6 +16,7 @@ struct DeviceWitnessProgram {
   // the permutation generators of each level that run cooperatively for small batches (contiguous: gens are sorted
   // by kind within a level): Poseidon2Gate's (inner circuits) or, where a level has none, PoseidonGate's (recursion)
   std::vector<uint32_t> level_p2_begin, level_p2_count, level_coop_kind;
+  std::vector<uint32_t> level_perm_arg_base;  // WitGen::arg_off of the level's first permutation generator (fixed stride after it)
   uint32_t n_inputs = 0, num_slots = 0, num_random_fill = 0;
   size_t n_wire_elems = 0;
 };
