@@ -96,9 +96,52 @@ __global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__
   s = coop::poseidon_permute_lat(s, threadIdx.x & 63, rc_lds);
   if (valid && rr < 4) parents[4 * g + rr] = s;
 }
-// Levels with at most this many parents use the cooperative kernel.  512 when many proofs are in flight
-// (the per-lane form costs several times fewer instructions and other streams hide its latency; measured
-// 4096 / 512 / 0: 122.3 / 123.0 / 122.8 proofs/s); a lone proof prefers 32768: at that size the per-lane
+// The top of a tree in ONE launch: block b reduces the subtree under cap entry b, from a level with up to 32 nodes
+// per cap entry down to the entry itself, one cooperative permutation per parent (16 groups of 16 lanes per block:
+// four waves, one per SIMD of the CU -- more waves per SIMD would share its issue slots and stretch every
+// permutation, which a first attempt with 64 groups per block showed: +0.15 ms per tree), the level just computed
+// staying in LDS for the next one; a wave with no parent left at a level skips it.  A level of this size is a single
+// permutation deep whatever the kernel (~14 us), so launching the top levels one by one costs a kernel boundary
+// plus the constants' staging per level for nothing.
+// `nodes`: the level with `per_block` nodes per cap entry (4 words each, tree layout); the levels above it follow
+// in memory (merkle_level_offset), which is where the parents are written.
+constexpr int TOP_GROUPS = 16;                       // 256 lanes per block
+constexpr size_t TOP_MAX_NODES = 2 * TOP_GROUPS;     // nodes per cap entry at the level the kernel starts from
+__global__ __launch_bounds__(256) void k_tree_top_coop(u64* __restrict__ nodes, uint32_t per_block, uint32_t n_blocks) {
+  __shared__ u64 rc_lds[360];
+  __shared__ u64 lvl[2][TOP_GROUPS * 4];
+  coop::stage_poseidon_rc(rc_lds);
+  const int g = threadIdx.x / coop::GROUP, rr = threadIdx.x & (coop::GROUP - 1), lane = threadIdx.x & 63;
+  const uint32_t b = blockIdx.x;
+  u64* cur = nodes;                       // level base (all blocks)
+  size_t level_nodes = (size_t)per_block * n_blocks;
+  uint32_t np = per_block >> 1;           // parents of this block at the level being computed
+  int buf = 0;
+  bool first = true;
+  while (np >= 1) {
+    u64* nxt = cur + 4 * level_nodes;     // next level's base
+    const uint32_t j = (uint32_t)g < np ? (uint32_t)g : np - 1;   // idle groups shadow the last parent (results unused)
+    if ((uint32_t)(g & ~3) < np) {        // wave-uniform: its first group still has a parent at this level
+      u64 s = 0;
+      if (rr < 8) s = first ? cur[4 * ((size_t)b * 2 * np) + 8 * j + rr] : lvl[buf ^ 1][8 * j + rr];
+      s = coop::poseidon_permute_lat(s, lane, rc_lds);
+      if ((uint32_t)g < np && rr < 4) {
+        nxt[4 * ((size_t)b * np + j) + rr] = s;
+        lvl[buf][4 * j + rr] = s;
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+    level_nodes >>= 1;
+    np >>= 1;
+    buf ^= 1;
+    first = false;
+  }
+}
+
+// Levels with at most this many parents use the cooperative per-level kernel (above the fused top).  512 when many
+// proofs are in flight (the per-lane form costs several times fewer instructions and other streams hide its latency;
+// measured 4096 / 512 / 0: 122.3 / 123.0 / 122.8 proofs/s); a lone proof prefers 32768: at that size the per-lane
 // form leaves most SIMDs with one wave or none, and the level takes a full permutation latency.
 constexpr size_t COOP_PARENTS_BATCH = 512, COOP_PARENTS_SINGLE = 32768;
 
@@ -109,6 +152,27 @@ static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st, boo
   } else {
     hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, cur, nxt, m);
   }
+}
+// Levels from `cur` (m nodes) up to the cap: one launch per level while a cap entry has more than TOP_MAX_NODES
+// nodes under it, then the fused top.
+static u64* launch_levels_to_cap(u64* cur, size_t m, unsigned cap_height, hipStream_t st, bool single_proof) {
+  const size_t cap = (size_t)1 << cap_height;
+  while (m > cap) {
+    if (m / cap <= TOP_MAX_NODES && cap <= 65536) {
+      hipLaunchKernelGGL(k_tree_top_coop, dim3((unsigned)cap), dim3(TOP_GROUPS * coop::GROUP), 0, st, cur,
+                         (uint32_t)(m / cap), (uint32_t)cap);
+      while (m > cap) {
+        cur += 4 * m;
+        m >>= 1;
+      }
+      return cur;
+    }
+    u64* nxt = cur + 4 * m;
+    m >>= 1;
+    launch_level(cur, nxt, m, st, single_proof);
+    cur = nxt;
+  }
+  return cur;
 }
 
 // Shader clock under the hashing load (bench.py's VALU view prices instructions in cycles): every wave runs
@@ -195,27 +259,12 @@ u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t 
     hipLaunchKernelGGL(k_hash_leaves, dim3((unsigned)((n_leaves + 63) / 64)), dim3(64), 0, st, d_cols,
                        col_stride, width, n_leaves, d_tree);
   if (ev_end) (void)hipEventRecord(ev_end, st);
-  u64* cur = d_tree;
-  size_t m = n_leaves;
-  while (m > ((size_t)1 << cap_height)) {
-    u64* nxt = cur + 4 * m;
-    m >>= 1;
-    launch_level(cur, nxt, m, st, single_proof);
-    cur = nxt;
-  }
-  return cur;
+  return launch_levels_to_cap(d_tree, n_leaves, cap_height, st, single_proof);
 }
 
 // Same as launch_merkle_tree but the leaf digests (level 0) are already in d_tree.
 void launch_tree_from_digests(u64* d_tree, size_t n_leaves, unsigned cap_height, hipStream_t st, bool single_proof) {
-  u64* cur = d_tree;
-  size_t m = n_leaves;
-  while (m > ((size_t)1 << cap_height)) {
-    u64* nxt = cur + 4 * m;
-    m >>= 1;
-    launch_level(cur, nxt, m, st, single_proof);
-    cur = nxt;
-  }
+  launch_levels_to_cap(d_tree, n_leaves, cap_height, st, single_proof);
 }
 
 }  // namespace p25

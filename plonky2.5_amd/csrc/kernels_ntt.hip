@@ -24,6 +24,7 @@
 // where imap/tmap are the identity or a bit reversal.  All values are canonical field elements.
 #include <tuple>
 #include "kernels.h"
+#include "ntt16.h"
 
 namespace p25 {
 
@@ -55,11 +56,34 @@ __device__ __forceinline__ void dif_group(u64* col, const u64* wl, int step, int
   for (int k = 0; k < K; k++) col[k * step] = x[k];
 }
 
+// Four DIF stages s0..s0+3 of the length-R sub-transforms as a pure 16-point transform plus ONE twiddle per element:
+// the stage-by-stage factors w_R^(((k mod hk) << lstride + l) << (s0 + m)) of the radix-2 network split into the
+// 16th-root part (compile-time, above) and w_R^(l << (s0 + m)) on every difference branch, which accumulates to
+// w_R^((l * rev4(k')) << s0) at output k' -- 15 general multiplications per 16 elements instead of 32, none in the
+// last group of a sub-transform (l = 0).  `wl` holds w_R^e for e < R.
+template <bool INV>
+__device__ __forceinline__ void dif16_group(u64* col, const u64* wl, int step, int l, int s0) {
+  u64 x[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) x[k] = col[k * step];
+  dft16<INV>(x);
+  if (l != 0) {
+#pragma unroll
+    for (int k = 1; k < 16; k++) {
+      const int f = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
+      x[k] = gl::mul(x[k], wl[(l * f) << s0]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) col[k * step] = x[k];
+}
+
+template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
   extern __shared__ u64 lds[];
   const int R = 1 << a.log_r, T = 1 << a.log_t;
   const int TP = T > 1 ? T + 1 : 1;  // row padding: conflict-free for both access directions
-  u64* wl = lds + (size_t)R * TP;    // R/2 twiddles of the sub-transform
+  u64* wl = lds + (size_t)R * TP;    // twiddles of the sub-transform: w_R^e, e < R/2 (e < R with full_table)
   const u32 NT = 1u << a.log_nt;
   // Block -> (tile, polynomial, coset).  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.
   // With xcd_map the 1-D grid is decoded so that the n_cosets blocks reading the SAME coefficient tile run on the
@@ -84,7 +108,7 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
   const int tid = threadIdx.x, nth = blockDim.x;
   const int wstride_log = a.log_n_table - a.log_r;  // w_R^k = w_N^(k * N/R)
 
-  for (int k = tid; k < R / 2; k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
+  for (int k = tid; k < (a.full_table ? R : R / 2); k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
 
   // coset pre-scale: one table entry per input coefficient (shift_c^k at the coefficient's address k)
   const u64* pre = a.pre ? a.pre + ((size_t)coset << (a.log_r + a.log_nt)) : nullptr;
@@ -120,7 +144,12 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
       const int l = q & ((1 << lstride) - 1), h = q >> lstride;
       u64* col = lds + ((h << (a.log_r - s0)) + l) * TP + t;
       switch (g) {
-        case 4: dif_group<4>(col, wl, TP << lstride, l, lstride, s0); break;
+        case 4:
+          if (a.full_table)
+            dif16_group<INV>(col, wl, TP << lstride, l, s0);
+          else
+            dif_group<4>(col, wl, TP << lstride, l, lstride, s0);
+          break;
         case 3: dif_group<3>(col, wl, TP << lstride, l, lstride, s0); break;
         case 2: dif_group<2>(col, wl, TP << lstride, l, lstride, s0); break;
         default: dif_group<1>(col, wl, TP << lstride, l, lstride, s0); break;
@@ -158,13 +187,19 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
 void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st) {
   const int R = 1 << p.log_r, T = 1 << p.log_t;
   const int TP = T > 1 ? T + 1 : 1;
-  size_t lds = ((size_t)R * TP + R / 2) * sizeof(u64);
   NttPass q = p;
+  // the radix-16 groups index a full table of R twiddles; a 2^11-point sub-transform (2^22-point transforms) would
+  // not fit the 64 KB of LDS a block may take with it and keeps the half table and the radix-2 network
+  q.full_table = p.log_r <= 10;
+  size_t lds = ((size_t)R * TP + (q.full_table ? R : R / 2)) * sizeof(u64);
   q.n_tiles = 1u << (p.log_nt - p.log_t);
   q.n_cosets = (uint32_t)n_cosets;
   q.xcd_map = n_cosets > 1 && (q.n_tiles & 7u) == 0;
   dim3 grid = q.xcd_map ? dim3(q.n_tiles * (uint32_t)n_polys * (uint32_t)n_cosets) : dim3(q.n_tiles, n_polys, n_cosets);
-  hipLaunchKernelGGL(k_ntt_tile, grid, dim3(256), lds, st, q);
+  if (q.inverse)
+    hipLaunchKernelGGL(k_ntt_tile<true>, grid, dim3(256), lds, st, q);
+  else
+    hipLaunchKernelGGL(k_ntt_tile<false>, grid, dim3(256), lds, st, q);
 }
 
 static int pick_log_t(int log_r, int log_nt) {
@@ -240,6 +275,7 @@ void ntt_inverse(NttTables& tb, const u64* d_in, size_t in_stride, bool in_bitre
   NttPass p{};
   p.pow_table = pw;
   p.log_n_table = log_n;
+  p.inverse = 1;
   if (l1 == 0) {  // single pass
     p.in = d_in; p.out = d_out;
     p.in_poly_stride = in_stride; p.out_poly_stride = out_stride;
@@ -262,6 +298,7 @@ void ntt_inverse(NttTables& tb, const u64* d_in, size_t in_stride, bool in_bitre
   // pass 2: t = j2 (NT = R2), i = k1 (R = R1); output coefficient j2 + R2*j1, scaled
   NttPass q{};
   q.pow_table = pw; q.log_n_table = log_n;
+  q.inverse = 1;
   q.in = d_tmp; q.out = d_out;
   q.in_poly_stride = tmp_stride; q.out_poly_stride = out_stride;
   q.log_r = l1; q.log_nt = l2; q.log_t = pick_log_t(l1, l2);
