@@ -179,6 +179,22 @@ p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out);
  * another process.  export: pass buf = NULL to query the size. */
 p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out);
 p25_status p25_circuit_import(const uint8_t* blob, size_t len, p25_circuit** out);
+/* Upstream's own binary form of a built circuit: `CircuitData::to_bytes(&gate_serializer, &generator_serializer)` /
+ * `CircuitData::from_bytes` (plonky2 util/serialization, restated -- the crate is absent, unpinned like the proof
+ * formats; the reference's gate / generator payloads are its own `serialize` bodies: poseidon2_gate.rs:399-405,
+ * 529-539, arithmetic_u32.rs:287-300, 445-464, interleave_u32.rs:237-247, 340-360, uninterleave_to_u32.rs:272-283,
+ * 396-412).  Gate / generator tags = upstream's default serializer lists followed by the reference's types
+ * (INTEGRATION.md section 5a gives the `impl_gate_serializer!` / `impl_generator_serializer!` declarations).
+ * to_bytes needs the GPU (the constants/sigmas commitment -- LDE leaves, Merkle digests, cap, circuit digest -- is
+ * part of the data: ~600 MB for the fib-64 circuit); *bytes_out is malloc'ed, release it with p25_free.
+ * from_bytes: input_targets[n_inputs] = target indices of the per-proof inputs in the order the host passes their
+ * values (they are not part of CircuitData; p25_circuit_input_targets returns them for a circuit built here);
+ * digest4_out (nullable) receives the circuit digest stored in the bytes -- p25_circuit_digest recomputes it. */
+p25_status p25_circuit_to_bytes(p25_circuit* c, uint8_t** bytes_out, size_t* len_out);
+p25_status p25_circuit_from_bytes(const uint8_t* bytes, size_t len, const uint32_t* input_targets, size_t n_inputs,
+                                  uint64_t* digest4_out, p25_circuit** out);
+p25_status p25_circuit_input_targets(const p25_circuit* c, uint32_t* targets_out, size_t cap, size_t* n_out);
+void p25_free(void* p);
 void p25_circuit_destroy(p25_circuit* c);
 
 typedef struct {

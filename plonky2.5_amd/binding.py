@@ -122,6 +122,10 @@ EXPORTED_SYMBOLS = {
     "p25_last_error": (C.c_char_p, []),
     "p25_shader_clock_hz": (i32, [C.POINTER(C.c_double)]),
     "p25_circuit_set_streams": (i32, [vp, i32]),
+    "p25_circuit_to_bytes": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
+    "p25_circuit_from_bytes": (i32, [vp, sz, vp, sz, vp, C.POINTER(vp)]),
+    "p25_circuit_input_targets": (i32, [vp, vp, sz, C.POINTER(sz)]),
+    "p25_free": (None, [vp]),
     "p25_version": (C.c_char_p, []),
     "p25_device_init": (i32, [C.c_int]),
     "p25_poseidon_permute": (i32, [vp, sz]),
@@ -390,6 +394,32 @@ class Circuit:
         buf = np.frombuffer(blob, dtype=np.uint8)
         _check(lib().p25_circuit_import(_ptr(buf), buf.size, C.byref(h)))
         return cls(h.value)
+
+    def to_bytes(self):
+        """upstream CircuitData::to_bytes (needs the GPU: the constants/sigmas commitment is part of the data)."""
+        p, n = vp(), sz(0)
+        _check(lib().p25_circuit_to_bytes(self._h, C.byref(p), C.byref(n)))
+        try:
+            return C.string_at(p, n.value)
+        finally:
+            lib().p25_free(p)
+
+    def input_target_indices(self):
+        n = sz(0)
+        _check(lib().p25_circuit_input_targets(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        _check(lib().p25_circuit_input_targets(self._h, _ptr(out), out.size, C.byref(n)))
+        return out
+
+    @classmethod
+    def from_bytes(cls, data, input_targets):
+        """upstream CircuitData::from_bytes + the per-proof input targets.  Returns (circuit, stored circuit digest)."""
+        h = vp()
+        buf = np.frombuffer(data, dtype=np.uint8)
+        it = np.ascontiguousarray(input_targets, dtype=np.uint32)
+        dg = np.zeros(4, dtype=np.uint64)
+        _check(lib().p25_circuit_from_bytes(_ptr(buf), buf.size, _ptr(it), it.size, _ptr(dg), C.byref(h)))
+        return cls(h.value), dg
 
     def to_blob(self):
         n = sz(0)

@@ -466,6 +466,96 @@ struct Dsu {
 };
 }  // namespace
 
+// The witness generators a gate row contributes (upstream `Gate::generators(row, local_constants)`): one per
+// operation slot for the multi-op gates, one per row for the others, none for gates whose wires are set by explicit
+// generators (ConstantGate, PublicInputGate) or by nothing (NoopGate).  Wire layouts as in the gate files cited in
+// kernels_witgen.hip.  Shared by `build()` and by the reader of upstream's `CircuitData` bytes (circuit_bytes.cpp).
+int gate_generator_ops(GateKind k) {
+  switch (k) {
+    case G_BASE_SUM:
+    case G_EXPONENTIATION:
+    case G_POSEIDON:
+    case G_POSEIDON2:
+      return 1;
+    case G_ARITHMETIC:
+    case G_MUL_EXT:
+    case G_U32_ARITHMETIC:
+    case G_U32_INTERLEAVE:
+    case G_U32_UNINTERLEAVE:
+    case G_ARITH_EXT:
+      return gate_info(k).num_ops;
+    default:
+      return 0;
+  }
+}
+Generator gate_op_generator(GateKind kind, const u64 constants[2], int r, int i) {
+  Generator g;
+  switch (kind) {
+    case G_BASE_SUM:
+      g.kind = GEN_BASE_SPLIT;
+      g.deps = {wire(r, 0)};
+      for (int l = 0; l < BASE_SUM_LIMBS; l++) g.outs.push_back(wire(r, 1 + l));
+      break;
+    case G_ARITHMETIC:
+      g.kind = GEN_ARITHMETIC;
+      g.c0 = constants[0];
+      g.c1 = constants[1];
+      g.deps = {wire(r, 4 * i), wire(r, 4 * i + 1), wire(r, 4 * i + 2)};
+      g.outs = {wire(r, 4 * i + 3)};
+      break;
+    case G_MUL_EXT:
+      g.kind = GEN_MUL_EXT;
+      g.c0 = constants[0];
+      g.deps = {wire(r, 6 * i), wire(r, 6 * i + 1), wire(r, 6 * i + 2), wire(r, 6 * i + 3)};
+      g.outs = {wire(r, 6 * i + 4), wire(r, 6 * i + 5)};
+      break;
+    case G_EXPONENTIATION:
+      g.kind = GEN_EXPONENTIATION;
+      for (int k = 0; k <= EXP_POWER_BITS; k++) g.deps.push_back(wire(r, k));  // base, bits
+      for (int k = 0; k < EXP_POWER_BITS; k++) g.outs.push_back(wire(r, 2 + EXP_POWER_BITS + k));
+      g.outs.push_back(wire(r, 1 + EXP_POWER_BITS));
+      break;
+    case G_U32_ARITHMETIC:
+      g.kind = GEN_U32_ARITHMETIC;
+      g.deps = {wire(r, 6 * i), wire(r, 6 * i + 1), wire(r, 6 * i + 2)};
+      g.outs = {wire(r, 6 * i + 3), wire(r, 6 * i + 4), wire(r, 6 * i + 5)};
+      for (int j = 0; j < 32; j++) g.outs.push_back(wire(r, 18 + 32 * i + j));
+      break;
+    case G_U32_INTERLEAVE:
+      g.kind = GEN_U32_INTERLEAVE;
+      g.deps = {wire(r, 2 * i)};
+      for (int j = 0; j < 32; j++) g.outs.push_back(wire(r, 6 + 32 * i + j));
+      g.outs.push_back(wire(r, 2 * i + 1));
+      break;
+    case G_U32_UNINTERLEAVE:
+      g.kind = GEN_U32_UNINTERLEAVE;
+      g.deps = {wire(r, 3 * i)};
+      for (int j = 0; j < 64; j++) g.outs.push_back(wire(r, 6 + 64 * i + j));
+      g.outs.push_back(wire(r, 3 * i + 1));
+      g.outs.push_back(wire(r, 3 * i + 2));
+      break;
+    case G_ARITH_EXT:
+      g.kind = GEN_ARITH_EXT;
+      g.c0 = constants[0];
+      g.c1 = constants[1];
+      for (int k = 0; k < 6; k++) g.deps.push_back(wire(r, 8 * i + k));
+      g.outs = {wire(r, 8 * i + 6), wire(r, 8 * i + 7)};
+      break;
+    case G_POSEIDON:
+    case G_POSEIDON2:
+      g.kind = kind == G_POSEIDON ? GEN_POSEIDON : GEN_POSEIDON2;
+      for (int k = 0; k < 12; k++) g.deps.push_back(wire(r, k));
+      g.deps.push_back(wire(r, 24));
+      for (int k = 0; k < 4; k++) g.outs.push_back(wire(r, 25 + k));     // delta
+      for (int k = 0; k < 106; k++) g.outs.push_back(wire(r, 29 + k));   // S-box inputs
+      for (int k = 0; k < 12; k++) g.outs.push_back(wire(r, 12 + k));    // outputs
+      break;
+    default:
+      throw std::logic_error("gate_op_generator: gate without generators");
+  }
+  return g;
+}
+
 Circuit CircuitBuilder::build() {
   Circuit c;
   c.cfg = config;
@@ -633,106 +723,10 @@ Circuit CircuitBuilder::build() {
   c.generators = generators_;
   for (size_t row = 0; row < n; row++) {
     const GateInstance& gi = rows_[row];
-    int ops = gate_info(gi.kind).num_ops;
+    int ops = gate_generator_ops(gi.kind);
     auto it = incomplete.find((int)row);
-    if (it != incomplete.end()) ops = it->second;
-    const int r = (int)row;
-    switch (gi.kind) {
-      case G_BASE_SUM: {
-        Generator g;
-        g.kind = GEN_BASE_SPLIT;
-        g.deps = {wire(r, 0)};
-        for (int l = 0; l < BASE_SUM_LIMBS; l++) g.outs.push_back(wire(r, 1 + l));
-        c.generators.push_back(std::move(g));
-        break;
-      }
-      case G_ARITHMETIC:
-        for (int i = 0; i < ops; i++) {
-          Generator g;
-          g.kind = GEN_ARITHMETIC;
-          g.c0 = gi.constants[0];
-          g.c1 = gi.constants[1];
-          g.deps = {wire(r, 4 * i), wire(r, 4 * i + 1), wire(r, 4 * i + 2)};
-          g.outs = {wire(r, 4 * i + 3)};
-          c.generators.push_back(std::move(g));
-        }
-        break;
-      case G_MUL_EXT:
-        for (int i = 0; i < ops; i++) {
-          Generator g;
-          g.kind = GEN_MUL_EXT;
-          g.c0 = gi.constants[0];
-          g.deps = {wire(r, 6 * i), wire(r, 6 * i + 1), wire(r, 6 * i + 2), wire(r, 6 * i + 3)};
-          g.outs = {wire(r, 6 * i + 4), wire(r, 6 * i + 5)};
-          c.generators.push_back(std::move(g));
-        }
-        break;
-      case G_EXPONENTIATION: {
-        Generator g;
-        g.kind = GEN_EXPONENTIATION;
-        for (int i = 0; i <= EXP_POWER_BITS; i++) g.deps.push_back(wire(r, i));  // base, bits
-        for (int i = 0; i < EXP_POWER_BITS; i++) g.outs.push_back(wire(r, 2 + EXP_POWER_BITS + i));
-        g.outs.push_back(wire(r, 1 + EXP_POWER_BITS));
-        c.generators.push_back(std::move(g));
-        break;
-      }
-      case G_U32_ARITHMETIC:
-        for (int i = 0; i < ops; i++) {
-          Generator g;
-          g.kind = GEN_U32_ARITHMETIC;
-          g.deps = {wire(r, 6 * i), wire(r, 6 * i + 1), wire(r, 6 * i + 2)};
-          g.outs = {wire(r, 6 * i + 3), wire(r, 6 * i + 4), wire(r, 6 * i + 5)};
-          for (int j = 0; j < 32; j++) g.outs.push_back(wire(r, 18 + 32 * i + j));
-          c.generators.push_back(std::move(g));
-        }
-        break;
-      case G_U32_INTERLEAVE:
-        for (int i = 0; i < ops; i++) {
-          Generator g;
-          g.kind = GEN_U32_INTERLEAVE;
-          g.deps = {wire(r, 2 * i)};
-          for (int j = 0; j < 32; j++) g.outs.push_back(wire(r, 6 + 32 * i + j));
-          g.outs.push_back(wire(r, 2 * i + 1));
-          c.generators.push_back(std::move(g));
-        }
-        break;
-      case G_U32_UNINTERLEAVE:
-        for (int i = 0; i < ops; i++) {
-          Generator g;
-          g.kind = GEN_U32_UNINTERLEAVE;
-          g.deps = {wire(r, 3 * i)};
-          for (int j = 0; j < 64; j++) g.outs.push_back(wire(r, 6 + 64 * i + j));
-          g.outs.push_back(wire(r, 3 * i + 1));
-          g.outs.push_back(wire(r, 3 * i + 2));
-          c.generators.push_back(std::move(g));
-        }
-        break;
-      case G_ARITH_EXT:
-        for (int i = 0; i < ops; i++) {
-          Generator g;
-          g.kind = GEN_ARITH_EXT;
-          g.c0 = gi.constants[0];
-          g.c1 = gi.constants[1];
-          for (int k = 0; k < 6; k++) g.deps.push_back(wire(r, 8 * i + k));
-          g.outs = {wire(r, 8 * i + 6), wire(r, 8 * i + 7)};
-          c.generators.push_back(std::move(g));
-        }
-        break;
-      case G_POSEIDON:
-      case G_POSEIDON2: {
-        Generator g;
-        g.kind = gi.kind == G_POSEIDON ? GEN_POSEIDON : GEN_POSEIDON2;
-        for (int i = 0; i < 12; i++) g.deps.push_back(wire(r, i));
-        g.deps.push_back(wire(r, 24));
-        for (int i = 0; i < 4; i++) g.outs.push_back(wire(r, 25 + i));     // delta
-        for (int i = 0; i < 106; i++) g.outs.push_back(wire(r, 29 + i));   // S-box inputs
-        for (int i = 0; i < 12; i++) g.outs.push_back(wire(r, 12 + i));    // outputs
-        c.generators.push_back(std::move(g));
-        break;
-      }
-      default:
-        break;
-    }
+    if (it != incomplete.end() && ops > 1) ops = it->second;
+    for (int i = 0; i < ops; i++) c.generators.push_back(gate_op_generator(gi.kind, gi.constants, (int)row, i));
   }
   return c;
 }

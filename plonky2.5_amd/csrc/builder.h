@@ -109,6 +109,9 @@ struct GateInstance {
   u64 constants[2];
 };
 
+struct Generator;
+// witness generators of a gate row (upstream `Gate::generators`): count per row and the i-th one
+int gate_generator_ops(GateKind k);
 // Everything the prover needs about one circuit shape.
 struct Circuit {
   CircuitConfig cfg;
@@ -284,6 +287,7 @@ class CircuitBuilder {
   std::map<ExtArithKey, Ext> ext_arithmetic_results_;
 };
 
+Generator gate_op_generator(GateKind kind, const u64 constants[2], int row, int i);
 // FRI arity schedule (upstream FriReductionStrategy::ConstantArityBits)
 std::vector<int> fri_reduction_arity_bits(const CircuitConfig& cfg, int degree_bits);
 

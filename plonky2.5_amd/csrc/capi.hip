@@ -249,6 +249,7 @@ p25_status p25_lde_commit_dev(const uint64_t* d_polys, unsigned log_n, size_t n_
 // circuits, proving, data formats
 // ======================================================================================
 #include "circuit_io.h"
+#include "circuit_bytes.h"
 #include "json_io.h"
 #include "p3_circuit.h"
 #include "p3_prover.h"
@@ -424,6 +425,57 @@ p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, si
     if (buf) {
       if (cap < b.size()) throw std::invalid_argument("buffer too small");
       memcpy(buf, b.data(), b.size());
+    }
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_to_bytes(p25_circuit* c, uint8_t** bytes_out, size_t* len_out) {
+  return guarded([&]() -> p25_status {
+    if (!c || !bytes_out || !len_out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
+    p25::DeviceCircuit& d = c->device();   // the constants/sigmas commitment is computed on the GPU
+    std::vector<u64> coeffs, lde, tree;
+    d.commitment_to_host(coeffs, lde, tree);
+    p25::CircuitCommitment cm;
+    cm.coeffs = coeffs.data();
+    cm.lde = lde.data();
+    cm.tree = tree.data();
+    memcpy(cm.digest, d.digest(), 32);
+    std::vector<uint8_t> b = p25::circuit_data_to_bytes(d.circuit(), cm);
+    uint8_t* m = (uint8_t*)malloc(b.size() ? b.size() : 1);
+    if (!m) throw std::runtime_error("out of host memory");
+    memcpy(m, b.data(), b.size());
+    *bytes_out = m;
+    *len_out = b.size();
+    return P25_OK;
+  });
+}
+void p25_free(void* p) { free(p); }
+p25_status p25_circuit_from_bytes(const uint8_t* bytes, size_t len, const uint32_t* input_targets, size_t n_inputs,
+                                  uint64_t* digest4_out, p25_circuit** out) {
+  return host_guarded([&]() -> p25_status {
+    if (!bytes || !out || (!input_targets && n_inputs)) throw std::invalid_argument("null argument");
+    auto* h = new p25_circuit();
+    try {
+      u64 dg[4];
+      h->circuit = p25::circuit_data_from_bytes(bytes, len, input_targets, n_inputs, dg);
+      if (digest4_out) memcpy(digest4_out, dg, 32);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_input_targets(const p25_circuit* c, uint32_t* targets_out, size_t cap, size_t* n_out) {
+  return host_guarded([&]() -> p25_status {
+    if (!c || !n_out) throw std::invalid_argument("null argument");
+    const p25::Circuit& k = c->c();
+    *n_out = k.input_targets.size();
+    if (targets_out) {
+      if (cap < k.input_targets.size()) throw std::invalid_argument("buffer too small");
+      for (size_t i = 0; i < k.input_targets.size(); i++) targets_out[i] = (uint32_t)k.target_index(k.input_targets[i]);
     }
     return P25_OK;
   });

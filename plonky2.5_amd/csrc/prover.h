@@ -68,6 +68,9 @@ class DeviceCircuit {
   const ProofLayout& layout() const { return layout_; }
   const u64* digest() const { return digest_; }                 // host copy [4]
   const std::vector<u64>& cs_cap() const { return cs_cap_; }    // host copy
+  // host copies of the constants/sigmas commitment (coefficients, LDE in leaf order, Merkle tree) for
+  // CircuitData::to_bytes (circuit_bytes.h)
+  void commitment_to_host(std::vector<u64>& coeffs, std::vector<u64>& lde, std::vector<u64>& tree);
   size_t n() const { return c_.degree(); }
   size_t big() const { return c_.degree() << c_.cfg.rate_bits; }
 

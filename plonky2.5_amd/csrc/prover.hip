@@ -318,6 +318,16 @@ DeviceCircuit::~DeviceCircuit() {
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
+void DeviceCircuit::commitment_to_host(std::vector<u64>& coeffs, std::vector<u64>& lde, std::vector<u64>& tree) {
+  sync();
+  coeffs.resize(cs_coeffs_.words);
+  lde.resize(cs_lde_.words);
+  tree.resize(cs_tree_.words);
+  P25_HIP(hipMemcpy(coeffs.data(), cs_coeffs_.p, coeffs.size() * 8, hipMemcpyDeviceToHost));
+  P25_HIP(hipMemcpy(lde.data(), cs_lde_.p, lde.size() * 8, hipMemcpyDeviceToHost));
+  P25_HIP(hipMemcpy(tree.data(), cs_tree_.p, tree.size() * 8, hipMemcpyDeviceToHost));
+}
+
 void DeviceCircuit::ensure_ctx(size_t count) {
   for (auto& e : ev_witness_)
     if (!e) P25_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

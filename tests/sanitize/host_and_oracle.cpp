@@ -7,6 +7,8 @@
 #include <vector>
 #include "builder.h"
 #include "circuit_io.h"
+#include "circuit_bytes.h"
+#include "ref_fft.h"
 #include "p3_circuit.h"
 #include "p3_prover.h"
 #include "witness_program.h"
@@ -83,6 +85,56 @@ int main() {
     }
     printf("blob fuzz: %d rejected, %d accepted\n", rejected, accepted);
     CHECK(rejected > 50);
+  }
+  // upstream's binary circuit form (circuit_bytes.cpp): write -> read gives the circuit back; truncation and bit
+  // flips are rejected or parse to something the witness scheduler can walk (the commitment part -- LDE leaves,
+  // Merkle digests -- is opaque to the reader, so placeholders of the right size stand in for the device's tables)
+  {
+    CircuitBuilder cbb;
+    P3ProveParams ps;
+    ps.log_n = 3; ps.num_queries = 2; ps.pow_bits = 4; ps.threads = 1;
+    P3Config cf;
+    p3_prove_fibonacci(ps, cf);
+    p3_verify_proof(cbb, cf, fib);
+    Circuit small = cbb.build();
+    const size_t n = small.degree(), big = n << small.cfg.rate_bits, ncs = small.constants_sigmas.size();
+    std::vector<u64> coeffs(ncs * n), lde(ncs * big, 1), tree(8 * big, 2);
+    for (size_t p = 0; p < ncs; p++) {
+      std::vector<u64> v = small.constants_sigmas[p];
+      ref_ifft(v);
+      std::copy(v.begin(), v.end(), coeffs.begin() + p * n);
+    }
+    CircuitCommitment cm;
+    cm.coeffs = coeffs.data(); cm.lde = lde.data(); cm.tree = tree.data();
+    for (int i = 0; i < 4; i++) cm.digest[i] = 1000 + i;
+    std::vector<uint8_t> bytes = circuit_data_to_bytes(small, cm);
+    std::vector<uint32_t> in_idx;
+    for (auto& t : small.input_targets) in_idx.push_back((uint32_t)small.target_index(t));
+    u64 dg[4];
+    Circuit back = circuit_data_from_bytes(bytes.data(), bytes.size(), in_idx.data(), in_idx.size(), dg);
+    CHECK(circuit_to_blob(back) == circuit_to_blob(small) && dg[3] == 1003);
+    u64 rng = 0x243F6A8885A308D3ull;
+    auto next = [&] { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    int rejected = 0, accepted = 0;
+    for (int trial = 0; trial < 60; trial++) {
+      std::vector<uint8_t> m(bytes);
+      if (trial % 3 == 0) {
+        m.resize(next() % m.size());
+      } else {
+        const size_t span = trial % 3 == 1 ? 4096 : m.size();
+        for (int f = 0; f < 1 + (int)(next() % 3); f++) m[next() % span] ^= (uint8_t)(1u << (next() % 8));
+      }
+      try {
+        Circuit cm2 = circuit_data_from_bytes(m.data(), m.size(), in_idx.data(), in_idx.size(), dg);
+        WitnessProgram wpm = build_witness_program(cm2);
+        CHECK(wpm.input_slots.size() == cm2.input_targets.size());
+        accepted++;
+      } catch (const std::exception&) {
+        rejected++;
+      }
+    }
+    printf("CircuitData bytes fuzz: %d rejected, %d accepted\n", rejected, accepted);
+    CHECK(rejected > 20);
   }
   // oracle on a small verifier circuit
   prm.log_n = 3; prm.num_queries = 3; prm.pow_bits = 4;

@@ -18,7 +18,7 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
     ora = os.path.join(ROOT, "oracle")
     srcs = [os.path.join(ROOT, "tests", "sanitize", "host_and_oracle.cpp")]
     srcs += [os.path.join(csrc, f) for f in ("builder.cpp", "p3_circuit.cpp", "p3_prover.cpp", "circuit_io.cpp",
-                                             "witness_program.cpp", "recursion.cpp")]
+                                             "circuit_bytes.cpp", "witness_program.cpp", "recursion.cpp")]
     srcs += sorted(glob.glob(os.path.join(ora, "*.cpp")))
     exe = str(tmp_path / "san")
     flags = ["-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
