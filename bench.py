@@ -113,14 +113,16 @@ def cpu_model():
 
 def aggregation_tree(p25, circuit, leaves, verify_root):
     """North star's "final aggregation step" taken literally: fold `leaves` (flat proofs of `circuit`, a power of two)
-    into ONE root proof with 2-to-1 recursive verifier circuits (upstream builder.verify_proof), every level a plain
-    batch prove on the GPU.  Returns the per-level record; the root is checked by `verify_root(circuit, proof)`."""
+    into ONE root proof with 2-to-1 aggregation circuits (upstream builder.verify_proof for both children + four
+    registered public inputs committing to them), every level a plain batch prove on the GPU.  Returns the per-level
+    record; the root is checked by `verify_root(circuit, proof)` and its public inputs -- the root of a Poseidon tree
+    over hash_no_pad(wires cap) of every leaf proof -- are recomputed from the leaves by the caller."""
     import numpy as np
     level, circ, levels, tree_s, build_s = leaves, circuit, [], 0.0, 0.0
     owned = []
     while len(level) > 1:
         t = time.perf_counter()
-        nxt = circ.build_recursive_verifier(2)
+        nxt = circ.build_aggregator(2)    # a recursive verifier that registers a 4-word commitment to its two proofs
         nxt.digest()
         bs = time.perf_counter() - t
         build_s += bs
@@ -137,9 +139,10 @@ def aggregation_tree(p25, circuit, leaves, verify_root):
                        "prove_s": round(dt, 4), "circuit_build_s": round(bs, 2)})
         circ = nxt
     ok = verify_root(circ, level[0])
+    root_pis = [int(v) for v in circ.public_inputs(level[0])]
     for c in owned:
         c.close()
-    return {"levels": levels, "tree_prove_s": round(tree_s, 4), "tree_circuit_build_s_once_per_shape": round(build_s, 2),
+    return {"levels": levels, "root_public_inputs": root_pis, "tree_prove_s": round(tree_s, 4), "tree_circuit_build_s_once_per_shape": round(build_s, 2),
             "root_proof_words": int(level[0].size), "oracle_verifier_accepts_root": bool(ok)}
 
 
@@ -516,10 +519,16 @@ def main():
             try:
                 agg = aggregation_tree(p25, circuit, all_p[:n_agg], verify_with_oracle)
                 leaf_s = n_agg / (total_proofs / elapsed)   # the leaves at the measured whole-job rate
+                # the root's public inputs must be the Poseidon tree over hash_no_pad(wires cap) of the leaves
+                lvl = [ora.hash_no_pad(all_p[i][:4 << 4]) for i in range(n_agg)]
+                while len(lvl) > 1:
+                    lvl = [ora.hash_no_pad(np.concatenate([lvl[2 * i], lvl[2 * i + 1]])) for i in range(len(lvl) // 2)]
+                agg["root_public_inputs_commit_to_the_leaves"] = [int(v) for v in lvl[0]] == agg["root_public_inputs"]
                 agg.update({"leaves": n_agg, "leaf_prove_s_at_measured_rate": round(leaf_s, 4),
                             "leaf_equivalent_proofs_per_s_including_aggregation": round(n_agg / (leaf_s + agg["tree_prove_s"]), 2),
                             "note": "leaves = the first proofs of the last timed step (gathered ones when N > 1); tree on rank 0's "
-                                    "GPU; every level is a 2-to-1 recursive verifier circuit proved as a batch; circuit builds are "
+                                    "GPU; every level is a 2-to-1 aggregation circuit (recursive verifier of both children + 4 public inputs "
+                                    "committing to them) proved as a batch; circuit builds are "
                                     "once per shape and excluded like the reference's build()"})
                 out["aggregation"] = agg
             except Exception as e:  # never lose the headline line to the optional block

@@ -151,6 +151,8 @@ p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t l
  *   F_p^2 and the expected result of ((5*((a*b+c)*a-b)+(3+9X))^7 / c + a + b + a0*b
  * 10 Poseidon (v1) in-circuit: hash_or_noop of `param` words, then one Merkle step `permute_swapped([h, sibling, 0],
  *   bit)` on a PoseidonGate; inputs = leaf words, sibling[4], bit, expected parent[4].
+ * 11 public inputs (upstream `register_public_input(s)`): `param` inputs x_i; the circuit registers every x_i and the
+ *   running products x_0 x_1, x_0 x_1 x_2, ... as public inputs (2 * param - 1 in all).
  * Inputs = operands followed by the expected result(s); a wrong expectation fails the proof with
  * P25_ERR_WITNESS_CONFLICT, as the failing `connect` panics upstream. */
 p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** out);
@@ -174,6 +176,13 @@ p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64
  * 3 BaseSum 4 U32Interleave 5 UninterleaveToU32 6 Arithmetic 7 MulExtension 8 Exponentiation 9 U32Arithmetic
  * 10 Poseidon2 11 ArithmeticExtension 12 Poseidon (the `kind` numbering of the circuit blob). */
 p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out);
+/* p25_circuit_build_recursive_verifier whose circuit also REGISTERS FOUR PUBLIC INPUTS (upstream
+ * `builder.register_public_inputs`): hash_no_pad over the identifiers of the proofs it verifies, a proof's identifier
+ * being its own public inputs when it has any (an aggregate further down the tree) and hash_no_pad(its wires cap)
+ * otherwise (a leaf).  Stacked 2-to-1 aggregators expose the root of a Poseidon tree over the batch: the "final
+ * aggregation step" of BASELINE.json leaves one proof whose public inputs commit to every leaf proof. */
+p25_status p25_circuit_build_aggregator(p25_circuit* inner, const uint64_t* digest4, const uint64_t* cs_cap,
+                                        int32_t n_proofs, p25_circuit** out);
 
 /* Circuit blob (format: plonky2.5_amd/csrc/circuit_io.h): persist a built circuit / hand it to
  * another process.  export: pass buf = NULL to query the size. */
@@ -204,6 +213,7 @@ typedef struct {
   /* sizes of the stage entry points' outputs: p25_partial_products writes num_challenges * (1 + num_partial_products)
    * rows, p25_quotient num_challenges * quotient_degree_factor rows, of 2^degree_bits words each */
   uint64_t num_challenges, num_partial_products, quotient_degree_factor;
+  uint64_t num_public_inputs;   /* registered public inputs: the last num_public_inputs words of a flat proof */
 } p25_circuit_info_t;
 p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out);
 /* Rows per gate type, in sorted-gate order; ids_out receives up to cap gate-id strings joined by '\n'. */
@@ -233,7 +243,12 @@ p25_status p25_circuit_digest(p25_circuit* c, uint64_t* digest4, uint64_t* const
  *   commit_phase_merkle_caps CAP[3] |
  *   query_round_proofs[28]: for each of the 4 oracles {leaf row u64[width], siblings H[15]};
  *                           for each FRI layer {evals E[16], siblings H[11,7,3]} |
- *   final_poly E[16] | pow_witness u64           (sizes shown for the fib-64 circuit; total 19,861 words)
+ *   final_poly E[16] | pow_witness u64 | public_inputs u64[num_public_inputs]
+ *                                                (sizes shown for the fib-64 circuit, which has no public inputs;
+ *                                                 total 19,861 words)
+ * Public inputs (upstream ProofWithPublicInputs::public_inputs): the values of the targets the circuit registered,
+ * read from the witness; their Poseidon hash_no_pad is what the PublicInputGate row holds, what every gate
+ * evaluator receives as `public_inputs_hash`, and what the transcript absorbs after the circuit digest.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   float witness_ms, wires_commit_ms, partial_products_ms, zs_commit_ms, quotient_ms, quotient_commit_ms,

@@ -120,7 +120,11 @@ long p25o_check_constraints(void* h, const u64* wires, char* msg, size_t msglen)
   const size_t n = c.n();
   long bad = 0;
   std::vector<FB> w(c.num_wires), out(c.num_gate_constraints + 8);
+  // public-inputs hash: what the PublicInputGate row of this witness holds (that it IS the hash of the registered
+  // inputs is enforced by the hashing rows behind it and checked by the prover / verifier pair)
   FB pih[4] = {FB{0}, FB{0}, FB{0}, FB{0}};
+  if (c.pi_row >= 0)
+    for (int i = 0; i < 4; i++) pih[i] = FB{wires[(size_t)i * n + (size_t)c.pi_row]};
   for (size_t row = 0; row < n; row++) {
     for (int col = 0; col < c.num_wires; col++) w[col] = FB{wires[(size_t)col * n + row]};
     FB k[2] = {FB{c.constants_sigmas[c.num_selectors][row]}, FB{c.constants_sigmas[c.num_selectors + 1][row]}};
@@ -251,7 +255,11 @@ void p25o_quotient(void* h, const u64* wires, const u64* zs_pp, const u64* betas
   RPolyBatch wb = ref_commit_values(w, c.rate_bits, c.cap_height), zb = ref_commit_values(z, c.rate_bits, c.cap_height);
   std::vector<u64> b(betas, betas + c.num_challenges), g(gammas, gammas + c.num_challenges),
       a(alphas, alphas + c.num_challenges);
-  auto q = ref_quotient_chunks(c, oc->pre->constants_sigmas, wb, zb, b, g, a);
+  // the public-inputs hash the PublicInputGate compares with: what that row of the given witness holds
+  u64 pih[4] = {0, 0, 0, 0};
+  if (c.pi_row >= 0)
+    for (int i = 0; i < 4; i++) pih[i] = wires[(size_t)i * n + (size_t)c.pi_row];
+  auto q = ref_quotient_chunks(c, oc->pre->constants_sigmas, wb, zb, b, g, a, pih);
   for (size_t k = 0; k < q.size(); k++) memcpy(out + k * n, q[k].data(), n * 8);
 }
 // coeffs[n_polys][n] at the extension point point*scale (Horner) -> out[n_polys][2]   (upstream PolynomialCoeffs::eval)

@@ -18,12 +18,12 @@ struct Rd {
   void a32(u32* out, size_t n) {
     size_t bytes = (n * 4 + 7) & ~(size_t)7;
     if (off + bytes > len) throw std::runtime_error("blob truncated");
-    memcpy(out, p + off, n * 4);
+    if (n) memcpy(out, p + off, n * 4);
     off += bytes;
   }
   void a64(u64* out, size_t n) {
     if (off + 8 * n > len) throw std::runtime_error("blob truncated");
-    memcpy(out, p + off, 8 * n);
+    if (n) memcpy(out, p + off, 8 * n);
     off += 8 * n;
   }
 };
@@ -69,6 +69,11 @@ RCircuit ref_circuit_parse(const unsigned char* blob, size_t len) {
     c.gen_args.resize(g.arg_off + g.n_deps + g.n_outs);
     r.a32(c.gen_args.data() + g.arg_off, g.n_deps + g.n_outs);
   }
+  if (h[22] > 4096) throw std::runtime_error("too many public inputs");
+  c.public_inputs.resize(h[22]);   // header word 22: registered public inputs, listed after the generator table
+  r.a32(c.public_inputs.data(), c.public_inputs.size());
+  for (u32 t : c.public_inputs)
+    if (t >= c.num_targets()) throw std::runtime_error("public-input target out of range");
   return c;
 }
 
@@ -331,5 +336,6 @@ RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 se
       u32 t = (u32)(row * c.num_wires + col);
       if (w.has(t)) res.wires[col][row] = w.get(t);
     }
+  for (u32 t : c.public_inputs) res.public_inputs.push_back(w.has(t) ? w.get(t) : 0);
   return res;
 }

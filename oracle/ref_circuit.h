@@ -43,6 +43,7 @@ struct RCircuit {
   std::vector<std::vector<u64>> constants_sigmas;  // selectors | constants | sigmas
   std::vector<u64> k_is;
   std::vector<u32> input_targets, rep;
+  std::vector<u32> public_inputs;               // target index of every registered public input (blob field 10)
   std::vector<RGenerator> gens;
   std::vector<u32> gen_args;
   size_t n() const { return (size_t)1 << degree_bits; }
@@ -59,6 +60,7 @@ struct RWitnessResult {
   int status;             // 0 ok, 4 conflict ("set twice with different values"), 5 generators not run
   std::string message;
   std::vector<std::vector<u64>> wires;  // [num_wires][n]  (full_witness: unset wires are 0)
+  std::vector<u64> public_inputs;       // upstream `partition_witness.get_targets(&prover_data.public_inputs)`
 };
 RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed, const u64* filler = nullptr);
 u64 ref_random_fill(u64 seed, u64 k);

@@ -245,6 +245,7 @@ size_t ref_proof_words(const RCircuit& c) {
   }
   total += per_q * c.num_queries;
   total += 2 * (size_t)final_poly_len(c) + 1;
+  total += c.public_inputs.size();
   return total;
 }
 std::vector<u64> ref_proof_flatten(const RCircuit& c, const RProof& p) {
@@ -273,6 +274,7 @@ std::vector<u64> ref_proof_flatten(const RCircuit& c, const RProof& p) {
   }
   exts(p.final_poly);
   o.push_back(p.pow_witness);
+  o.insert(o.end(), p.public_inputs.begin(), p.public_inputs.end());
   return o;
 }
 RProof ref_proof_unflatten(const RCircuit& c, const u64* w) {
@@ -322,6 +324,7 @@ RProof ref_proof_unflatten(const RCircuit& c, const u64* w) {
   }
   exts(p.final_poly, final_poly_len(c));
   p.pow_witness = w[off++];
+  p.public_inputs.assign(w + off, w + off + c.public_inputs.size());
   return p;
 }
 
@@ -418,13 +421,12 @@ std::vector<std::vector<u64>> ref_partial_products(const RCircuit& c, const std:
 std::vector<std::vector<u64>> ref_quotient_chunks(const RCircuit& c, const RPolyBatch& constants_sigmas,
                                                   const RPolyBatch& wires, const RPolyBatch& zs_batch,
                                                   const std::vector<u64>& betas, const std::vector<u64>& gammas,
-                                                  const std::vector<u64>& alphas) {
+                                                  const std::vector<u64>& alphas, const u64* pih) {
   const size_t n = c.n();
   const int NC = c.num_challenges, RW = c.num_routed, NP = c.num_partial_products, Q = c.quotient_degree_factor;
   const int lde_bits = c.degree_bits + c.rate_bits;
   const size_t big = (size_t)1 << lde_bits;
   const int n_consts = c.num_constants_total();
-  const u64 pih[4] = {0, 0, 0, 0};
   struct { const RPolyBatch& constants_sigmas; } pre{constants_sigmas};
   std::vector<std::vector<u64>> qvals(NC, std::vector<u64>(big));
   {
@@ -581,14 +583,17 @@ int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64
     return wr.status;
   }
   T.witness = now_s() - t0; t0 = now_s();
-  const u64 pih[4] = {0, 0, 0, 0};  // hash_no_pad([]) : no public inputs (src/p3/mod.rs:264 prints [])
+  // "let public_inputs_hash = C::InnerHasher::hash_no_pad(&public_inputs)" (upstream prover.rs); of the empty list
+  // (the fib-64 circuit: src/p3/mod.rs:264 prints []) it is four zeros
+  const RHash pi_hash = ref_hash_no_pad(wr.public_inputs.data(), wr.public_inputs.size());
+  const u64* pih = pi_hash.e;
 
   RPolyBatch wires = ref_commit_values(wr.wires, c.rate_bits, c.cap_height);
   T.wires_commit = now_s() - t0; t0 = now_s();
 
   RChallenger ch;
   ch.observe_hash(pre.circuit_digest);
-  ch.observe_hash(RHash{{pih[0], pih[1], pih[2], pih[3]}});
+  ch.observe_hash(pi_hash);
   ch.observe_cap(wires.tree.cap());
   std::vector<u64> betas(NC), gammas(NC);
   for (auto& b : betas) b = ch.challenge();
@@ -602,7 +607,7 @@ int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64
   std::vector<u64> alphas(NC);
   for (auto& a : alphas) a = ch.challenge();
 
-  std::vector<std::vector<u64>> qchunks = ref_quotient_chunks(c, pre.constants_sigmas, wires, zs_batch, betas, gammas, alphas);
+  std::vector<std::vector<u64>> qchunks = ref_quotient_chunks(c, pre.constants_sigmas, wires, zs_batch, betas, gammas, alphas, pih);
   T.quotient = now_s() - t0; t0 = now_s();
   RPolyBatch quot = ref_commit_coeffs(qchunks, c.rate_bits, c.cap_height);
   T.quotient_commit = now_s() - t0; t0 = now_s();
@@ -625,6 +630,7 @@ int ref_prove(const RCircuit& c, const RPrecomputed& pre, const u64* inputs, u64
     });
   }
   out = RProof();
+  out.public_inputs = wr.public_inputs;
   out.wires_cap = wires.tree.cap();
   out.zs_cap = zs_batch.tree.cap();
   out.quotient_cap = quot.tree.cap();
@@ -707,10 +713,12 @@ int ref_verify(const RCircuit& c, const RHash& circuit_digest, const std::vector
   const int NC = c.num_challenges, NP = c.num_partial_products, Q = c.quotient_degree_factor;
   const int lde_bits = c.degree_bits + c.rate_bits;
   const size_t big = (size_t)1 << lde_bits;
-  const u64 pih[4] = {0, 0, 0, 0};
+  if (p.public_inputs.size() != c.public_inputs.size()) return fail(1, "wrong number of public inputs");
+  const RHash pi_hash = ref_hash_no_pad(p.public_inputs.data(), p.public_inputs.size());
+  const u64* pih = pi_hash.e;
   RChallenger ch;
   ch.observe_hash(circuit_digest);
-  ch.observe_hash(RHash{{0, 0, 0, 0}});
+  ch.observe_hash(pi_hash);
   ch.observe_cap(p.wires_cap);
   std::vector<u64> betas(NC), gammas(NC), alphas(NC);
   for (auto& b : betas) b = ch.challenge();

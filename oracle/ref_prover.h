@@ -46,6 +46,7 @@ struct RProof {
   std::vector<Query> queries;
   std::vector<RE2> final_poly;
   u64 pow_witness = 0;
+  std::vector<u64> public_inputs;   // ProofWithPublicInputs::public_inputs
 };
 struct RTimings {
   double witness = 0, wires_commit = 0, zs = 0, zs_commit = 0, quotient = 0, quotient_commit = 0, openings = 0,
@@ -63,7 +64,7 @@ std::vector<std::vector<u64>> ref_partial_products(const RCircuit& c, const std:
 std::vector<std::vector<u64>> ref_quotient_chunks(const RCircuit& c, const RPolyBatch& constants_sigmas,
                                                   const RPolyBatch& wires, const RPolyBatch& zs_batch,
                                                   const std::vector<u64>& betas, const std::vector<u64>& gammas,
-                                                  const std::vector<u64>& alphas);
+                                                  const std::vector<u64>& alphas, const u64* pih /*public-inputs hash [4]*/);
 struct RFriParams {
   int degree_bits, rate_bits, cap_height;
   std::vector<int> arity_bits;

@@ -103,7 +103,8 @@ class CircuitInfo(C.Structure):
                                           "num_inputs", "num_generators", "num_gate_types", "num_selectors",
                                           "num_constants_sigmas", "num_gate_constraints", "proof_words",
                                           "witness_levels", "witness_slots", "num_random_fill",
-                                          "num_challenges", "num_partial_products", "quotient_degree_factor")]
+                                          "num_challenges", "num_partial_products", "quotient_degree_factor",
+                                          "num_public_inputs")]
 
 
 class Timings(C.Structure):
@@ -122,6 +123,7 @@ EXPORTED_SYMBOLS = {
     "p25_last_error": (C.c_char_p, []),
     "p25_shader_clock_hz": (i32, [C.POINTER(C.c_double)]),
     "p25_circuit_set_streams": (i32, [vp, i32]),
+    "p25_circuit_build_aggregator": (i32, [vp, vp, vp, i32, C.POINTER(vp)]),
     "p25_circuit_to_bytes": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
     "p25_circuit_from_bytes": (i32, [vp, sz, vp, sz, vp, C.POINTER(vp)]),
     "p25_circuit_input_targets": (i32, [vp, vp, sz, C.POINTER(sz)]),
@@ -387,6 +389,20 @@ class Circuit:
         cap = _u64(cs_cap) if cs_cap is not None else None
         _check(lib().p25_circuit_build_recursive_verifier(self._h, _ptr(d), _ptr(cap), n_proofs, C.byref(h)))
         return Circuit(h.value)
+
+    def build_aggregator(self, n_proofs=2, digest=None, cs_cap=None):
+        """build_recursive_verifier whose circuit registers 4 public inputs committing to the proofs it verifies."""
+        h = vp()
+        d = _u64(digest) if digest is not None else None
+        cap = _u64(cs_cap) if cs_cap is not None else None
+        _check(lib().p25_circuit_build_aggregator(self._h, _ptr(d), _ptr(cap), n_proofs, C.byref(h)))
+        return Circuit(h.value)
+
+    def public_inputs(self, proof):
+        """The public inputs of a flat proof (its last num_public_inputs words)."""
+        n = int(self.info.num_public_inputs)
+        p = _u64(proof)
+        return p[p.size - n:].copy() if n else np.zeros(0, dtype=np.uint64)
 
     @classmethod
     def from_blob(cls, blob):

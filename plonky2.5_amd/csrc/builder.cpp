@@ -561,11 +561,13 @@ Circuit CircuitBuilder::build() {
   c.cfg = config;
   const int W = config.num_wires, RW = config.num_routed_wires;
 
-  // public-inputs hash of [] = 4 zeros routed to a PublicInputGate; the gate's unused wires get
-  // RandomValueGenerators (upstream randomize_unused_pi_wires)
-  Target z = zero();
+  // "Hash the public inputs, and route them to a PublicInputGate which will enforce that they hash to the expected
+  // value" (upstream build()): hash_n_to_hash_no_pad of the registered targets on PoseidonGate rows -- of [] it is 4
+  // zeros and costs no row; the gate's unused wires get RandomValueGenerators (upstream randomize_unused_pi_wires)
+  c.public_inputs = public_inputs_;
+  std::array<Target, 4> pi_hash = hash_n_to_hash_no_pad(public_inputs_);
   int pi_gate = add_gate(G_PUBLIC_INPUT);
-  for (int i = 0; i < 4; i++) connect(z, wire(pi_gate, i));
+  for (int i = 0; i < 4; i++) connect(pi_hash[i], wire(pi_gate, i));
   for (int w = 4; w < W; w++) {
     Generator g;
     g.kind = GEN_RANDOM;

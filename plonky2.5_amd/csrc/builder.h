@@ -75,6 +75,7 @@ const GateInfo& gate_info(GateKind k);
 constexpr int ALPHA_POWS = 192;   // alpha-power table of the quotient kernel: max constraints per gate
 constexpr int MAX_ROUTED = 128;   // routed wires the permutation argument kernels hold
 constexpr int MAX_CHUNKS = 16;    // partial-product chunks per challenge (num_partial_products + 1) they hold per row
+constexpr int MAX_PUBLIC_INPUTS = 4096;  // public inputs a circuit may register (hashed by one wave per proof)
 constexpr int BASE_SUM_LIMBS = 63;
 constexpr int EXP_POWER_BITS = 66;
 
@@ -139,6 +140,9 @@ struct Circuit {
   }
   size_t num_targets() const { return degree() * cfg.num_wires + num_virtual_targets; }
   int pi_row = -1;
+  // upstream `builder.register_public_input`: targets whose values the proof exposes (ProofWithPublicInputs::public_inputs);
+  // their Poseidon hash is what the PublicInputGate row holds and what the transcript absorbs after the circuit digest
+  std::vector<Target> public_inputs;
   // statistics
   std::map<std::string, size_t> gate_counts() const;
 };
@@ -165,6 +169,9 @@ class CircuitBuilder {
   int add_gate(GateKind k, u64 c0 = 0, u64 c1 = 0);
   std::pair<int, int> find_slot(GateKind k, int n_params, u64 p0, u64 p1);
   void add_generator(Generator g) { generators_.push_back(std::move(g)); }
+  // upstream circuit_builder.rs `register_public_input(s)`
+  void register_public_input(Target t) { public_inputs_.push_back(t); }
+  void register_public_inputs(const std::vector<Target>& ts) { public_inputs_.insert(public_inputs_.end(), ts.begin(), ts.end()); }
   size_t num_gates() const { return rows_.size(); }
 
   // ---- base arithmetic (upstream gadgets/arithmetic.rs) ----
@@ -274,6 +281,7 @@ class CircuitBuilder {
   std::map<std::tuple<int, u64, u64, int>, std::pair<int, int>> current_slots_;
   std::vector<ConstGen> constant_generators_;
   std::vector<Generator> generators_;
+  std::vector<Target> public_inputs_;
   std::map<std::array<Target, 4>, Ext> mul_ext_memo_;
   struct ExtArithKey {
     u64 c0, c1;

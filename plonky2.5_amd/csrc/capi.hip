@@ -384,8 +384,8 @@ p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out) {
     return P25_OK;
   });
 }
-p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64_t* digest4, const uint64_t* cs_cap,
-                                                int32_t n_proofs, p25_circuit** out) {
+static p25_status build_recursive(p25_circuit* inner, const uint64_t* digest4, const uint64_t* cs_cap, int32_t n_proofs,
+                                  bool expose_commitment, p25_circuit** out) {
   auto body = [&]() -> p25_status {
     if (!inner || !out) throw std::invalid_argument("null argument");
     if ((digest4 == nullptr) != (cs_cap == nullptr)) throw std::invalid_argument("pass both digest4 and cs_cap, or neither");
@@ -406,7 +406,7 @@ p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64
     }
     auto* h = new p25_circuit();
     try {
-      h->circuit = p25::build_recursive_verifier(inner->c(), dg, cap, n_proofs);
+      h->circuit = p25::build_recursive_verifier(inner->c(), dg, cap, n_proofs, expose_commitment);
     } catch (...) {
       delete h;
       throw;
@@ -415,6 +415,14 @@ p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64
     return P25_OK;
   };
   return digest4 ? host_guarded(body) : guarded(body);
+}
+p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64_t* digest4, const uint64_t* cs_cap,
+                                                int32_t n_proofs, p25_circuit** out) {
+  return build_recursive(inner, digest4, cs_cap, n_proofs, false, out);
+}
+p25_status p25_circuit_build_aggregator(p25_circuit* inner, const uint64_t* digest4, const uint64_t* cs_cap,
+                                        int32_t n_proofs, p25_circuit** out) {
+  return build_recursive(inner, digest4, cs_cap, n_proofs, true, out);
 }
 
 p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out) {
@@ -441,6 +449,7 @@ p25_status p25_circuit_to_bytes(p25_circuit* c, uint8_t** bytes_out, size_t* len
     cm.lde = lde.data();
     cm.tree = tree.data();
     memcpy(cm.digest, d.digest(), 32);
+    cm.public_inputs = d.circuit().public_inputs;
     std::vector<uint8_t> b = p25::circuit_data_to_bytes(d.circuit(), cm);
     uint8_t* m = (uint8_t*)malloc(b.size() ? b.size() : 1);
     if (!m) throw std::runtime_error("out of host memory");
@@ -518,6 +527,7 @@ p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out) {
     out->witness_levels = c->wp_info->level_start.size() - 1;
     out->witness_slots = c->wp_info->num_slots;
     out->num_random_fill = c->wp_info->num_random_fill;
+    out->num_public_inputs = k.public_inputs.size();
     out->num_challenges = k.cfg.num_challenges;
     out->num_partial_products = k.num_partial_products;
     out->quotient_degree_factor = k.cfg.max_quotient_degree_factor;

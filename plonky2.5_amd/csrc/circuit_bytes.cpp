@@ -519,7 +519,7 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
   if (r.usize() != (u64)c.cfg.max_quotient_degree_factor) R::bad("quotient_degree_factor != max_quotient_degree_factor");
   c.num_gate_constraints = (int)r.usize_max(1 << 20, "num_gate_constraints");
   if (r.usize() != (u64)c.cfg.num_constants) R::bad("num_constants disagree");
-  if (r.usize() != 0) R::bad("circuits with public inputs are not supported");
+  const u64 n_pi = r.usize_max(MAX_PUBLIC_INPUTS, "num_public_inputs");
   if (r.usize() != RW) R::bad("k_is length");
   c.k_is.resize(RW);
   r.fields(c.k_is.data(), RW);
@@ -606,7 +606,11 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
     if (r.usize() != n) R::bad("subgroup length");
     r.skip(8 * n);
   }
-  if (r.usize() != 0) R::bad("circuits with public inputs are not supported");
+  const size_t pis_at = r.off;   // the targets are range-checked once the number of virtual targets is known
+  if (r.usize() != n_pi) R::bad("public_inputs length != num_public_inputs");
+  for (u64 i = 0; i < n_pi; i++) {
+    if (r.boolean()) r.skip(16); else r.skip(8);
+  }
   {
     u64 nt = r.usize_max((u64)1 << 31, "representative map");
     if (nt < n * Wn) R::bad("representative map shorter than the wire grid");
@@ -774,6 +778,12 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
       }
       c.generators.push_back(std::move(gen));
     }
+  }
+  {
+    R g{data, len};
+    g.off = pis_at;
+    g.usize();
+    for (u64 i = 0; i < n_pi; i++) c.public_inputs.push_back(g.target(n, Wn, c.num_virtual_targets));
   }
   // the per-proof inputs are not part of CircuitData (upstream hands a PartialWitness to prove): the caller names them
   const size_t NT = c.num_targets();

@@ -59,7 +59,7 @@ std::vector<uint8_t> circuit_to_blob(const Circuit& c) {
   h[10] = c.fri_reduction_arity_bits.size(); h[11] = c.num_selectors; h[12] = c.num_gate_constraints;
   h[13] = c.num_partial_products; h[14] = c.gates.size(); h[15] = (u64)c.pi_row; h[16] = c.num_virtual_targets;
   h[17] = c.input_targets.size(); h[18] = c.generators.size(); h[19] = c.constants_sigmas.size();
-  h[20] = c.cfg.fri_arity_bits; h[21] = c.cfg.fri_final_poly_bits;
+  h[20] = c.cfg.fri_arity_bits; h[21] = c.cfg.fri_final_poly_bits; h[22] = c.public_inputs.size();
   w.u64arr(h, 32);
   for (size_t i = 0; i < c.gates.size(); i++) {
     int s = c.selector_index[i];
@@ -83,6 +83,11 @@ std::vector<uint8_t> circuit_to_blob(const Circuit& c) {
     for (auto& t : g.outs) args.push_back((uint32_t)c.target_index(t));
     w.u32arr(args.data(), args.size());
   }
+  if (!c.public_inputs.empty()) {  // field 10 (absent without public inputs: earlier blobs stay valid)
+    std::vector<uint32_t> pi(c.public_inputs.size());
+    for (size_t i = 0; i < pi.size(); i++) pi[i] = (uint32_t)c.target_index(c.public_inputs[i]);
+    w.u32arr(pi.data(), pi.size());
+  }
   return std::move(w.b);
 }
 
@@ -99,10 +104,13 @@ Circuit circuit_from_blob(const uint8_t* data, size_t len) {
   c.num_partial_products = (int)h[13]; size_t ng = h[14]; c.pi_row = (int)h[15]; c.num_virtual_targets = h[16];
   size_t n_in = h[17], n_gen = h[18], n_cs = h[19];
   c.cfg.fri_arity_bits = (int)h[20]; c.cfg.fri_final_poly_bits = (int)h[21];
+  const size_t n_pi = h[22];
   // Everything below is indexed by these fields, on the host and in the kernels: validate before use.
   auto bad = [](const char* what) { throw std::invalid_argument(std::string("circuit blob: ") + what); };
-  for (int i = 0; i < 22; i++)
+  for (int i = 0; i < 23; i++)
     if (i != 15 && h[i] > ((u64)1 << 31)) bad("header field out of range");
+  if (n_pi > MAX_PUBLIC_INPUTS) bad("too many public inputs");
+  if (n_pi && c.pi_row < 0) bad("public inputs without a PublicInputGate row");
   if (h[15] != (u64)-1 && h[15] >= ((u64)1 << 31)) bad("bad public-input row");
   if (c.degree_bits < 1 || c.degree_bits > 22) bad("degree_bits must be in 1..22");
   if (c.cfg.num_wires < 1 || c.cfg.num_wires > 1024 || c.cfg.num_routed_wires < 1 ||
@@ -232,6 +240,15 @@ Circuit circuit_from_blob(const uint8_t* data, size_t len) {
     for (size_t i = 0; i < nd; i++) g.deps.push_back(to_target(args[i]));
     for (size_t i = 0; i < no; i++) g.outs.push_back(to_target(args[nd + i]));
   }
+  if (n_pi) {
+    std::vector<uint32_t> pi(n_pi);
+    r.u32arr(pi.data(), n_pi);
+    for (uint32_t i : pi) {
+      if (i >= NT) bad("public-input target out of range");
+      c.public_inputs.push_back(to_target(i));
+    }
+  }
+  if (r.off != len) bad("trailing bytes");
   return c;
 }
 }  // namespace p25

@@ -293,7 +293,9 @@ std::string proof_to_json(const Circuit& c, const ProofLayout& L, const u64* w) 
   o.exts(w + L.final_poly, L.final_poly_len);
   o.s += "},\"pow_witness\":";
   o.num(w[L.pow_witness]);
-  o.s += "}},\"public_inputs\":[]}";
+  o.s += "}},\"public_inputs\":";
+  o.nums(w + L.public_inputs, L.num_public_inputs);
+  o.s += "}";
   return o.s;
 }
 
@@ -301,7 +303,7 @@ std::string proof_to_json(const Circuit& c, const ProofLayout& L, const u64* w) 
 // emits; absent crate, restated): every field element as 8 little-endian bytes in the order of the flat layout --
 // caps, the opening set (constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, [lookup_zs, next_lookup_zs: empty],
 // partial_products, quotient_polys), commit-phase caps, query rounds, final polynomial, PoW witness, public inputs
-// (none) -- with ONE difference: every Merkle proof is preceded by its sibling count as a u8 (write_merkle_proof).
+// -- with ONE difference: every Merkle proof is preceded by its sibling count as a u8 (write_merkle_proof).
 namespace {
 // calls f(is_path_len, value / count, n_words) over the proof in order
 template <class F>
@@ -366,7 +368,7 @@ void proof_from_bytes(const Circuit& c, const ProofLayout& L, const uint8_t* dat
       words(n);
     }
   });
-  if (off != len) throw std::invalid_argument("proof bytes: trailing data (public inputs are not supported)");
+  if (off != len) throw std::invalid_argument("proof bytes: trailing data");
 }
 
 }  // namespace p25

@@ -87,9 +87,9 @@ __device__ void gate_constant(Ctx& cx, u64 k0, u64 k1) {
   cx.at(0, gl::sub(k0, cx.w(0)));
   cx.at(1, gl::sub(k1, cx.w(1)));
 }
-__device__ void gate_public_input(Ctx& cx) {
-  // public-inputs hash of the empty input list is [0,0,0,0]
-  for (int i = 0; i < 4; i++) cx.at(i, cx.w(i));
+__device__ void gate_public_input(Ctx& cx, const u64* __restrict__ pih) {
+  // wire_i - public_inputs_hash_i (upstream gates/public_input.rs); the hash of the empty list is [0, 0, 0, 0]
+  for (int i = 0; i < 4; i++) cx.at(i, gl::sub(cx.w(i), pih[i]));
 }
 __device__ void gate_base_sum(Ctx& cx) {
   // sum_i limb_i 2^i, i < 63: carry-free groups of eight limbs (cf. SmallLin below), most significant group
@@ -447,7 +447,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
 #endif
       switch (ge.kind) {
         case G_CONSTANT: gate_constant(cx, k0, k1); break;
-        case G_PUBLIC_INPUT: gate_public_input(cx); break;
+        case G_PUBLIC_INPUT: gate_public_input(cx, a.pi_hash); break;
         case G_BASE_SUM: gate_base_sum(cx); break;
         case G_U32_INTERLEAVE: gate_u32_interleave(cx); break;
         case G_U32_UNINTERLEAVE: gate_u32_uninterleave(cx); break;

@@ -108,6 +108,29 @@ __global__ __launch_bounds__(256) void k_pow_search(const Transcript* __restrict
 }
 __global__ void k_pow_init(u64* result) { *result = ~0ull; }
 
+// hash_no_pad of a proof's public inputs (overwrite-mode sponge, rate 8; hash/hashing.rs `hash_n_to_m_no_pad`): state
+// word r in lane r, one cooperative permutation per chunk of 8.
+__global__ __launch_bounds__(64) void k_public_inputs(const u64* __restrict__ vals, size_t B, uint32_t p,
+                                                      const uint32_t* __restrict__ pi_slots, uint32_t n,
+                                                      u64* __restrict__ values_out, u64* __restrict__ hash_out) {
+  __shared__ u64 rc_lds[360];
+  coop::stage_poseidon_rc(rc_lds);
+  const int lane = threadIdx.x;
+  u64 s = 0;
+  for (uint32_t off = 0; off < n; off += 8) {
+    if (lane < 8 && off + lane < n) {
+      s = vals[(size_t)pi_slots[off + lane] * B + p];
+      values_out[off + lane] = s;
+    }
+    s = coop::poseidon_permute_single(s, lane, rc_lds);
+  }
+  if (lane < 4) hash_out[lane] = s;
+}
+void launch_public_inputs(const u64* d_vals, size_t B, uint32_t p, const uint32_t* d_pi_slots, uint32_t n, u64* d_values_out,
+                          u64* d_hash_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_public_inputs, dim3(1), dim3(64), 0, st, d_vals, B, p, d_pi_slots, n, d_values_out, d_hash_out);
+}
+
 void launch_pow_search(const Transcript* d_tr, int pow_bits, u64* d_result, hipStream_t st) {
   hipLaunchKernelGGL(k_pow_init, dim3(1), dim3(1), 0, st, d_result);
   // Expected number of candidates is 2^pow_bits; a window is skipped once a smaller witness is known.

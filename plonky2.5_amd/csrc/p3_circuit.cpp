@@ -837,6 +837,19 @@ Circuit build_gadget_circuit(int kind, int param) {
       for (int i = 0; i < 4; i++) cb.connect(out[i], in());
       break;
     }
+    case GADGET_PUBLIC_INPUTS: {  // upstream `register_public_input(s)`: `param` inputs x_i; exposes every x_i, then their
+      // running products x_0 x_1, x_0 x_1 x_2, ... (so public inputs are a mix of virtual targets and gate wires)
+      if (param < 1 || param > 64) throw std::invalid_argument("public-inputs gadget: 1..64 inputs");
+      std::vector<Target> xs;
+      for (int i = 0; i < param; i++) xs.push_back(in());
+      cb.register_public_inputs(xs);
+      Target acc = xs[0];
+      for (int i = 1; i < param; i++) {
+        acc = cb.mul(acc, xs[i]);
+        cb.register_public_input(acc);
+      }
+      break;
+    }
     default:
       throw std::invalid_argument("unknown gadget kind");
   }

@@ -15,7 +15,8 @@ struct ProofLayout {
   // word offsets into the flat proof (include/p25.h "Proof layout")
   size_t wires_cap, zs_cap, quotient_cap;
   size_t constants, sigmas, wires, zs, zs_next, pps, quotient;
-  size_t fri_caps, queries, query_stride, final_poly, pow_witness, total;
+  size_t fri_caps, queries, query_stride, final_poly, pow_witness, public_inputs, total;
+  uint32_t num_public_inputs;
   uint32_t oracle_width[4];
   uint32_t final_poly_len;
 };

@@ -62,6 +62,8 @@ ProofLayout make_proof_layout(const Circuit& c) {
   L.final_poly_len = final_poly_len(c);
   L.final_poly = o; o += 2 * (size_t)L.final_poly_len;
   L.pow_witness = o; o += 1;
+  L.num_public_inputs = (uint32_t)c.public_inputs.size();
+  L.public_inputs = o; o += L.num_public_inputs;   // ProofWithPublicInputs::public_inputs, after the proof proper
   L.total = o;
   return L;
 }
@@ -163,6 +165,7 @@ struct DeviceCircuit::Ctx {
   DevMem zs_vals, zs_coeffs, zs_lde, zs_tree, zpp_chunk, zpp_tot, zpp_btot;
   DevMem q_vals, q_tmp, q_coeffs, q_lde, q_tree;
   DevMem transcript, chal, alpha_pows, eval_pows;
+  DevMem preamble;  // circuit_digest[4] | public_inputs_hash[4] of the proof in flight: what the transcript absorbs first
   DevMem fri_comp, fri_scan;
   FriWork fri;
   DevMem proof, status;
@@ -234,6 +237,8 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
     }
     wp_.level_perm_arg_base.push_back(pc ? wp.gens[pb].arg_off : 0);
   }
+  wp_.d_pi_slots = wp.pi_slots.empty() ? nullptr : up32(wp.pi_slots);
+  wp_.n_public_inputs = (uint32_t)wp.pi_slots.size();
   wp_.n_inputs = (uint32_t)wp.input_slots.size();
   wp_.num_slots = wp.num_slots;
   wp_.num_random_fill = wp.num_random_fill;
@@ -357,6 +362,8 @@ void DeviceCircuit::ensure_ctx(size_t count) {
   x.q_coeffs = DevMem((size_t)NC * B);
   x.q_lde = DevMem((size_t)nq * B);
   x.q_tree = DevMem(tw);
+  x.preamble = DevMem(8);
+  P25_HIP(hipMemcpy(x.preamble.p, preamble_.p, 64, hipMemcpyDeviceToDevice));  // digest | hash_no_pad([]) = zeros
   x.transcript = DevMem(sizeof(Transcript) / 8 + 1);
   x.chal = DevMem(CH_WORDS);
   x.alpha_pows = DevMem(2 * ALPHA_POWS);
@@ -433,6 +440,10 @@ void DeviceCircuit::prove_one(Ctx& x, int buf, size_t Bstride, uint32_t p, u64* 
   mark();  // 0
   // "compute full witness" + "compute wire polynomials"
   launch_fill_wires(wp_, d_vals, Bstride, p, x.wires_vals.p, st);
+  // "let public_inputs = partition_witness.get_targets(&prover_data.public_inputs); let public_inputs_hash = ..."
+  // (no launch at all for a circuit without public inputs: the preamble keeps the hash of the empty list)
+  if (wp_.n_public_inputs)
+    launch_public_inputs(d_vals, Bstride, p, wp_.d_pi_slots, wp_.n_public_inputs, d_proof + L.public_inputs, x.preamble.p + 4, st);
   P25_HIP(hipEventRecord(x.done[buf], st));  // last read of this witness-value buffer by this proof
   mark();  // 1
   // "compute wires commitment"
@@ -455,7 +466,7 @@ void DeviceCircuit::prove_one(Ctx& x, int buf, size_t Bstride, uint32_t p, u64* 
   }
   const u64* wires_cap = x.wires_tree.p + tw - capw;
   d2d(d_proof + L.wires_cap, wires_cap, capw);
-  launch_transcript(tr, 1, preamble_.p, 8, chal, 0, st);
+  launch_transcript(tr, 1, x.preamble.p, 8, chal, 0, st);
   launch_transcript(tr, 0, wires_cap, (uint32_t)capw, chal + CH_BETAS, 2 * NC, st);  // betas, gammas
   mark();  // 2
   // "compute partial products"
@@ -585,6 +596,7 @@ void DeviceCircuit::enqueue_quotient(Ctx& x, hipStream_t st) {
     qa.wires_lde = x.wires_lde.p;
     qa.zs_lde = x.zs_lde.p;
     qa.chal = chal;
+    qa.pi_hash = x.preamble.p + 4;
     qa.alpha_pows = x.alpha_pows.p;
     qa.out = x.q_vals.p;
     launch_quotient(qa, st);
@@ -636,6 +648,12 @@ void DeviceCircuit::quotient(const u64* wires, const u64* zs_pp, const u64* beta
   check_canonical(zs_pp, (size_t)nz * n, "zs_partial_products");
   set_challenges(x, betas, gammas, alphas);
   hipStream_t st = x.st;
+  if (c_.pi_row >= 0) {  // the public-inputs hash the PublicInputGate compares with is what that row of the witness holds
+    u64 pih[4];
+    for (int i = 0; i < 4; i++) pih[i] = wires[(size_t)i * n + (size_t)c_.pi_row];
+    P25_HIP(hipMemcpyAsync(x.preamble.p + 4, pih, 32, hipMemcpyHostToDevice, st));
+    P25_HIP(hipStreamSynchronize(st));  // pih is on this stack
+  }
   P25_HIP(hipMemcpyAsync(x.wires_vals.p, wires, (size_t)W * n * 8, hipMemcpyHostToDevice, st));
   P25_HIP(hipMemcpyAsync(x.zs_vals.p, zs_pp, (size_t)nz * n * 8, hipMemcpyHostToDevice, st));
   ntt_inverse(tables_, x.wires_vals.p, n, false, x.tmp.p, n, x.wires_coeffs.p, n, db, W, 1, st);

@@ -17,6 +17,8 @@ struct DeviceWitnessProgram {
   // by kind within a level): Poseidon2Gate's (inner circuits) or, where a level has none, PoseidonGate's (recursion)
   std::vector<uint32_t> level_p2_begin, level_p2_count, level_coop_kind;
   std::vector<uint32_t> level_perm_arg_base;  // WitGen::arg_off of the level's first permutation generator (fixed stride after it)
+  uint32_t* d_pi_slots = nullptr;
+  uint32_t n_public_inputs = 0;
   uint32_t n_inputs = 0, num_slots = 0, num_random_fill = 0;
   size_t n_wire_elems = 0;
 };
@@ -44,6 +46,11 @@ void launch_transcript(Transcript* d_tr, int init, const u64* d_obs, uint32_t n_
                        uint32_t n_chal, hipStream_t st);
 // observe two buffers back to back (e.g. openings at zeta, then at g*zeta)
 void launch_pow_search(const Transcript* d_tr, int pow_bits, u64* d_result, hipStream_t st);
+// Public inputs of proof p of a witness pass: values[i] = vals[pi_slots[i] * B + p] -> d_values_out[n] (the flat
+// proof's public_inputs section) and their hash_no_pad (upstream `C::InnerHasher::hash_no_pad(&public_inputs)`) ->
+// d_hash_out[4].  One wave: the sponge is a chain of ceil(n / 8) permutations.
+void launch_public_inputs(const u64* d_vals, size_t B, uint32_t p, const uint32_t* d_pi_slots, uint32_t n, u64* d_values_out,
+                          u64* d_hash_out, hipStream_t st);
 
 // challenge block layout (u64 words) in the per-proof device scratch
 enum {
@@ -68,6 +75,7 @@ struct QuotientArgs {
   uint32_t quotient_degree_factor;  // routed wires per partial-product chunk (max_quotient_degree_factor)
   u64 zh[8], zh_inv[8];  // Z_H on the coset (index = i mod 2^rate_bits), and inverses
   const u64* l0_inv;     // [big] 1 / (n (x - 1)) at bit-reversed positions (per circuit)
+  const u64* pi_hash;    // [4] public-inputs hash of this proof (PublicInputGate: wire_i - hash_i)
 #ifdef P25_PROFILE_GATE_MASK
   uint32_t debug_gate_mask;  // profiling builds only (tools/qmask.sh)
 #endif

@@ -373,6 +373,7 @@ struct ProofTargets {
   std::vector<Query> queries;
   std::vector<Ext> final_poly;
   Target pow_witness;
+  std::vector<Target> public_inputs;
 };
 
 struct Reader {
@@ -437,6 +438,7 @@ ProofTargets add_virtual_proof(CircuitBuilder& b, const Circuit& c) {
   for (int a : c.fri_reduction_arity_bits) fdeg -= a;
   p.final_poly = r.exts((size_t)1 << fdeg);
   p.pow_witness = r.word();
+  for (size_t i = 0; i < c.public_inputs.size(); i++) p.public_inputs.push_back(r.word());  // ProofWithPublicInputs::public_inputs
   return p;
 }
 
@@ -489,13 +491,15 @@ Target exp_from_bits_const_base(CircuitBuilder& b, u64 base, const std::vector<B
   return product;
 }
 
-// one inner proof
-void verify_one(CircuitBuilder& b, const Circuit& c, const Hash& digest, const std::vector<Hash>& cs_cap) {
+// one inner proof; returns its targets (the caller may expose some of them as public inputs of the outer circuit)
+ProofTargets verify_one(CircuitBuilder& b, const Circuit& c, const Hash& digest, const std::vector<Hash>& cs_cap) {
   ProofTargets p = add_virtual_proof(b, c);
   const int NC = c.cfg.num_challenges, NP = c.num_partial_products, RW = c.cfg.num_routed_wires;
   const int Q = c.cfg.max_quotient_degree_factor;
   const int db = c.degree_bits, rb = c.cfg.rate_bits, lde_bits = db + rb;
-  const Hash pih = {b.zero(), b.zero(), b.zero(), b.zero()};  // hash_no_pad([]) : no public inputs
+  // "let public_inputs_hash = self.hash_n_to_hash_no_pad::<C::InnerHasher>(proof_with_pis.public_inputs)"
+  // (plonk/recursive_verifier.rs verify_proof); of the empty list it is four zeros and costs no row
+  const Hash pih = b.hash_n_to_hash_no_pad(p.public_inputs);
 
   // ---- challenges (upstream plonk/get_challenges.rs, in-circuit)
   RecursiveChallenger ch(b);
@@ -667,11 +671,13 @@ void verify_one(CircuitBuilder& b, const Circuit& c, const Hash& digest, const s
     Ext final_eval = reduce_ext(b, p.final_poly, b.convert_to_ext(subgroup_x));
     b.connect_extension(final_eval, old_eval);
   }
+  return p;
 }
 
 }  // namespace
 
-Circuit build_recursive_verifier(const Circuit& inner, const u64 digest[4], const std::vector<u64>& cs_cap, int n_proofs) {
+Circuit build_recursive_verifier(const Circuit& inner, const u64 digest[4], const std::vector<u64>& cs_cap, int n_proofs,
+                                 bool expose_commitment) {
   if (n_proofs < 1 || n_proofs > 16) throw std::invalid_argument("recursive verifier: 1..16 inner proofs");
   if (cs_cap.size() != ((size_t)4 << inner.cfg.cap_height)) throw std::invalid_argument("recursive verifier: bad cap size");
   CircuitBuilder cb(inner.cfg);
@@ -680,7 +686,26 @@ Circuit build_recursive_verifier(const Circuit& inner, const u64 digest[4], cons
   std::vector<Hash> cap(cs_cap.size() / 4);
   for (size_t k = 0; k < cap.size(); k++)
     for (int i = 0; i < 4; i++) cap[k][i] = cb.constant(cs_cap[4 * k + i]);
-  for (int p = 0; p < n_proofs; p++) verify_one(cb, inner, dg, cap);
+  std::vector<Target> ids;  // what identifies each inner proof to the outside
+  for (int p = 0; p < n_proofs; p++) {
+    ProofTargets pt = verify_one(cb, inner, dg, cap);
+    if (!expose_commitment) continue;
+    if (!pt.public_inputs.empty()) {
+      ids.insert(ids.end(), pt.public_inputs.begin(), pt.public_inputs.end());  // an aggregate: its own commitment
+    } else {
+      // a leaf proof without public inputs: the hash of its wires commitment (binds the proof's witness)
+      std::vector<Target> capw;
+      for (const Hash& h : pt.wires_cap) capw.insert(capw.end(), h.begin(), h.end());
+      Hash id = cb.hash_n_to_hash_no_pad(capw);
+      ids.insert(ids.end(), id.begin(), id.end());
+    }
+  }
+  if (expose_commitment) {
+    // the aggregate's public inputs: one 4-word commitment to everything verified below it (a Poseidon tree over
+    // the leaf proofs' identifiers when aggregation circuits are stacked)
+    Hash root = ids.size() == 4 ? Hash{ids[0], ids[1], ids[2], ids[3]} : cb.hash_n_to_hash_no_pad(ids);
+    cb.register_public_inputs({root[0], root[1], root[2], root[3]});
+  }
   return cb.build();
 }
 

@@ -39,6 +39,11 @@ Circuit build_gate_eval_circuit(GateKind kind);
 
 // The recursive verifier: inputs = n_proofs inner proofs, each in the flat layout of include/p25.h.  `digest` /
 // `cs_cap` are the inner circuit's verifier data (VerifierOnlyCircuitData), baked in as constants.
-Circuit build_recursive_verifier(const Circuit& inner, const u64 digest[4], const std::vector<u64>& cs_cap, int n_proofs);
+// expose_commitment: the new circuit registers FOUR public inputs -- hash_no_pad over the identifiers of the proofs it
+// verifies, where a proof's identifier is its own public inputs if it has any (an aggregate further down) and
+// hash_no_pad(its wires cap) otherwise (a leaf): stacked 2-to-1 aggregators thereby expose a Poseidon tree root over
+// the batch (the north star's "final aggregation" needs something to show for itself).
+Circuit build_recursive_verifier(const Circuit& inner, const u64 digest[4], const std::vector<u64>& cs_cap, int n_proofs,
+                                 bool expose_commitment = false);
 
 }  // namespace p25

@@ -138,6 +138,7 @@ WitnessProgram build_witness_program(const Circuit& c) {
   }
   wp.level_start.push_back((uint32_t)wp.gens.size());
 
+  for (const Target& t : c.public_inputs) wp.pi_slots.push_back(slot_of_rep[rep_of(t)]);
   const size_t n = c.degree();
   const int W = c.cfg.num_wires;
   wp.wire_slot_cm.resize((size_t)W * n);

@@ -38,6 +38,7 @@ struct WitnessProgram {
   // input_slots[i] carries WIT_CHECK_FLAG and input_first[i] is the index of the first writer.
   std::vector<uint32_t> input_first;
   std::vector<uint32_t> wire_slot_cm;     // [num_wires][degree] column-major: slot of each wire
+  std::vector<uint32_t> pi_slots;         // slot of each registered public input (Circuit::public_inputs order)
 };
 
 // Throws std::runtime_error("N generators weren't run") if the circuit is not fully determined.

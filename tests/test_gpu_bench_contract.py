@@ -40,6 +40,7 @@ def test_bench_json_contract():
     # the batch folded to one root proof by the recursive verifier circuits, root accepted by the oracle's verifier
     ag = d["aggregation"]
     assert ag["leaves"] == 4 and len(ag["levels"]) == 2 and ag["oracle_verifier_accepts_root"] is True
+    assert len(ag["root_public_inputs"]) == 4 and ag["root_public_inputs_commit_to_the_leaves"] is True
     assert ag["leaf_equivalent_proofs_per_s_including_aggregation"] > 0
     # VALU view: priced with the clock measured in the run, and only from a PMC pass of these very kernel sources
     v = rf["valu"]
