@@ -36,6 +36,14 @@ class OracleCircuit:
         st = self.lib.p25o_witness(self.h, _p(inp), seed, _p(wires), msg, 512)
         return wires, st, msg.value.decode()
 
+    def witness_forced(self, inputs, seed=0):
+        """witness() that carries on past a copy-constraint conflict (the partition keeps its first value)."""
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
+        wires = np.zeros((self.num_wires, self.n), dtype=np.uint64)
+        msg = C.create_string_buffer(512)
+        st = self.lib.p25o_witness_forced(self.h, _p(inp), seed, _p(wires), msg, 512)
+        return wires, st, msg.value.decode()
+
     def check_constraints(self, wires):
         msg = C.create_string_buffer(512)
         bad = self.lib.p25o_check_constraints(self.h, _p(np.ascontiguousarray(wires)), msg, 512)
@@ -140,6 +148,7 @@ class Oracle:
         L.p25o_circuit_free.argtypes = [vp]
         L.p25o_circuit_info.argtypes = [vp, vp]
         L.p25o_witness.argtypes = [vp, vp, u64, vp, C.c_char_p, sz]
+        L.p25o_witness_forced.argtypes = [vp, vp, u64, vp, C.c_char_p, sz]
         L.p25o_check_constraints.argtypes = [vp, vp, C.c_char_p, sz]
         L.p25o_check_constraints.restype = C.c_long
         L.p25o_precompute.argtypes = [vp]

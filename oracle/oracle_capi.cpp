@@ -112,6 +112,17 @@ int p25o_witness(void* h, const u64* inputs, u64 seed, u64* wires_out, char* msg
   for (int col = 0; col < oc->c.num_wires; col++) memcpy(wires_out + (size_t)col * n, r.wires[col].data(), n * 8);
   return 0;
 }
+// Witness generation that does not stop at a copy-constraint conflict: the conflicting partition keeps its first
+// value, the wires are returned, the status is still 4 (see ref_generate_witness keep_going).
+int p25o_witness_forced(void* h, const u64* inputs, u64 seed, u64* wires_out, char* msg, size_t msglen) {
+  auto* oc = (OracleCircuit*)h;
+  RWitnessResult r = ref_generate_witness(oc->c, inputs, seed, nullptr, true);
+  put_msg(msg, msglen, r.message);
+  if (r.wires.empty()) return r.status ? r.status : 5;
+  const size_t n = oc->c.n();
+  for (int col = 0; col < oc->c.num_wires; col++) memcpy(wires_out + (size_t)col * n, r.wires[col].data(), n * 8);
+  return r.status;
+}
 // Evaluates every row's own gate on the witness; returns the number of non-zero constraints
 // (0 = witness satisfies the circuit) and reports the first offender.
 long p25o_check_constraints(void* h, const u64* wires, char* msg, size_t msglen) {

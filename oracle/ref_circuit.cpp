@@ -272,7 +272,7 @@ void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitnes
 }
 }  // namespace
 
-RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed, const u64* filler) {
+RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed, const u64* filler, bool keep_going) {
   RWitnessResult res;
   res.status = 0;
   PartitionWitness w(c);
@@ -322,7 +322,7 @@ RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 se
   if (w.conflict) {
     res.status = 4;
     res.message = w.msg;
-    return res;
+    if (!keep_going) return res;
   }
   if (remaining) {
     res.status = 5;

@@ -62,5 +62,9 @@ struct RWitnessResult {
   std::vector<std::vector<u64>> wires;  // [num_wires][n]  (full_witness: unset wires are 0)
   std::vector<u64> public_inputs;       // upstream `partition_witness.get_targets(&prover_data.public_inputs)`
 };
-RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed, const u64* filler = nullptr);
+// keep_going: on a copy-constraint conflict keep the partition's FIRST value, finish the run and return the wires
+// with status 4 (test infrastructure: such a witness satisfies every copy constraint by construction, so whatever is
+// wrong with it must show up as a violated GATE constraint -- tests/test_recursion_cpu.py)
+RWitnessResult ref_generate_witness(const RCircuit& c, const u64* inputs, u64 seed, const u64* filler = nullptr,
+                                    bool keep_going = false);
 u64 ref_random_fill(u64 seed, u64 k);

@@ -96,6 +96,33 @@ def test_recursive_verifier_rejects_tampered_inner_proofs(oracle, small_recursio
         assert oo.witness(bad, seed=9)[1] == 4, k
 
 
+def test_constraints_not_only_generators_reject_a_bad_inner_proof(oracle, small_recursion):
+    """The tests above see a corrupted inner proof fail through the witness generator's `connect` conflict.  That a
+    CONSTRAINT fails too -- that no gadget of the verifier circuit merely has its generator do the comparing -- is
+    shown here: witness generation carries on past the conflict (the partition keeps its first value, so every copy
+    constraint holds by construction) and the gate constraints of the resulting witness must then be violated.
+    One corruption per check of the recursive verifier: a cap word (Merkle root select), an opening (vanishing
+    identity and reduced openings), a leaf word and a sibling (Merkle paths), a FRI evaluation (fold consistency),
+    the final polynomial, the PoW witness (range check of the response)."""
+    inner, oi, proof, outer = small_recursion
+    oo = oracle.load_circuit(outer.to_blob())
+    good, st, _m = oo.witness_forced(proof, seed=9)
+    assert st == 0 and oo.check_constraints(good)[0] == 0
+    n = proof.size
+    openings = 64 * 3
+    queries = openings + 2 * (5 + 80 + 135 + 2 + 2 + 18 + 16) + 64 * len(range(0))
+    spots = {"wires cap": 5, "opening (wires)": openings + 2 * (5 + 80) + 3, "opening (quotient)": openings + 2 * (5 + 80 + 135 + 4 + 18) + 1,
+             "query leaf word": queries + 40, "query sibling": queries + 85 + 7, "final poly": n - 4, "pow witness": n - 1}
+    for what, k in spots.items():
+        bad = proof.copy()
+        bad[k] = (int(bad[k]) + 1) % P
+        assert oi.verify(bad)[0] != 0, what
+        wires, st, _m = oo.witness_forced(bad, seed=9)
+        assert st == 4, what
+        nbad, msg = oo.check_constraints(wires)
+        assert nbad > 0, f"{what}: every gate constraint holds on a witness built from a false inner proof"
+
+
 def test_recursive_verifier_with_fri_layers(p25, oracle):
     """inner = the plonky3-verifier circuit of a 2^3-row Fibonacci STARK (2^10 rows, all 11 gate types, one FRI
     reduction layer): covers the in-circuit fold (coset interpolation at beta), the layer Merkle proofs and the
