@@ -286,8 +286,11 @@ def main():
     def step():
         if B:
             circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), d_proofs.data_ptr(), pw, d_status.data_ptr())
-        circuit.sync()
+        # On one GPU the steps are only enqueued here (the library's streams order step k+1's proof i behind step k's
+        # proof i, which it overwrites); the timed region is bracketed by device-wide synchronisations.  With N > 1
+        # the gather needs the finished proofs, so every step ends with a sync.
         if distributed:  # the final aggregation step: finished proofs gathered onto rank 0 over RCCL/xGMI
+            circuit.sync()
             g0 = time.perf_counter()
             if args.dist_backend == "nccl":
                 gathered[0], gathered[1] = gatherer.gather(d_proofs, d_status)
@@ -298,6 +301,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    circuit.sync()
     gather_s[0] = 0.0
     circuit.kernel_stats(enable=True, reset=True)
     if distributed:
@@ -306,6 +310,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    circuit.sync()
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0
     if distributed:

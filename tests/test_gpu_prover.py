@@ -195,3 +195,19 @@ def test_circuit_create_destroy_does_not_leak_device_memory(gpu):
     torch.cuda.synchronize()
     free1, _total = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 8 create/prove/destroy cycles"
+
+
+def test_gpu_proof_through_upstream_binary_form(gpu, fib_circuit, fib_inputs, fib_oracle):
+    """The device's proof in upstream's `ProofWithPublicInputs::to_bytes()` form and back: what a Rust host would
+    hand to `from_bytes` and then to `data.verify(proof)` (src/p3/mod.rs:266) -- the oracle's verifier stands in."""
+    proofs, st = fib_circuit.prove(fib_inputs[None, :], seeds=[21])
+    assert st.tolist() == [0]
+    raw = fib_circuit.proof_to_bytes(proofs[0])
+    assert len(raw) == 8 * proofs[0].size + 28 * (4 + 3)           # + one length byte per Merkle proof
+    back = fib_circuit.proof_from_bytes(raw)
+    assert (back == proofs[0]).all()
+    dg, cap = fib_circuit.digest()
+    assert fib_oracle.verify(back, dg, cap)[0] == 0
+    import json
+    js = json.loads(fib_circuit.proof_to_json(proofs[0]))
+    assert js["public_inputs"] == [] and len(js["proof"]["opening_proof"]["query_round_proofs"]) == 28

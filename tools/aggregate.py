@@ -24,7 +24,7 @@ assert (st == 0).all()
 levels = [{"level": 0, "circuit_rows_log2": int(circ.info.degree_bits), "proofs": n, "prove_s": round(dt, 3)}]
 total = dt
 while len(level) > 1:
-    t = time.perf_counter(); circ = circ.build_recursive_verifier(2); circ.digest(); build = time.perf_counter() - t
+    t = time.perf_counter(); circ = circ.build_aggregator(2); circ.digest(); build = time.perf_counter() - t
     pairs = np.stack([np.concatenate([level[2 * i], level[2 * i + 1]]) for i in range(len(level) // 2)])
     circ.prove(pairs[:min(16, len(pairs))], seeds=list(range(min(16, len(pairs)))))   # warm-up: this circuit's contexts
     t = time.perf_counter(); level, st = circ.prove(pairs, seeds=np.arange(len(pairs), dtype=np.uint64)); dt = time.perf_counter() - t

@@ -22,11 +22,13 @@ done
 # rocprofv3 per-kernel summary of the same command (smaller batch) + the dominant kernel's launches split into
 # "GPU to itself" (bench.py's single-proof passes = roofline.avg_launch_ms) and "in flight"
 rm -rf $OUT/_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_prof -- python3 bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_b64_rocprof.json 2> $OUT/_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_prof -- python3 bench.py --batch 64 --steps 1 --warmup 1 --no-cpu-baseline --extra-configs none --aggregate 0 > $OUT/${TAG}_bench_b64_rocprof.json 2> $OUT/_prof.err
 find $OUT/_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_rocprofv3_kernel_stats_bench_b64.csv
 find $OUT/_prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/rocprof_kernel_split.py {} > $OUT/${TAG}_rocprof_hash_leaves_split.txt
 rm -rf $OUT/_prof
 python tools/aggregate.py 64 > $OUT/${TAG}_aggregate_64.json 2> $OUT/_agg.err
+tools/build/latbench > $OUT/${TAG}_latbench.txt 2>&1
+tools/build/coopbench > $OUT/${TAG}_coopbench.txt 2>&1
 python tools/kernel_bench.py > $OUT/${TAG}_kernel_bench.txt 2>&1
 tail -3 $OUT/${TAG}_pytest_gpu.txt
 cut -c1-160 $OUT/${TAG}_bench_default.json

@@ -11,8 +11,14 @@ if "--lib" in sys.argv:   # profiling builds only (tools/qmask.sh): an explicit 
     sys.modules["plonky25_amd.binding"].lib_path = sys.argv[i + 1]
     del sys.argv[i:i + 2]
 p25.device_init(0)
-inputs, _ = p25.p3_proof_from_json(open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")).read())
-c = p25.Circuit.build_p3_verifier(p25.P3Config.fib64())
+if "--log-n" in sys.argv:   # another inner trace height (BASELINE config 5: --log-n 20), from the native plonky3 prover
+    i = sys.argv.index("--log-n")
+    inputs, cfg = p25.p3_prove_fibonacci(int(sys.argv[i + 1]), 100, 16, threads=os.cpu_count() or 1)
+    del sys.argv[i:i + 2]
+    c = p25.Circuit.build_p3_verifier(cfg)
+else:
+    inputs, _ = p25.p3_proof_from_json(open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")).read())
+    c = p25.Circuit.build_p3_verifier(p25.P3Config.fib64())
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 c.prove(inputs, seeds=[0])
 if n == 1:  # a lone proof: per-phase device times (and the latency-oriented kernel forms)
