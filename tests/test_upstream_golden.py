@@ -82,3 +82,31 @@ def test_gpu_reproduces_upstream_proof_bytes(gpu, fib_circuit, fib_inputs):
     assert st.tolist() == [0]
     diff = np.nonzero(proofs[0] != want)[0]
     assert diff.size == 0, f"first differing proof words {diff[:8]}"
+
+
+@need
+def test_binary_proof_form_equals_upstream(p25, fib_circuit):
+    """`proof.to_bytes()` of the real crate against p25_proof_to_bytes on the same proof (parsed from its JSON)."""
+    pb, pj = os.path.join(GOLD, "upstream_proof.bin"), os.path.join(GOLD, "upstream_proof.json")
+    if not (os.path.exists(pb) and os.path.exists(pj)):
+        pytest.skip("no upstream binary proof")
+    want = open(pb, "rb").read()
+    flat = flatten_upstream_proof(json.load(open(pj)))
+    assert fib_circuit.proof_to_bytes(flat) == want
+    assert (fib_circuit.proof_from_bytes(want) == flat).all()
+
+
+@need
+@pytest.mark.gpu
+def test_circuit_data_bytes_equal_upstream(gpu, fib_circuit):
+    """`data.to_bytes(..)` of the real crate (length, SHA-256, first 64 KiB) against p25_circuit_to_bytes."""
+    meta, head = os.path.join(GOLD, "upstream_circuit_data.json"), os.path.join(GOLD, "upstream_circuit_data_head.bin")
+    if not (os.path.exists(meta) and os.path.exists(head)):
+        pytest.skip("no upstream CircuitData bytes")
+    import hashlib
+    up = json.load(open(meta))
+    mine = fib_circuit.to_bytes()
+    h = open(head, "rb").read()
+    first = next((i for i, (a, b) in enumerate(zip(mine, h)) if a != b), None)
+    assert first is None, f"CircuitData bytes differ from upstream's at offset {first}"
+    assert len(mine) == up["len"] and hashlib.sha256(mine).hexdigest() == up["sha256"]

@@ -12,6 +12,7 @@
 //! plonky2/src/plonk/prover.rs).  If a later revision hides them, drop the filler file: the other two still pin
 //! the circuit and the verifier semantics.
 mod export_blob; // CircuitData -> libp25 circuit blob
+mod p25_serializers; // the gate / generator serializers of INTEGRATION.md section 5a
 
 use anyhow::Result;
 use plonky2::iop::generator::generate_partial_witness;
@@ -96,6 +97,20 @@ fn main() -> Result<()> {
     let proof = prove_with_partition_witness::<F, C, D>(prover_only, common, partition_witness,
                                                           &mut TimingTree::default())?;
     std::fs::write("upstream_proof.json", serde_json::to_string(&proof)?)?;
+    // the binary forms libp25 restates: ProofWithPublicInputs::to_bytes (p25_proof_to_bytes) and CircuitData::to_bytes
+    // with the serializers of INTEGRATION.md section 5a (p25_circuit_to_bytes / p25_circuit_from_bytes).  The circuit
+    // bytes are ~600 MB; only their length, a SHA-256 and the first 64 KiB (config, FRI params, selectors, gate list,
+    // the head of the generator list) are kept as a fixture.
+    std::fs::write("upstream_proof.bin", proof.to_bytes())?;
+    {
+        use sha2::{Digest, Sha256};
+        let bytes = data.to_bytes(&p25_serializers::P25GateSerializer, &p25_serializers::P25GeneratorSerializer::<C, D>::default())
+            .map_err(|e| anyhow::anyhow!("CircuitData::to_bytes: {e:?}"))?;
+        let head = &bytes[..bytes.len().min(1 << 16)];
+        std::fs::write("upstream_circuit_data_head.bin", head)?;
+        std::fs::write("upstream_circuit_data.json", serde_json::to_string(&json!({
+            "len": bytes.len(), "sha256": format!("{:x}", Sha256::digest(&bytes)), "head_len": head.len() }))?)?;
+    }
     data.verify(proof)?;                                                      // src/p3/mod.rs:266
     // the circuit as libp25 takes it (p25_circuit_import): prove it on the GPU, feed the proof back to data.verify
     std::fs::write("upstream_circuit.p25blob", export_blob::export_p25_blob(&data, &proof_t.flat_targets()))?;   // flat_targets(): the add_virtual_to order, proof.rs:357-373
