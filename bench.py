@@ -52,6 +52,7 @@ def parse_args():
                     help="leaves of the aggregation-tree measurement after the timed region (recursive 2-to-1 verifier "
                          "circuits down to ONE root proof); -1 = 64 on a single GPU, the gathered step otherwise is NOT "
                          "folded (0 = off)")
+    ap.add_argument("--aggregate-arity", type=int, default=8, choices=(2, 4, 8, 16), help="children per aggregation circuit")
     ap.add_argument("--extra-configs", choices=("auto", "none"), default="auto",
                     help="auto: also measure BASELINE configs 2 (single proof) and 5 (2^20-row inner STARK) and report "
                          "them in the `configs` block (N = 1 only)")
@@ -111,38 +112,47 @@ def cpu_model():
     return "unknown"
 
 
-def aggregation_tree(p25, circuit, leaves, verify_root):
+def aggregation_tree(p25, circuit, leaves, verify_root, hash_no_pad, arity=8):
     """North star's "final aggregation step" taken literally: fold `leaves` (flat proofs of `circuit`, a power of two)
-    into ONE root proof with 2-to-1 aggregation circuits (upstream builder.verify_proof for both children + four
-    registered public inputs committing to them), every level a plain batch prove on the GPU.  Returns the per-level
-    record; the root is checked by `verify_root(circuit, proof)` and its public inputs -- the root of a Poseidon tree
-    over hash_no_pad(wires cap) of every leaf proof -- are recomputed from the leaves by the caller."""
+    into ONE root proof with `arity`-to-1 aggregation circuits (upstream builder.verify_proof for every child + four
+    registered public inputs committing to them), every level a plain batch prove on the GPU.  The last levels hold
+    one or two proofs each and cost a full single-proof latency whatever their size, so fewer, larger levels beat
+    many small ones (2-to-1: six levels of 2^14 rows; 8-to-1: two levels of 2^16 rows, the leaf circuit's own size).
+    Returns the per-level record; the root is checked by `verify_root(circuit, proof)`, and its public inputs are
+    recomputed here from the leaves: the Poseidon tree, of the tree's own shape, over hash_no_pad(wires cap) of every
+    leaf proof."""
     import numpy as np
     level, circ, levels, tree_s, build_s = leaves, circuit, [], 0.0, 0.0
+    ids = [hash_no_pad(p[:64]) for p in leaves]      # wires cap = the first 16 x 4 words of a flat proof
     owned = []
     while len(level) > 1:
+        k = min(arity, len(level))
         t = time.perf_counter()
-        nxt = circ.build_aggregator(2)    # a recursive verifier that registers a 4-word commitment to its two proofs
+        nxt = circ.build_aggregator(k)    # a recursive verifier of k proofs that registers a 4-word commitment to them
         nxt.digest()
         bs = time.perf_counter() - t
         build_s += bs
         owned.append(nxt)
-        pairs = np.stack([np.concatenate([level[2 * i], level[2 * i + 1]]) for i in range(len(level) // 2)])
-        nxt.prove(pairs[:min(16, len(pairs))], seeds=list(range(min(16, len(pairs)))))   # warm-up: this circuit's contexts
+        groups = np.stack([np.concatenate(level[k * i:k * (i + 1)]) for i in range(len(level) // k)])
+        ids = [hash_no_pad(np.concatenate(ids[k * i:k * (i + 1)])) for i in range(len(ids) // k)]
+        nxt.prove(groups[:min(16, len(groups))], seeds=list(range(min(16, len(groups)))))   # warm-up: this circuit's contexts
         t = time.perf_counter()
-        level, st = nxt.prove(pairs, seeds=np.arange(len(pairs), dtype=np.uint64))
+        level, st = nxt.prove(groups, seeds=np.arange(len(groups), dtype=np.uint64))
         dt = time.perf_counter() - t
         if not (st == 0).all():
             raise RuntimeError(f"aggregation level {len(levels) + 1}: statuses {st.tolist()}")
         tree_s += dt
-        levels.append({"level": len(levels) + 1, "circuit_rows_log2": int(nxt.info.degree_bits), "proofs": len(level),
-                       "prove_s": round(dt, 4), "circuit_build_s": round(bs, 2)})
+        levels.append({"level": len(levels) + 1, "arity": k, "circuit_rows_log2": int(nxt.info.degree_bits),
+                       "rows_used": int(nxt.info.num_rows_used), "proofs": len(level), "prove_s": round(dt, 4),
+                       "circuit_build_s": round(bs, 2)})
         circ = nxt
     ok = verify_root(circ, level[0])
     root_pis = [int(v) for v in circ.public_inputs(level[0])]
     for c in owned:
         c.close()
-    return {"levels": levels, "root_public_inputs": root_pis, "tree_prove_s": round(tree_s, 4), "tree_circuit_build_s_once_per_shape": round(build_s, 2),
+    return {"levels": levels, "root_public_inputs": root_pis,
+            "root_public_inputs_commit_to_the_leaves": root_pis == [int(v) for v in ids[0]],
+            "tree_prove_s": round(tree_s, 4), "tree_circuit_build_s_once_per_shape": round(build_s, 2),
             "root_proof_words": int(level[0].size), "oracle_verifier_accepts_root": bool(ok)}
 
 
@@ -522,17 +532,13 @@ def main():
             n_agg &= n_agg - 1          # largest power of two
         if n_agg >= 2 and ok:
             try:
-                agg = aggregation_tree(p25, circuit, all_p[:n_agg], verify_with_oracle)
+                agg = aggregation_tree(p25, circuit, [all_p[i] for i in range(n_agg)], verify_with_oracle, ora.hash_no_pad,
+                                       arity=args.aggregate_arity)
                 leaf_s = n_agg / (total_proofs / elapsed)   # the leaves at the measured whole-job rate
-                # the root's public inputs must be the Poseidon tree over hash_no_pad(wires cap) of the leaves
-                lvl = [ora.hash_no_pad(all_p[i][:4 << 4]) for i in range(n_agg)]
-                while len(lvl) > 1:
-                    lvl = [ora.hash_no_pad(np.concatenate([lvl[2 * i], lvl[2 * i + 1]])) for i in range(len(lvl) // 2)]
-                agg["root_public_inputs_commit_to_the_leaves"] = [int(v) for v in lvl[0]] == agg["root_public_inputs"]
                 agg.update({"leaves": n_agg, "leaf_prove_s_at_measured_rate": round(leaf_s, 4),
                             "leaf_equivalent_proofs_per_s_including_aggregation": round(n_agg / (leaf_s + agg["tree_prove_s"]), 2),
                             "note": "leaves = the first proofs of the last timed step (gathered ones when N > 1); tree on rank 0's "
-                                    "GPU; every level is a 2-to-1 aggregation circuit (recursive verifier of both children + 4 public inputs "
+                                    "GPU; every level is an aggregation circuit (recursive verifier of its children + 4 public inputs "
                                     "committing to them) proved as a batch; circuit builds are "
                                     "once per shape and excluded like the reference's build()"})
                 out["aggregation"] = agg

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "16", "--steps", "1", "--warmup", "1",
-                        "--cpu-cores", "4", "--aggregate", "4", "--extra-configs", "none"],
+                        "--cpu-cores", "4", "--aggregate", "4", "--aggregate-arity", "2", "--extra-configs", "none"],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -39,7 +39,7 @@ def test_bench_json_contract():
     assert len(d["config"]["oracle_verified_indices"]) == 8
     # the batch folded to one root proof by the recursive verifier circuits, root accepted by the oracle's verifier
     ag = d["aggregation"]
-    assert ag["leaves"] == 4 and len(ag["levels"]) == 2 and ag["oracle_verifier_accepts_root"] is True
+    assert ag["leaves"] == 4 and [l["arity"] for l in ag["levels"]] == [2, 2] and ag["oracle_verifier_accepts_root"] is True
     assert len(ag["root_public_inputs"]) == 4 and ag["root_public_inputs_commit_to_the_leaves"] is True
     assert ag["leaf_equivalent_proofs_per_s_including_aggregation"] > 0
     # VALU view: priced with the clock measured in the run, and only from a PMC pass of these very kernel sources
