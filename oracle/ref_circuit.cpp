@@ -265,6 +265,27 @@ void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitnes
       out.push_back(od);
       break;
     }
+    case RGEN_RANDOM_ACCESS: {  // upstream RandomAccessGenerator: index, 16 items -> claimed element, 4 bits
+      const u64 idx = d(0);
+      if (idx >= 16) throw std::runtime_error("random access index out of range");
+      out.push_back(d(1 + (int)idx));
+      for (int i = 0; i < 4; i++) out.push_back((idx >> i) & 1);
+      break;
+    }
+    case RGEN_REDUCING:
+    case RGEN_REDUCING_EXT: {  // upstream ReducingGenerator: alpha, old_acc, coefficients -> all accumulators
+      const bool ext = g.kind == RGEN_REDUCING_EXT;
+      const int nco = ext ? 32 : 43;
+      RE2 alpha{d(0), d(1)}, acc{d(2), d(3)};
+      for (int i = 0; i < nco; i++) {
+        acc = re_mul(acc, alpha);
+        acc.a = rf_add(acc.a, d(ext ? 4 + 2 * i : 4 + i));
+        if (ext) acc.b = rf_add(acc.b, d(5 + 2 * i));
+        out.push_back(acc.a);
+        out.push_back(acc.b);
+      }
+      break;
+    }
     default:
       throw std::runtime_error("unknown generator kind");
   }

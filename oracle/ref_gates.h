@@ -272,6 +272,46 @@ static int ref_eval_gate(u32 kind, const F* w, const F* k, const F* pih, F* out)
       for (int i = 0; i < 12; i++) out[nc++] = st[i] - w[12 + i];
       return nc;
     }
+    case RG_RANDOM_ACCESS: {  // upstream gates/random_access.rs eval_unfiltered (bits 4, copies 4, 2 extra constants)
+      const int bits = 4, vec = 16, copies = 4, routed = (2 + vec) * copies + 2;
+      for (int copy = 0; copy < copies; copy++) {
+        const F* cw = w + (2 + vec) * copy;   // access_index, claimed_element, list items
+        const F* bw = w + routed + bits * copy;
+        for (int i = 0; i < bits; i++) out[nc++] = bw[i] * (bw[i] - one);
+        F idx = F::from(0);
+        for (int i = bits - 1; i >= 0; i--) idx = idx.smul(2) + bw[i];
+        out[nc++] = idx - cw[0];
+        F items[16];
+        for (int i = 0; i < vec; i++) items[i] = cw[2 + i];
+        int len = vec;
+        for (int bi = 0; bi < bits; bi++) {
+          len /= 2;
+          for (int i = 0; i < len; i++) items[i] = items[2 * i] + bw[bi] * (items[2 * i + 1] - items[2 * i]);
+        }
+        out[nc++] = items[0] - cw[1];
+      }
+      out[nc++] = k[0] - w[(2 + vec) * copies];
+      out[nc++] = k[1] - w[(2 + vec) * copies + 1];
+      return nc;
+    }
+    case RG_REDUCING:        // upstream gates/reducing.rs: acc * alpha + coeff - next acc, in the D = 2 algebra
+    case RG_REDUCING_EXT: {  // reducing_extension.rs: the same with algebra-valued coefficients
+      const bool ext = kind == RG_REDUCING_EXT;
+      const int nco = ext ? 32 : 43, cw = ext ? 2 : 1, start_accs = 6 + nco * cw;
+      const F al0 = w[2], al1 = w[3];
+      F a0 = w[4], a1 = w[5];
+      for (int i = 0; i < nco; i++) {
+        const int aw = i == nco - 1 ? 0 : start_accs + 2 * i;
+        F t0 = a0 * al0 + (a1 * al1).smul(7) + w[6 + cw * i];
+        F t1 = a0 * al1 + a1 * al0;
+        if (ext) t1 = t1 + w[6 + cw * i + 1];
+        out[nc++] = t0 - w[aw];
+        out[nc++] = t1 - w[aw + 1];
+        a0 = w[aw];
+        a1 = w[aw + 1];
+      }
+      return nc;
+    }
     default:
       return 0;
   }

@@ -25,6 +25,10 @@ static const GateInfo GATE_INFOS[G_NUM_KINDS] = {
     {"Poseidon2Gate { _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<WIDTH=12>", 7, 0, 123, 1},
     {"ArithmeticExtensionGate { num_ops: 10 }", 3, 2, 20, 10},
     {"PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", 7, 0, 123, 1},
+    {"RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>",
+     RA_BITS + 1, RA_EXTRA_CONSTS, RA_COPIES * (RA_BITS + 2) + RA_EXTRA_CONSTS, RA_COPIES},
+    {"ReducingGate { num_coeffs: 43 }", 2, 0, 2 * RED_COEFFS, 1},
+    {"ReducingExtensionGate { num_coeffs: 32 }", 2, 0, 2 * REDX_COEFFS, 1},
 };
 const GateInfo& gate_info(GateKind k) { return GATE_INFOS[k]; }
 
@@ -436,6 +440,37 @@ std::array<Target, 4> CircuitBuilder::hash_or_noop(const std::vector<Target>& in
   return hash_n_to_hash_no_pad(inputs);
 }
 
+// ---------------------------------------------------------------- random access (upstream gadgets/random_access.rs)
+Target CircuitBuilder::random_access(Target access_index, const std::vector<Target>& v) {
+  if (v.size() == 1) return v[0];
+  if ((int)v.size() != RA_VEC) throw std::invalid_argument("random_access: lists of 16 (or 1) elements");
+  Target claimed = add_virtual_target();
+  auto [row, copy] = find_slot(G_RANDOM_ACCESS, 0, 0, 0);
+  const int base = (2 + RA_VEC) * copy;
+  for (int i = 0; i < RA_VEC; i++) connect(v[i], wire(row, base + 2 + i));
+  connect(access_index, wire(row, base));
+  connect(claimed, wire(row, base + 1));
+  return claimed;
+}
+Ext CircuitBuilder::random_access_extension(Target access_index, const std::vector<Ext>& v) {
+  Ext r;
+  for (int d = 0; d < 2; d++) {
+    std::vector<Target> comp;
+    for (const Ext& e : v) comp.push_back(e[d]);
+    r[d] = random_access(access_index, comp);
+  }
+  return r;
+}
+std::array<Target, 4> CircuitBuilder::random_access_hash(Target access_index, const std::vector<std::array<Target, 4>>& v) {
+  std::array<Target, 4> r;
+  for (int i = 0; i < 4; i++) {
+    std::vector<Target> comp;
+    for (const auto& h : v) comp.push_back(h[i]);
+    r[i] = random_access(access_index, comp);
+  }
+  return r;
+}
+
 // ---------------------------------------------------------------- build
 std::vector<int> fri_reduction_arity_bits(const CircuitConfig& cfg, int degree_bits) {
   std::vector<int> r;
@@ -483,7 +518,11 @@ int gate_generator_ops(GateKind k) {
     case G_U32_INTERLEAVE:
     case G_U32_UNINTERLEAVE:
     case G_ARITH_EXT:
+    case G_RANDOM_ACCESS:
       return gate_info(k).num_ops;
+    case G_REDUCING:
+    case G_REDUCING_EXT:
+      return 1;
     default:
       return 0;
   }
@@ -550,6 +589,28 @@ Generator gate_op_generator(GateKind kind, const u64 constants[2], int r, int i)
       for (int k = 0; k < 106; k++) g.outs.push_back(wire(r, 29 + k));   // S-box inputs
       for (int k = 0; k < 12; k++) g.outs.push_back(wire(r, 12 + k));    // outputs
       break;
+    case G_RANDOM_ACCESS: {  // upstream RandomAccessGenerator: the index and the list -> the element and the index bits
+      g.kind = GEN_RANDOM_ACCESS;
+      const int base = (2 + RA_VEC) * i;
+      g.deps.push_back(wire(r, base));
+      for (int k = 0; k < RA_VEC; k++) g.deps.push_back(wire(r, base + 2 + k));
+      g.outs.push_back(wire(r, base + 1));
+      for (int k = 0; k < RA_BITS; k++) g.outs.push_back(wire(r, RA_ROUTED + RA_BITS * i + k));
+      break;
+    }
+    case G_REDUCING:
+    case G_REDUCING_EXT: {  // upstream ReducingGenerator: alpha, old_acc, coefficients -> every accumulator
+      const bool ext = kind == G_REDUCING_EXT;
+      const int nco = ext ? REDX_COEFFS : RED_COEFFS, cw = ext ? 2 : 1, start_accs = 6 + nco * cw;
+      g.kind = ext ? GEN_REDUCING_EXT : GEN_REDUCING;
+      for (int k = 2; k < 6 + nco * cw; k++) g.deps.push_back(wire(r, k));        // alpha, old_acc, coefficients
+      for (int k = 0; k < nco; k++) {
+        const int w0 = k == nco - 1 ? 0 : start_accs + 2 * k;                      // the last accumulator is the output
+        g.outs.push_back(wire(r, w0));
+        g.outs.push_back(wire(r, w0 + 1));
+      }
+      break;
+    }
     default:
       throw std::logic_error("gate_op_generator: gate without generators");
   }

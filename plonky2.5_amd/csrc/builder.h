@@ -64,6 +64,10 @@ enum GateKind : uint8_t {
   // recursion: the gates of upstream's recursive verifier used by recursion.cpp
   G_ARITH_EXT,          // ArithmeticExtensionGate{num_ops: 10}
   G_POSEIDON,           // PoseidonGate (Poseidon v1 permutation with swap; hashes and Merkle paths of inner proofs)
+  // round 3: more of upstream's recursive-verifier gate set (also importable from upstream-built circuits)
+  G_RANDOM_ACCESS,      // RandomAccessGate{bits: 4, num_copies: 4, num_extra_constants: 2}: list[index] of 16 elements
+  G_REDUCING,           // ReducingGate{num_coeffs: 43}: acc_{i+1} = acc_i * alpha + coeff_i, base-field coefficients
+  G_REDUCING_EXT,       // ReducingExtensionGate{num_coeffs: 32}: the same with extension-field coefficients
   G_NUM_KINDS
 };
 struct GateInfo {
@@ -78,6 +82,11 @@ constexpr int MAX_CHUNKS = 16;    // partial-product chunks per challenge (num_p
 constexpr int MAX_PUBLIC_INPUTS = 4096;  // public inputs a circuit may register (hashed by one wave per proof)
 constexpr int BASE_SUM_LIMBS = 63;
 constexpr int EXP_POWER_BITS = 66;
+// the instances of upstream's parameterised gates that `new_from_config` / `max_coeffs_len` give for the standard
+// recursion config (135 wires, 80 routed, 2 constants): RandomAccessGate::new_from_config(config, 4),
+// ReducingGate::max_coeffs_len = min(80 - 6, (135 - 4) / 3), ReducingExtensionGate: min((80 - 6) / 2, (135 - 4) / 4)
+constexpr int RA_BITS = 4, RA_VEC = 16, RA_COPIES = 4, RA_EXTRA_CONSTS = 2, RA_ROUTED = (2 + RA_VEC) * RA_COPIES + RA_EXTRA_CONSTS;
+constexpr int RED_COEFFS = 43, REDX_COEFFS = 32;
 
 enum GenKind : uint32_t {
   GEN_CONSTANT = 0,     // out = c0
@@ -96,6 +105,9 @@ enum GenKind : uint32_t {
   GEN_U32_UNINTERLEAVE, // uninterleave_to_u32.rs:353-390
   GEN_ARITH_EXT,        // ArithmeticExtensionGenerator: out = c0*m0*m1 + c1*addend in F_p^2
   GEN_POSEIDON,         // PoseidonGenerator: deltas, S-box inputs, outputs of one Poseidon permutation
+  GEN_RANDOM_ACCESS,    // RandomAccessGenerator: index, 16 items -> claimed element, 4 index bits
+  GEN_REDUCING,         // ReducingGenerator: alpha, old_acc (ext), 43 base coefficients -> 43 accumulators (ext)
+  GEN_REDUCING_EXT,     // ReducingGenerator of the extension gate: 32 ext coefficients -> 32 accumulators
   GEN_NUM_KINDS
 };
 struct Generator {
@@ -219,6 +231,12 @@ class CircuitBuilder {
   Ext inverse_extension(Ext y) { return div_extension(one_extension(), y); }
   void connect_extension(Ext a, Ext b) { connect(a[0], b[0]); connect(a[1], b[1]); }
   Ext select_ext(BoolTarget b, Ext x, Ext y);
+
+  // ---- upstream gadgets/random_access.rs: v[access_index] through a RandomAccessGate (16-element lists; a list of
+  // one element is returned as is)
+  Target random_access(Target access_index, const std::vector<Target>& v);
+  Ext random_access_extension(Target access_index, const std::vector<Ext>& v);
+  std::array<Target, 4> random_access_hash(Target access_index, const std::vector<std::array<Target, 4>>& v);
 
   // ---- Poseidon (v1) in-circuit: upstream gates/poseidon.rs + hash/poseidon.rs `permute_swapped` ----
   std::array<Target, 12> poseidon_permute_swapped(const std::array<Target, 12>& in, BoolTarget swap);

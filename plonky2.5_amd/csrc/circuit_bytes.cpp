@@ -48,8 +48,8 @@ enum : uint32_t {
 };
 struct GateTag {
   uint32_t tag;
-  int has_param;   // a single usize payload (num_ops / num_limbs / num_consts / num_power_bits)
-  u64 param;
+  int has_param;   // 1: a single usize payload (num_ops / num_limbs / num_consts / num_power_bits / num_coeffs);
+  u64 param;       // 3: RandomAccessGate's three (bits, num_copies, num_extra_constants)
 };
 GateTag gate_tag(GateKind k) {
   switch (k) {
@@ -66,6 +66,9 @@ GateTag gate_tag(GateKind k) {
     case G_POSEIDON2: return {T_POSEIDON2, 0, 0};
     case G_ARITH_EXT: return {T_ARITH_EXT, 1, (u64)gate_info(k).num_ops};
     case G_POSEIDON: return {T_POSEIDON, 0, 0};
+    case G_RANDOM_ACCESS: return {T_RANDOM_ACCESS, 3, (u64)RA_BITS};
+    case G_REDUCING: return {T_REDUCING, 1, (u64)RED_COEFFS};
+    case G_REDUCING_EXT: return {T_REDUCING_EXT, 1, (u64)REDX_COEFFS};
     default: throw std::logic_error("gate kind without a serializer tag");
   }
 }
@@ -288,6 +291,20 @@ void write_generator(W& w, const Circuit& c, const Generator& g) {
       w.usize(row_of(g.deps[0]));
       w.usize((u64)g.deps[0].col / 3);
       break;
+    case GEN_RANDOM_ACCESS:   // upstream RandomAccessGenerator { row, gate, copy }: row, copy, gate.serialize
+      w.u32(GT_RANDOM_ACCESS);
+      w.usize(row_of(g.deps[0]));
+      w.usize((u64)g.deps[0].col / (2 + RA_VEC));
+      w.usize(RA_BITS);
+      w.usize(RA_COPIES);
+      w.usize(RA_EXTRA_CONSTS);
+      break;
+    case GEN_REDUCING:        // upstream ReducingGenerator { row, gate }: row, gate.serialize
+    case GEN_REDUCING_EXT:
+      w.u32(g.kind == GEN_REDUCING ? GT_REDUCING : GT_REDUCING_EXT);
+      w.usize(row_of(g.deps[0]));
+      w.usize(g.kind == GEN_REDUCING ? (u64)RED_COEFFS : (u64)REDX_COEFFS);
+      break;
     default:
       throw std::logic_error("generator kind without a serializer tag");
   }
@@ -339,6 +356,10 @@ std::vector<uint8_t> circuit_data_to_bytes(const Circuit& c, const CircuitCommit
     GateTag t = gate_tag(k);
     w.u32(t.tag);
     if (t.has_param) w.usize(t.param);
+    if (t.has_param == 3) {
+      w.usize(RA_COPIES);
+      w.usize(RA_EXTRA_CONSTS);
+    }
   }
   // ---- ProverOnlyCircuitData
   w.usize(c.generators.size());
@@ -536,6 +557,8 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
       if (kind == G_NUM_KINDS) R::bad("a gate type this library has no evaluator for");
       GateTag t = gate_tag(kind);
       if (t.has_param && r.usize() != t.param) R::bad("a gate with parameters this library does not support");
+      if (t.has_param == 3 && (r.usize() != (u64)RA_COPIES || r.usize() != (u64)RA_EXTRA_CONSTS))
+        R::bad("a RandomAccessGate other than new_from_config(standard_recursion_config, 4)");
       c.gates.push_back(kind);
     }
   }
@@ -561,6 +584,8 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
       case GT_EXPONENTIATION: r.skip(16); break;
       case GT_POSEIDON: case GT_POSEIDON2: r.skip(8); break;
       case GT_U32_ARITHMETIC: case GT_U32_INTERLEAVE: case GT_U32_UNINTERLEAVE: r.skip(24); break;
+      case GT_RANDOM_ACCESS: r.skip(40); break;
+      case GT_REDUCING: case GT_REDUCING_EXT: r.skip(16); break;
       default: R::bad("a generator type this library has no body for");
     }
   }
@@ -771,6 +796,25 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
           u64 op = g.usize_max((u64)gate_info(gk).num_ops - 1, "op index");
           u64 k[2] = {0, 0};
           gen = gate_op_generator(gk, k, row, (int)op);
+          break;
+        }
+        case GT_RANDOM_ACCESS: {
+          int row = row_kind(g.usize(), G_RANDOM_ACCESS, "RandomAccessGenerator outside its gate");
+          u64 copy = g.usize_max(RA_COPIES - 1, "copy index");
+          if (g.usize() != (u64)RA_BITS || g.usize() != (u64)RA_COPIES || g.usize() != (u64)RA_EXTRA_CONSTS) R::bad("RandomAccessGate shape");
+          u64 k[2] = {0, 0};
+          gen = gate_op_generator(G_RANDOM_ACCESS, k, row, (int)copy);
+          break;
+        }
+        case GT_REDUCING:
+        case GT_REDUCING_EXT: {
+          g.off -= 4;
+          const bool ext = g.u32() == GT_REDUCING_EXT;
+          const GateKind gk = ext ? G_REDUCING_EXT : G_REDUCING;
+          int row = row_kind(g.usize(), gk, "ReducingGenerator outside its gate");
+          if (g.usize() != (u64)(ext ? REDX_COEFFS : RED_COEFFS)) R::bad("reducing gate num_coeffs");
+          u64 k[2] = {0, 0};
+          gen = gate_op_generator(gk, k, row, 0);
           break;
         }
         default:

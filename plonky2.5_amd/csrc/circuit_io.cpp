@@ -43,6 +43,9 @@ bool generator_shape_ok(GenKind k, size_t nd, size_t no, int aux) {
     case GEN_U32_ARITHMETIC: return nd == 3 && no == 35;
     case GEN_U32_INTERLEAVE: return nd == 1 && no == 33;
     case GEN_U32_UNINTERLEAVE: return nd == 1 && no == 66;
+    case GEN_RANDOM_ACCESS: return nd == 1 + RA_VEC && no == 1 + RA_BITS;
+    case GEN_REDUCING: return nd == 4 + RED_COEFFS && no == 2 * RED_COEFFS;
+    case GEN_REDUCING_EXT: return nd == 4 + 2 * REDX_COEFFS && no == 2 * REDX_COEFFS;
     default: return false;
   }
 }
@@ -172,7 +175,8 @@ Circuit circuit_from_blob(const uint8_t* data, size_t len) {
     }
     // the evaluators index a row's wires by fixed column numbers
     static const int MIN_WIRES[G_NUM_KINDS] = {0, 2, 4, 1 + BASE_SUM_LIMBS, 6 + 96, 6 + 128, 80, 78, 2 + 2 * EXP_POWER_BITS,
-                                               18 + 96, 135, 80, 135};
+                                               18 + 96, 135, 80, 135, RA_ROUTED + RA_BITS * RA_COPIES,
+                                               4 + 3 * RED_COEFFS, 4 + 4 * REDX_COEFFS};
     for (GateKind k : c.gates)
       if (MIN_WIRES[k] > c.cfg.num_wires) bad("a gate needs more wires than the circuit has");
   }

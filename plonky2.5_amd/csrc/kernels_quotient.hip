@@ -299,6 +299,52 @@ __device__ void gate_arith_ext(Ctx& cx, u64 k0, u64 k1) {
     cx.at(2 * i + 1, gl::sub(cx.w(8 * i + 7), r.b));
   }
 }
+// upstream gates/random_access.rs eval_unfiltered_base_one: per copy the index bits are boolean and recompose the
+// index, and folding the list by them (x + b (y - x) on adjacent pairs, least significant bit first) leaves the
+// claimed element; then the extra constant wires equal the row's constants.
+__device__ void gate_random_access(Ctx& cx, u64 k0, u64 k1) {
+  int nc = 0;
+  for (int copy = 0; copy < RA_COPIES; copy++) {
+    const int base = (2 + RA_VEC) * copy;
+    u64 bits[RA_BITS];
+    for (int i = 0; i < RA_BITS; i++) {
+      bits[i] = cx.w(RA_ROUTED + RA_BITS * copy + i);
+      cx.at(nc++, gl::mul_nc(bits[i], gl::sub(bits[i], 1)));
+    }
+    u64 idx = 0;
+    for (int i = RA_BITS - 1; i >= 0; i--) idx = gl::add(gl::add(idx, idx), bits[i]);
+    cx.at(nc++, gl::sub(idx, cx.w(base)));
+    u64 items[RA_VEC];
+    for (int i = 0; i < RA_VEC; i++) items[i] = cx.w(base + 2 + i);
+    int len = RA_VEC;
+    for (int bi = 0; bi < RA_BITS; bi++) {
+      len >>= 1;
+      for (int i = 0; i < len; i++)
+        items[i] = gl::add(items[2 * i], gl::mul(bits[bi], gl::sub(items[2 * i + 1], items[2 * i])));
+    }
+    cx.at(nc++, gl::sub(items[0], cx.w(base + 1)));
+  }
+  cx.at(nc++, gl::sub(k0, cx.w((2 + RA_VEC) * RA_COPIES)));
+  cx.at(nc++, gl::sub(k1, cx.w((2 + RA_VEC) * RA_COPIES + 1)));
+}
+// upstream gates/reducing.rs / reducing_extension.rs: acc_i = acc_{i-1} * alpha + coeff_i in the extension field
+// (old_acc first, the last accumulator is the output pair at wires 0, 1); two base-field constraints per step.
+template <bool EXT>
+__device__ void gate_reducing(Ctx& cx) {
+  constexpr int NCO = EXT ? REDX_COEFFS : RED_COEFFS, CW = EXT ? 2 : 1, START_ACCS = 6 + NCO * CW;
+  const gl::E2 alpha{cx.w(2), cx.w(3)};
+  gl::E2 acc{cx.w(4), cx.w(5)};
+  for (int i = 0; i < NCO; i++) {
+    const int aw = i == NCO - 1 ? 0 : START_ACCS + 2 * i;
+    const gl::E2 nxt{cx.w(aw), cx.w(aw + 1)};
+    gl::E2 t = gl::mul(acc, alpha);
+    t.a = gl::add(t.a, cx.w(6 + CW * i));
+    if (EXT) t.b = gl::add(t.b, cx.w(6 + CW * i + 1));
+    cx.at(2 * i, gl::sub(t.a, nxt.a));
+    cx.at(2 * i + 1, gl::sub(t.b, nxt.b));
+    acc = nxt;
+  }
+}
 // upstream gates/poseidon.rs eval_unfiltered_base_one (rounds in the defining form; same constraint polynomials as
 // upstream's fast partial rounds, which are a linear change of basis on lanes 1..11)
 __device__ void gate_poseidon(Ctx& cx) {
@@ -462,6 +508,15 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
         case G_POSEIDON:
           if constexpr (REC) gate_poseidon(cx);
           break;
+        case G_RANDOM_ACCESS:
+          if constexpr (REC) gate_random_access(cx, k0, k1);
+          break;
+        case G_REDUCING:
+          if constexpr (REC) gate_reducing<false>(cx);
+          break;
+        case G_REDUCING_EXT:
+          if constexpr (REC) gate_reducing<true>(cx);
+          break;
         default: break;  // NoopGate: no constraints
       }
       g0 = gl::add(g0, gl::mul(filter, cx.acc0()));
@@ -510,7 +565,7 @@ void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
       throw std::runtime_error("quotient: gate with too many constraints for the alpha-power table");
   const size_t big = (size_t)1 << (a.degree_bits + a.rate_bits);
   bool rec = false;
-  for (uint32_t gi = 0; gi < a.n_gates; gi++) rec |= a.gates[gi].kind == G_ARITH_EXT || a.gates[gi].kind == G_POSEIDON;
+  for (uint32_t gi = 0; gi < a.n_gates; gi++) rec |= a.gates[gi].kind >= G_ARITH_EXT;   // the recursion gate set
   if (rec)
     hipLaunchKernelGGL(k_quotient_rec, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
   else

@@ -170,6 +170,31 @@ __device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* 
       for (int i = 0; i < 12; i++) emit(4 + 106 + i, st[i]);
       break;
     }
+    case GEN_RANDOM_ACCESS: {  // upstream RandomAccessGenerator::run_once
+      const u64 idx = d(0);
+      if (idx >= (u64)RA_VEC) {  // upstream: debug_assert!(access_index < vec_size) / out-of-bounds panic
+        set_status(status + p, 7);
+        break;
+      }
+      emit(0, d(1 + (int)idx));
+      for (int i = 0; i < RA_BITS; i++) emit(1 + i, (idx >> i) & 1);
+      break;
+    }
+    case GEN_REDUCING:
+    case GEN_REDUCING_EXT: {  // upstream ReducingGenerator::run_once: acc = acc * alpha + coeff, every accumulator set
+      const bool ext = g.kind == GEN_REDUCING_EXT;
+      const int nco = ext ? REDX_COEFFS : RED_COEFFS;
+      const gl::E2 alpha{d(0), d(1)};
+      gl::E2 acc{d(2), d(3)};
+      for (int i = 0; i < nco; i++) {
+        acc = gl::mul(acc, alpha);
+        acc.a = gl::add(acc.a, d(ext ? 4 + 2 * i : 4 + i));
+        if (ext) acc.b = gl::add(acc.b, d(5 + 2 * i));
+        emit(2 * i, acc.a);
+        emit(2 * i + 1, acc.b);
+      }
+      break;
+    }
     case GEN_U32_ARITHMETIC: {
       u64 o = gl::add(gl::mul(d(0), d(1)), d(2));
       u64 hi = o >> 32, lo = o & 0xFFFFFFFFull;

@@ -1,5 +1,6 @@
 // See recursion.h.
 #include "recursion.h"
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include "poseidon.h"
@@ -10,16 +11,46 @@ namespace p25 {
 namespace {
 
 // ---------------------------------------------------------------- small helpers (upstream util/reducing.rs semantics)
-// sum_i base^i * terms[i]  (ReducingFactorTarget::reduce; Horner from the last term)
+// sum_i base^i * terms[i]: upstream ReducingFactorTarget::reduce -- up to num_ops + 1 terms as a Horner chain on
+// ArithmeticExtensionGate operations (`reduce_arithmetic`), longer lists on ReducingExtensionGate rows of 32
+// coefficients each (terms reversed and zero-padded to whole rows, every row's old_acc wired to the previous output).
 Ext reduce_ext(CircuitBuilder& b, const std::vector<Ext>& terms, Ext base) {
+  if ((int)terms.size() <= gate_info(G_ARITH_EXT).num_ops + 1) {
+    Ext acc = b.zero_extension();
+    for (size_t i = terms.size(); i-- > 0;) acc = b.mul_add_extension(base, acc, terms[i]);
+    return acc;
+  }
+  std::vector<Ext> rev(terms);
+  while (rev.size() % REDX_COEFFS) rev.push_back(b.zero_extension());
+  std::reverse(rev.begin(), rev.end());
   Ext acc = b.zero_extension();
-  for (size_t i = terms.size(); i-- > 0;) acc = b.mul_add_extension(acc, base, terms[i]);
+  for (size_t off = 0; off < rev.size(); off += REDX_COEFFS) {
+    const int row = b.add_gate(G_REDUCING_EXT);
+    b.connect_extension(base, Ext{wire(row, 2), wire(row, 3)});
+    b.connect_extension(acc, Ext{wire(row, 4), wire(row, 5)});
+    for (int i = 0; i < REDX_COEFFS; i++) b.connect_extension(rev[off + i], Ext{wire(row, 6 + 2 * i), wire(row, 7 + 2 * i)});
+    acc = Ext{wire(row, 0), wire(row, 1)};
+  }
   return acc;
 }
-// the same for base-field terms (ReducingFactorTarget::reduce_base)
+// the same for base-field terms (ReducingFactorTarget::reduce_base: ReducingGate rows of 43 coefficients)
 Ext reduce_base(CircuitBuilder& b, const std::vector<Target>& terms, Ext base) {
+  if ((int)terms.size() <= gate_info(G_ARITH_EXT).num_ops + 1) {
+    Ext acc = b.zero_extension();
+    for (size_t i = terms.size(); i-- > 0;) acc = b.mul_add_extension(base, acc, b.convert_to_ext(terms[i]));
+    return acc;
+  }
+  std::vector<Target> rev(terms);
+  while (rev.size() % RED_COEFFS) rev.push_back(b.zero());
+  std::reverse(rev.begin(), rev.end());
   Ext acc = b.zero_extension();
-  for (size_t i = terms.size(); i-- > 0;) acc = b.mul_add_extension(acc, base, b.convert_to_ext(terms[i]));
+  for (size_t off = 0; off < rev.size(); off += RED_COEFFS) {
+    const int row = b.add_gate(G_REDUCING);
+    b.connect_extension(base, Ext{wire(row, 2), wire(row, 3)});
+    b.connect_extension(acc, Ext{wire(row, 4), wire(row, 5)});
+    for (int i = 0; i < RED_COEFFS; i++) b.connect(rev[off + i], wire(row, 6 + i));
+    acc = Ext{wire(row, 0), wire(row, 1)};
+  }
   return acc;
 }
 // reduce_with_powers_ext_circuit(terms, alpha: Target)
@@ -235,6 +266,49 @@ std::vector<Ext> eval_gate_circuit(CircuitBuilder& b, GateKind kind, const std::
       for (int i = 0; i < 12; i++) c.push_back(b.sub_extension(st[i], w[12 + i]));
       break;
     }
+    case G_RANDOM_ACCESS: {  // upstream gates/random_access.rs eval_unfiltered_circuit
+      const Ext zero = b.zero_extension(), two = cext(b, 2);
+      for (int copy = 0; copy < RA_COPIES; copy++) {
+        const int base = (2 + RA_VEC) * copy;
+        std::vector<Ext> bits, items;
+        for (int i = 0; i < RA_BITS; i++) bits.push_back(w[RA_ROUTED + RA_BITS * copy + i]);
+        for (int i = 0; i < RA_VEC; i++) items.push_back(w[base + 2 + i]);
+        for (const Ext& bt : bits) c.push_back(b.mul_sub_extension(bt, bt, bt));
+        Ext idx = zero;
+        for (int i = RA_BITS - 1; i >= 0; i--) idx = b.mul_add_extension(idx, two, bits[i]);
+        c.push_back(b.sub_extension(idx, w[base]));
+        for (const Ext& bt : bits) {   // select_ext_generalized(bit, y, x) on adjacent pairs
+          std::vector<Ext> nxt;
+          for (size_t i = 0; i + 1 < items.size(); i += 2) {
+            Ext tmp = b.mul_sub_extension(bt, items[i], items[i]);
+            nxt.push_back(b.mul_sub_extension(bt, items[i + 1], tmp));
+          }
+          items.swap(nxt);
+        }
+        c.push_back(b.sub_extension(items[0], w[base + 1]));
+      }
+      for (int i = 0; i < RA_EXTRA_CONSTS; i++) c.push_back(b.sub_extension(k[i], w[(2 + RA_VEC) * RA_COPIES + i]));
+      break;
+    }
+    case G_REDUCING:
+    case G_REDUCING_EXT: {  // upstream gates/reducing{,_extension}.rs eval_unfiltered_circuit: acc * alpha + coeff - next acc
+      const bool ext = kind == G_REDUCING_EXT;                       // in the algebra F_ext[X]/(X^2 - 7) over wire pairs
+      const int nco = ext ? REDX_COEFFS : RED_COEFFS, cw = ext ? 2 : 1, start_accs = 6 + nco * cw;
+      const Ext al0 = w[2], al1 = w[3];
+      Ext a0 = w[4], a1 = w[5];
+      for (int i = 0; i < nco; i++) {
+        const int aw = i == nco - 1 ? 0 : start_accs + 2 * i;
+        // (a0 + a1 X)(al0 + al1 X) + coeff
+        Ext t0 = b.mul_add_extension(a0, al0, b.mul_const_add_extension(7, b.mul_extension(a1, al1), w[6 + cw * i]));
+        Ext t1 = b.mul_add_extension(a0, al1, b.mul_extension(a1, al0));
+        if (ext) t1 = b.add_extension(t1, w[6 + cw * i + 1]);
+        c.push_back(b.sub_extension(t0, w[aw]));
+        c.push_back(b.sub_extension(t1, w[aw + 1]));
+        a0 = w[aw];
+        a1 = w[aw + 1];
+      }
+      break;
+    }
     case G_POSEIDON: {  // upstream gates/poseidon.rs eval_unfiltered_circuit, rounds in the defining form: the MDS layer
                         // as mul_const_add chains on ArithmeticExtensionGate ops (upstream routes it through PoseidonMdsGate)
       Ext swap = w[24];
@@ -445,7 +519,7 @@ ProofTargets add_virtual_proof(CircuitBuilder& b, const Circuit& c) {
 // upstream hash/merkle_proofs.rs verify_merkle_proof_to_cap_with_cap_index; the cap entry is selected with a
 // one-hot vector of the cap index (instead of upstream's RandomAccessGate).
 void verify_merkle_proof_to_cap(CircuitBuilder& b, const std::vector<Target>& leaf, const std::vector<BoolTarget>& index_bits,
-                                const std::vector<Target>& cap_onehot, const std::vector<Hash>& cap,
+                                Target cap_index, const std::vector<Target>& cap_onehot, const std::vector<Hash>& cap,
                                 const std::vector<Hash>& siblings) {
   Hash state = b.hash_or_noop(leaf);
   if (siblings.size() > index_bits.size()) throw std::logic_error("merkle: more siblings than index bits");
@@ -459,7 +533,13 @@ void verify_merkle_proof_to_cap(CircuitBuilder& b, const std::vector<Target>& le
     auto out = b.poseidon_permute_swapped(in, index_bits[k]);
     state = Hash{out[0], out[1], out[2], out[3]};
   }
-  for (int i = 0; i < 4; i++) {
+  if ((int)cap.size() == RA_VEC || cap.size() == 1) {
+    // upstream: `let state_cap = self.random_access_hash(cap_index, merkle_cap.0.clone()); connect_hashes(state, ..)`
+    Hash sel = b.random_access_hash(cap_index, cap);
+    for (int i = 0; i < 4; i++) b.connect(sel[i], state[i]);
+    return;
+  }
+  for (int i = 0; i < 4; i++) {   // caps of other sizes (no RandomAccessGate instance for them here): one-hot select
     Target sel = b.zero();
     for (size_t k = 0; k < cap.size(); k++) sel = b.mul_add(cap_onehot[k], cap[k][i], sel);
     b.connect(sel, state[i]);
@@ -601,8 +681,11 @@ ProofTargets verify_one(CircuitBuilder& b, const Circuit& c, const Hash& digest,
     std::vector<BoolTarget> all_bits = b.split_le(query_indices[qi], 64);           // low_bits(x, n_log, 64)
     std::vector<BoolTarget> x_bits(all_bits.begin(), all_bits.begin() + lde_bits);
     std::vector<BoolTarget> cap_bits(x_bits.end() - c.cfg.cap_height, x_bits.end());
-    const std::vector<Target> cap_onehot = one_hot(b, cap_bits);
-    for (int o = 0; o < 4; o++) verify_merkle_proof_to_cap(b, q.leaf[o], x_bits, cap_onehot, *caps[o], q.path[o]);
+    // "let cap_index = self.le_sum(x_index_bits[x_index_bits.len() - params.config.cap_height..].iter())"
+    const Target cap_index = b.le_sum(cap_bits);
+    const bool ra_cap = (1 << c.cfg.cap_height) == RA_VEC || c.cfg.cap_height == 0;
+    const std::vector<Target> cap_onehot = ra_cap ? std::vector<Target>() : one_hot(b, cap_bits);
+    for (int o = 0; o < 4; o++) verify_merkle_proof_to_cap(b, q.leaf[o], x_bits, cap_index, cap_onehot, *caps[o], q.path[o]);
     // subgroup_x = g * phi^rev(x_index): the point of the LDE coset this leaf sits at
     std::vector<BoolTarget> rev_bits(x_bits.rbegin(), x_bits.rend());
     Target subgroup_x = b.mul(b.constant(gl::GENERATOR), exp_from_bits_const_base(b, gl::root_of_unity(lde_bits), rev_bits));
@@ -628,7 +711,11 @@ ProofTargets verify_one(CircuitBuilder& b, const Circuit& c, const Hash& digest,
       std::vector<BoolTarget> within(idx_bits.begin(), idx_bits.begin() + ab);
       std::vector<BoolTarget> coset_bits(idx_bits.begin() + ab, idx_bits.end());
       // consistency with the previous layer: evals[x_index_within_coset] == old_eval  (random_access_extension)
-      {
+      if (arity == RA_VEC) {
+        // "let x_index_within_coset = self.le_sum(..); let new_eval = self.random_access_extension(x_index_within_coset, evals.clone())"
+        const Target within_index = b.le_sum(within);
+        b.connect_extension(b.random_access_extension(within_index, evals), old_eval);
+      } else {
         std::vector<Target> oh = one_hot(b, within);
         Ext sel = b.zero_extension();
         for (int k = 0; k < arity; k++) sel = b.mul_add_extension(b.convert_to_ext(oh[k]), evals[k], sel);
@@ -663,7 +750,7 @@ ProofTargets verify_one(CircuitBuilder& b, const Circuit& c, const Hash& digest,
         flat.push_back(e[0]);
         flat.push_back(e[1]);
       }
-      verify_merkle_proof_to_cap(b, flat, coset_bits, cap_onehot, p.fri_caps[l], q.step_path[l]);
+      verify_merkle_proof_to_cap(b, flat, coset_bits, cap_index, cap_onehot, p.fri_caps[l], q.step_path[l]);
       subgroup_x = b.exp_power_of_2(subgroup_x, ab);
       idx_bits = coset_bits;
     }

@@ -15,11 +15,13 @@
 //    plonk/vanishing_poly.rs `eval_vanishing_poly_circuit`, iop/challenger.rs `RecursiveChallenger`,
 //    hash/merkle_proofs.rs `verify_merkle_proof_to_cap_with_cap_index`, fri/recursive_verifier.rs).
 //
-// DEVIATION (documented in DESIGN.md): upstream's recursive verifier also uses RandomAccessGate, ReducingGate,
-// ReducingExtensionGate and CosetInterpolationGate.  Here the same checks are expressed with ArithmeticGate /
-// ArithmeticExtensionGate / MulExtensionGate operations (select trees, Horner chains, barycentric interpolation),
-// so the circuit is a valid plonky2 circuit with upstream-standard gates only, but it is NOT row-for-row the
-// circuit `builder.verify_proof::<C>()` would emit (same statement, ~2^13 rows per inner fib-64 proof).
+// Gate set (round 3): cap entries and the evaluation compared at every FRI layer are selected with RandomAccessGate,
+// reductions with powers of a challenge run on ReducingGate / ReducingExtensionGate -- as upstream's verifier does.
+// DEVIATION (documented in DESIGN.md): upstream also uses CosetInterpolationGate (here: the barycentric formula on
+// arithmetic gates) and, when PoseidonGate is evaluated in-circuit, PoseidonMdsGate (here: multiply-add chains); and
+// upstream hands the RandomAccessGate's two extra constant wires to its constant allocator, this builder does not.
+// So the circuit uses upstream-standard gates only and proves the same statement, but it is NOT row-for-row the
+// circuit `builder.verify_proof::<C>()` would emit (5,464 rows per inner fib-64 proof).
 #pragma once
 #include <vector>
 #include "builder.h"

@@ -15,7 +15,7 @@ from conftest import P, splitmix_field
 
 GATES = {1: "Constant", 2: "PublicInput", 3: "BaseSum", 4: "U32Interleave", 5: "UninterleaveToU32", 6: "Arithmetic",
          7: "MulExtension", 8: "Exponentiation", 9: "U32Arithmetic", 10: "Poseidon2", 11: "ArithmeticExtension",
-         12: "Poseidon"}
+         12: "Poseidon", 13: "RandomAccess", 14: "Reducing", 15: "ReducingExtension"}
 
 
 @pytest.mark.parametrize("kind", sorted(GATES))
@@ -48,7 +48,7 @@ def test_eval_fns_base_extension_and_circuit_agree(p25, oracle, kind):
 
 
 def test_gate_eval_rejects_gates_without_evaluator(p25):
-    for kind in (13, 99, -1):
+    for kind in (16, 99, -1):
         with pytest.raises(p25.P25Error):
             p25.Circuit.build_gate_eval(kind)
 
@@ -73,6 +73,10 @@ def test_recursive_verifier_of_a_small_circuit(p25, oracle, small_recursion):
     assert int(outer.info.num_inputs) == int(inner.info.proof_words)
     counts = outer.gate_counts()
     assert any(k.startswith("PoseidonGate") for k in counts) and "ArithmeticExtensionGate { num_ops: 10 }" in counts
+    # upstream's verifier gate set (round 3): cap / evaluation selection on RandomAccessGate, reductions with powers of
+    # alpha on ReducingGate (base-field terms) and ReducingExtensionGate (extension terms)
+    assert any(k.startswith("RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2") for k in counts)
+    assert "ReducingGate { num_coeffs: 43 }" in counts and "ReducingExtensionGate { num_coeffs: 32 }" in counts
     oo = oracle.load_circuit(outer.to_blob())
     wires, st, msg = oo.witness(proof, seed=9)
     assert st == 0, msg
