@@ -164,7 +164,8 @@ p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** o
  * with every gate's `eval_unfiltered_circuit` (the reference's: poseidon2_gate.rs:312-397,
  * arithmetic_u32.rs:178-245, interleave_u32.rs:143-189, uninterleave_to_u32.rs:164-228), and the FRI verifier
  * (PoW, Merkle paths, folding; cap entries and the evaluation checked at every FRI layer are selected with
- * RandomAccessGate, reductions with powers of alpha run on ReducingGate / ReducingExtensionGate as upstream's do).
+ * RandomAccessGate, reductions with powers of alpha run on ReducingGate / ReducingExtensionGate, a layer's fold is
+ * one CosetInterpolationGate row, as in upstream's verifier).
  * Inputs of the new circuit = the inner proofs' words in the flat layout below, concatenated.  digest4 / cs_cap: the inner circuit's verifier data, baked in as constants; pass NULL to have them
  * computed on the GPU (p25_circuit_digest).  Gate set: upstream-standard gates only, but not row-for-row upstream's
  * circuit (plonky2.5_amd/csrc/recursion.h).  A false inner proof fails with P25_ERR_WITNESS_CONFLICT. */
@@ -175,8 +176,8 @@ p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64
  * expected value of every constraint as extension elements; the circuit evaluates gate `kind` in-circuit
  * (`eval_unfiltered_circuit`) and connects each constraint to its expectation.  kind: 1 Constant 2 PublicInput
  * 3 BaseSum 4 U32Interleave 5 UninterleaveToU32 6 Arithmetic 7 MulExtension 8 Exponentiation 9 U32Arithmetic
- * 10 Poseidon2 11 ArithmeticExtension 12 Poseidon 13 RandomAccess 14 Reducing 15 ReducingExtension (the `kind`
- * numbering of the circuit blob). */
+ * 10 Poseidon2 11 ArithmeticExtension 12 Poseidon 13 RandomAccess 14 Reducing 15 ReducingExtension
+ * 16 CosetInterpolation (the `kind` numbering of the circuit blob). */
 p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out);
 /* p25_circuit_build_recursive_verifier whose circuit also REGISTERS FOUR PUBLIC INPUTS (upstream
  * `builder.register_public_inputs`): hash_no_pad over the identifiers of the proofs it verifies, a proof's identifier

@@ -286,6 +286,34 @@ void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitnes
       }
       break;
     }
+    case RGEN_COSET_INTERP: {  // upstream InterpolationGenerator: shift, 16 values, point -> shifted point, states, value
+      const u64 shift = d(0);
+      const RE2 x = re_muls(RE2{d(33), d(34)}, rf_inv(shift));
+      out.push_back(x.a);
+      out.push_back(x.b);
+      const u64 gen = rf_root_of_unity(4), inv16 = rf_inv(16);
+      RE2 eval{0, 0}, prod{1, 0};
+      u64 xi = 1;
+      for (int c = 0; c < 3; c++) {
+        if (c > 0) {
+          out.push_back(eval.a);
+          out.push_back(eval.b);
+          out.push_back(prod.a);
+          out.push_back(prod.b);
+        }
+        const int begin = c == 0 ? 0 : 1 + 5 * c, end = c == 0 ? 6 : (1 + 5 * (c + 1) < 16 ? 1 + 5 * (c + 1) : 16);
+        for (int i = begin; i < end; i++) {
+          const RE2 v = re_muls(RE2{d(1 + 2 * i), d(2 + 2 * i)}, rf_mul(xi, inv16));
+          const RE2 term{rf_sub(x.a, xi), x.b};
+          eval = re_add(re_mul(eval, term), re_mul(v, prod));
+          prod = re_mul(prod, term);
+          xi = rf_mul(xi, gen);
+        }
+      }
+      out.push_back(eval.a);
+      out.push_back(eval.b);
+      break;
+    }
     default:
       throw std::runtime_error("unknown generator kind");
   }

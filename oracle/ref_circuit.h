@@ -15,13 +15,15 @@ enum RGate {  // numbering = blob encoding
   RG_RANDOM_ACCESS,   // RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2 }
   RG_REDUCING,        // ReducingGate { num_coeffs: 43 }
   RG_REDUCING_EXT,    // ReducingExtensionGate { num_coeffs: 32 }
+  RG_COSET_INTERP,    // CosetInterpolationGate { subgroup_bits: 4, degree: 6, .. }
   RG_NUM
 };
 enum RGen {
   RGEN_CONSTANT = 0, RGEN_RANDOM, RGEN_ARITHMETIC, RGEN_MUL_EXT, RGEN_QUOTIENT_EXT, RGEN_BASE_SPLIT,
   RGEN_WIRE_SPLIT, RGEN_BASE_SUM, RGEN_LOW_HIGH, RGEN_EXPONENTIATION, RGEN_POSEIDON2,
   RGEN_U32_ARITHMETIC, RGEN_U32_INTERLEAVE, RGEN_U32_UNINTERLEAVE,
-  RGEN_ARITH_EXT, RGEN_POSEIDON, RGEN_RANDOM_ACCESS, RGEN_REDUCING, RGEN_REDUCING_EXT, RGEN_NUM
+  RGEN_ARITH_EXT, RGEN_POSEIDON, RGEN_RANDOM_ACCESS, RGEN_REDUCING, RGEN_REDUCING_EXT,
+  RGEN_COSET_INTERP, RGEN_NUM
 };
 struct RGenerator {
   u32 kind;

@@ -312,6 +312,44 @@ static int ref_eval_gate(u32 kind, const F* w, const F* k, const F* pih, F* out)
       }
       return nc;
     }
+    case RG_COSET_INTERP: {  // upstream gates/coset_interpolation.rs eval_unfiltered, subgroup_bits 4, degree 6
+      // wire pairs are elements of the algebra F[X]/(X^2 - 7); the shift and the domain points / weights are scalars
+      struct Alg {
+        F a, b;
+      };
+      auto amul = [](Alg x, Alg y) { return Alg{x.a * y.a + (x.b * y.b).smul(7), x.a * y.b + x.b * y.a}; };
+      const F shift = w[0];
+      const Alg point{w[33], w[34]}, x{w[45], w[46]};
+      out[nc++] = point.a - x.a * shift;
+      out[nc++] = point.b - x.b * shift;
+      const u64 g = rf_root_of_unity(4), inv16 = rf_inv(16);
+      Alg eval{F::from(0), F::from(0)}, prod{one, F::from(0)};
+      u64 xi = 1;
+      for (int c = 0; c < 3; c++) {
+        if (c > 0) {
+          const Alg ie{w[37 + 2 * (c - 1)], w[38 + 2 * (c - 1)]}, ip{w[41 + 2 * (c - 1)], w[42 + 2 * (c - 1)]};
+          out[nc++] = ie.a - eval.a;
+          out[nc++] = ie.b - eval.b;
+          out[nc++] = ip.a - prod.a;
+          out[nc++] = ip.b - prod.b;
+          eval = ie;
+          prod = ip;
+        }
+        const int begin = c == 0 ? 0 : 1 + 5 * c, end = c == 0 ? 6 : (1 + 5 * (c + 1) < 16 ? 1 + 5 * (c + 1) : 16);
+        for (int i = begin; i < end; i++) {
+          const u64 weight = rf_mul(xi, inv16);
+          const Alg v{w[1 + 2 * i].smul(weight), w[2 + 2 * i].smul(weight)};
+          const Alg term{x.a - F::from(xi), x.b};
+          const Alg e1 = amul(eval, term), e2 = amul(v, prod);
+          eval = Alg{e1.a + e2.a, e1.b + e2.b};
+          prod = amul(prod, term);
+          xi = rf_mul(xi, g);
+        }
+      }
+      out[nc++] = w[35] - eval.a;
+      out[nc++] = w[36] - eval.b;
+      return nc;
+    }
     default:
       return 0;
   }

@@ -10,6 +10,21 @@
 
 namespace p25 {
 
+// id() of the CosetInterpolationGate = format!("{self:?}<D={D}>") spells out its 16 barycentric weights (x_i / 16 on the
+// subgroup of order 16): built once
+static const std::string& coset_interp_id() {
+  static const std::string id = [] {
+    std::string s = "CosetInterpolationGate { subgroup_bits: 4, degree: 6, barycentric_weights: [";
+    const u64 g = gl::root_of_unity(4), inv16 = gl::inv(16);
+    u64 x = 1;
+    for (int i = 0; i < CI_POINTS; i++) {
+      s += (i ? ", " : "") + std::to_string(gl::mul(x, inv16));
+      x = gl::mul(x, g);
+    }
+    return s + "], _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>";
+  }();
+  return id;
+}
 static const GateInfo GATE_INFOS[G_NUM_KINDS] = {
     {"NoopGate", 0, 0, 0, 1},
     {"ConstantGate { num_consts: 2 }", 1, 2, 2, 1},
@@ -29,8 +44,16 @@ static const GateInfo GATE_INFOS[G_NUM_KINDS] = {
      RA_BITS + 1, RA_EXTRA_CONSTS, RA_COPIES * (RA_BITS + 2) + RA_EXTRA_CONSTS, RA_COPIES},
     {"ReducingGate { num_coeffs: 43 }", 2, 0, 2 * RED_COEFFS, 1},
     {"ReducingExtensionGate { num_coeffs: 32 }", 2, 0, 2 * REDX_COEFFS, 1},
+    {nullptr /* coset_interp_id() */, CI_DEGREE, 0, 2 * (2 + 2 * CI_INTER), 1},
 };
-const GateInfo& gate_info(GateKind k) { return GATE_INFOS[k]; }
+const GateInfo& gate_info(GateKind k) {
+  if (k == G_COSET_INTERP) {
+    static const GateInfo ci = {coset_interp_id().c_str(), GATE_INFOS[k].degree, GATE_INFOS[k].num_constants,
+                                GATE_INFOS[k].num_constraints, GATE_INFOS[k].num_ops};
+    return ci;
+  }
+  return GATE_INFOS[k];
+}
 
 // ---------------------------------------------------------------- core
 Target CircuitBuilder::add_virtual_target() { return Target{-1, virtual_index_++}; }
@@ -471,6 +494,15 @@ std::array<Target, 4> CircuitBuilder::random_access_hash(Target access_index, co
   return r;
 }
 
+Ext CircuitBuilder::interpolate_coset(Target coset_shift, const std::vector<Ext>& values, Ext evaluation_point) {
+  if ((int)values.size() != CI_POINTS) throw std::invalid_argument("interpolate_coset: 16 values");
+  const int row = add_gate(G_COSET_INTERP);
+  connect(coset_shift, wire(row, 0));
+  for (int i = 0; i < CI_POINTS; i++) connect_extension(values[i], Ext{wire(row, 1 + 2 * i), wire(row, 2 + 2 * i)});
+  connect_extension(evaluation_point, Ext{wire(row, CI_W_POINT), wire(row, CI_W_POINT + 1)});
+  return Ext{wire(row, CI_W_VALUE), wire(row, CI_W_VALUE + 1)};
+}
+
 // ---------------------------------------------------------------- build
 std::vector<int> fri_reduction_arity_bits(const CircuitConfig& cfg, int degree_bits) {
   std::vector<int> r;
@@ -522,6 +554,7 @@ int gate_generator_ops(GateKind k) {
       return gate_info(k).num_ops;
     case G_REDUCING:
     case G_REDUCING_EXT:
+    case G_COSET_INTERP:
       return 1;
     default:
       return 0;
@@ -611,6 +644,20 @@ Generator gate_op_generator(GateKind kind, const u64 constants[2], int r, int i)
       }
       break;
     }
+    case G_COSET_INTERP:  // upstream InterpolationGenerator
+      g.kind = GEN_COSET_INTERP;
+      for (int k = 0; k < CI_W_VALUE; k++) g.deps.push_back(wire(r, k));            // shift, 16 values, the point
+      g.outs.push_back(wire(r, CI_W_SHIFTED));
+      g.outs.push_back(wire(r, CI_W_SHIFTED + 1));
+      for (int k = 0; k < CI_INTER; k++) {
+        g.outs.push_back(wire(r, CI_W_INTER + 2 * k));                               // intermediate eval k
+        g.outs.push_back(wire(r, CI_W_INTER + 2 * k + 1));
+        g.outs.push_back(wire(r, CI_W_INTER + 2 * (CI_INTER + k)));                  // intermediate product k
+        g.outs.push_back(wire(r, CI_W_INTER + 2 * (CI_INTER + k) + 1));
+      }
+      g.outs.push_back(wire(r, CI_W_VALUE));
+      g.outs.push_back(wire(r, CI_W_VALUE + 1));
+      break;
     default:
       throw std::logic_error("gate_op_generator: gate without generators");
   }

@@ -68,6 +68,7 @@ enum GateKind : uint8_t {
   G_RANDOM_ACCESS,      // RandomAccessGate{bits: 4, num_copies: 4, num_extra_constants: 2}: list[index] of 16 elements
   G_REDUCING,           // ReducingGate{num_coeffs: 43}: acc_{i+1} = acc_i * alpha + coeff_i, base-field coefficients
   G_REDUCING_EXT,       // ReducingExtensionGate{num_coeffs: 32}: the same with extension-field coefficients
+  G_COSET_INTERP,       // CosetInterpolationGate{subgroup_bits: 4, degree: 6}: interpolant of 16 values on shift*H at a point
   G_NUM_KINDS
 };
 struct GateInfo {
@@ -87,6 +88,14 @@ constexpr int EXP_POWER_BITS = 66;
 // ReducingGate::max_coeffs_len = min(80 - 6, (135 - 4) / 3), ReducingExtensionGate: min((80 - 6) / 2, (135 - 4) / 4)
 constexpr int RA_BITS = 4, RA_VEC = 16, RA_COPIES = 4, RA_EXTRA_CONSTS = 2, RA_ROUTED = (2 + RA_VEC) * RA_COPIES + RA_EXTRA_CONSTS;
 constexpr int RED_COEFFS = 43, REDX_COEFFS = 32;
+// CosetInterpolationGate::with_max_degree(4, max_quotient_degree_factor = 8): n_intermediates = (16 - 2) / (8 - 1) = 2,
+// degree = (16 - 2) / (2 + 1) + 2 = 6.  Wires: shift 0 | values 1..32 | point 33,34 | value 35,36 | intermediate
+// evals 37..40 | intermediate products 41..44 | shifted point 45,46.  Chunks of the barycentric recurrence: points
+// [0,6), [6,11), [11,16).
+constexpr int CI_POINTS = 16, CI_DEGREE = 6, CI_INTER = 2, CI_W_POINT = 33, CI_W_VALUE = 35, CI_W_INTER = 37,
+              CI_W_SHIFTED = CI_W_INTER + 4 * CI_INTER, CI_WIRES = CI_W_SHIFTED + 2;
+inline int ci_chunk_begin(int c) { return c == 0 ? 0 : 1 + (CI_DEGREE - 1) * c; }
+inline int ci_chunk_end(int c) { return c == 0 ? CI_DEGREE : (1 + (CI_DEGREE - 1) * (c + 1) < CI_POINTS ? 1 + (CI_DEGREE - 1) * (c + 1) : CI_POINTS); }
 
 enum GenKind : uint32_t {
   GEN_CONSTANT = 0,     // out = c0
@@ -108,6 +117,7 @@ enum GenKind : uint32_t {
   GEN_RANDOM_ACCESS,    // RandomAccessGenerator: index, 16 items -> claimed element, 4 index bits
   GEN_REDUCING,         // ReducingGenerator: alpha, old_acc (ext), 43 base coefficients -> 43 accumulators (ext)
   GEN_REDUCING_EXT,     // ReducingGenerator of the extension gate: 32 ext coefficients -> 32 accumulators
+  GEN_COSET_INTERP,     // InterpolationGenerator: shift, 16 ext values, point -> shifted point, 2 x (eval, prod), value
   GEN_NUM_KINDS
 };
 struct Generator {
@@ -237,6 +247,9 @@ class CircuitBuilder {
   Target random_access(Target access_index, const std::vector<Target>& v);
   Ext random_access_extension(Target access_index, const std::vector<Ext>& v);
   std::array<Target, 4> random_access_hash(Target access_index, const std::vector<std::array<Target, 4>>& v);
+  // upstream gadgets/interpolation.rs `interpolate_coset`: the interpolant of (coset_shift * g^i, values[i]), i < 16,
+  // evaluated at `evaluation_point`, on one CosetInterpolationGate row
+  Ext interpolate_coset(Target coset_shift, const std::vector<Ext>& values, Ext evaluation_point);
 
   // ---- Poseidon (v1) in-circuit: upstream gates/poseidon.rs + hash/poseidon.rs `permute_swapped` ----
   std::array<Target, 12> poseidon_permute_swapped(const std::array<Target, 12>& in, BoolTarget swap);

@@ -69,6 +69,7 @@ GateTag gate_tag(GateKind k) {
     case G_RANDOM_ACCESS: return {T_RANDOM_ACCESS, 3, (u64)RA_BITS};
     case G_REDUCING: return {T_REDUCING, 1, (u64)RED_COEFFS};
     case G_REDUCING_EXT: return {T_REDUCING_EXT, 1, (u64)REDX_COEFFS};
+    case G_COSET_INTERP: return {T_COSET_INTERP, 4, 4};   // subgroup_bits, degree, weights length, the 16 weights
     default: throw std::logic_error("gate kind without a serializer tag");
   }
 }
@@ -299,6 +300,20 @@ void write_generator(W& w, const Circuit& c, const Generator& g) {
       w.usize(RA_COPIES);
       w.usize(RA_EXTRA_CONSTS);
       break;
+    case GEN_COSET_INTERP:    // upstream InterpolationGenerator { row, gate }: row, gate.serialize
+      w.u32(GT_INTERPOLATION);
+      w.usize(row_of(g.deps[0]));
+      w.usize(4);
+      w.usize(CI_DEGREE);
+      w.usize(CI_POINTS);
+      {
+        u64 x = 1;
+        for (int i = 0; i < CI_POINTS; i++) {
+          w.field(gl::mul(x, gl::inv(16)));
+          x = gl::mul(x, gl::root_of_unity(4));
+        }
+      }
+      break;
     case GEN_REDUCING:        // upstream ReducingGenerator { row, gate }: row, gate.serialize
     case GEN_REDUCING_EXT:
       w.u32(g.kind == GEN_REDUCING ? GT_REDUCING : GT_REDUCING_EXT);
@@ -359,6 +374,15 @@ std::vector<uint8_t> circuit_data_to_bytes(const Circuit& c, const CircuitCommit
     if (t.has_param == 3) {
       w.usize(RA_COPIES);
       w.usize(RA_EXTRA_CONSTS);
+    }
+    if (t.has_param == 4) {  // CosetInterpolationGate::serialize: subgroup_bits, degree, barycentric_weights (len + values)
+      w.usize(CI_DEGREE);
+      w.usize(CI_POINTS);
+      u64 x = 1;
+      for (int i = 0; i < CI_POINTS; i++) {
+        w.field(gl::mul(x, gl::inv(16)));
+        x = gl::mul(x, gl::root_of_unity(4));
+      }
     }
   }
   // ---- ProverOnlyCircuitData
@@ -559,6 +583,14 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
       if (t.has_param && r.usize() != t.param) R::bad("a gate with parameters this library does not support");
       if (t.has_param == 3 && (r.usize() != (u64)RA_COPIES || r.usize() != (u64)RA_EXTRA_CONSTS))
         R::bad("a RandomAccessGate other than new_from_config(standard_recursion_config, 4)");
+      if (t.has_param == 4) {
+        if (r.usize() != (u64)CI_DEGREE || r.usize() != (u64)CI_POINTS) R::bad("a CosetInterpolationGate other than with_max_degree(4, 8)");
+        u64 x = 1;
+        for (int k = 0; k < CI_POINTS; k++) {
+          if (r.field() != gl::mul(x, gl::inv(16))) R::bad("CosetInterpolationGate barycentric weights");
+          x = gl::mul(x, gl::root_of_unity(4));
+        }
+      }
       c.gates.push_back(kind);
     }
   }
@@ -586,6 +618,7 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
       case GT_U32_ARITHMETIC: case GT_U32_INTERLEAVE: case GT_U32_UNINTERLEAVE: r.skip(24); break;
       case GT_RANDOM_ACCESS: r.skip(40); break;
       case GT_REDUCING: case GT_REDUCING_EXT: r.skip(16); break;
+      case GT_INTERPOLATION: r.skip(8 + 24 + 8 * CI_POINTS); break;
       default: R::bad("a generator type this library has no body for");
     }
   }
@@ -804,6 +837,14 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
           if (g.usize() != (u64)RA_BITS || g.usize() != (u64)RA_COPIES || g.usize() != (u64)RA_EXTRA_CONSTS) R::bad("RandomAccessGate shape");
           u64 k[2] = {0, 0};
           gen = gate_op_generator(G_RANDOM_ACCESS, k, row, (int)copy);
+          break;
+        }
+        case GT_INTERPOLATION: {
+          int row = row_kind(g.usize(), G_COSET_INTERP, "InterpolationGenerator outside its gate");
+          if (g.usize() != 4 || g.usize() != (u64)CI_DEGREE || g.usize() != (u64)CI_POINTS) R::bad("CosetInterpolationGate shape");
+          g.skip(8 * CI_POINTS);   // the weights were checked with the gate list
+          u64 k[2] = {0, 0};
+          gen = gate_op_generator(G_COSET_INTERP, k, row, 0);
           break;
         }
         case GT_REDUCING:

@@ -345,6 +345,42 @@ __device__ void gate_reducing(Ctx& cx) {
     acc = nxt;
   }
 }
+// upstream gates/coset_interpolation.rs eval_unfiltered_base_one (subgroup of order 16, degree 6, 2 intermediates):
+// the point divided by the shift is given on wires and checked; the barycentric recurrence
+//   eval' = eval (x - x_i) + w_i v_i prod,  prod' = prod (x - x_i)
+// runs over the points in three chunks [0,6) [6,11) [11,16), its state pinned to wires between chunks.
+__device__ void gate_coset_interp(Ctx& cx) {
+  const u64 shift = cx.w(0);
+  const gl::E2 point{cx.w(CI_W_POINT), cx.w(CI_W_POINT + 1)}, x{cx.w(CI_W_SHIFTED), cx.w(CI_W_SHIFTED + 1)};
+  int nc = 0;
+  cx.at(nc++, gl::sub(point.a, gl::mul(x.a, shift)));
+  cx.at(nc++, gl::sub(point.b, gl::mul(x.b, shift)));
+  const u64 g = gl::root_of_unity(4), inv16 = gl::inv(16);
+  gl::E2 eval{0, 0}, prod{1, 0};
+  u64 xi = 1;
+  for (int c = 0; c <= CI_INTER; c++) {
+    if (c > 0) {
+      const gl::E2 ie{cx.w(CI_W_INTER + 2 * (c - 1)), cx.w(CI_W_INTER + 2 * (c - 1) + 1)};
+      const gl::E2 ip{cx.w(CI_W_INTER + 2 * (CI_INTER + c - 1)), cx.w(CI_W_INTER + 2 * (CI_INTER + c - 1) + 1)};
+      cx.at(nc++, gl::sub(ie.a, eval.a));
+      cx.at(nc++, gl::sub(ie.b, eval.b));
+      cx.at(nc++, gl::sub(ip.a, prod.a));
+      cx.at(nc++, gl::sub(ip.b, prod.b));
+      eval = ie;
+      prod = ip;
+    }
+    const int end = c == 0 ? CI_DEGREE : (1 + (CI_DEGREE - 1) * (c + 1) < CI_POINTS ? 1 + (CI_DEGREE - 1) * (c + 1) : CI_POINTS);
+    for (int i = c == 0 ? 0 : 1 + (CI_DEGREE - 1) * c; i < end; i++) {
+      const gl::E2 v = gl::mul(gl::E2{cx.w(1 + 2 * i), cx.w(2 + 2 * i)}, gl::mul(xi, inv16));   // value * weight (= x_i / 16)
+      const gl::E2 term{gl::sub(x.a, xi), x.b};
+      eval = gl::add(gl::mul(eval, term), gl::mul(v, prod));
+      prod = gl::mul(prod, term);
+      xi = gl::mul(xi, g);
+    }
+  }
+  cx.at(nc++, gl::sub(cx.w(CI_W_VALUE), eval.a));
+  cx.at(nc++, gl::sub(cx.w(CI_W_VALUE + 1), eval.b));
+}
 // upstream gates/poseidon.rs eval_unfiltered_base_one (rounds in the defining form; same constraint polynomials as
 // upstream's fast partial rounds, which are a linear change of basis on lanes 1..11)
 __device__ void gate_poseidon(Ctx& cx) {
@@ -516,6 +552,9 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
           break;
         case G_REDUCING_EXT:
           if constexpr (REC) gate_reducing<true>(cx);
+          break;
+        case G_COSET_INTERP:
+          if constexpr (REC) gate_coset_interp(cx);
           break;
         default: break;  // NoopGate: no constraints
       }

@@ -195,6 +195,34 @@ __device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* 
       }
       break;
     }
+    case GEN_COSET_INTERP: {  // upstream InterpolationGenerator::run_once
+      const u64 shift = d(0);
+      const gl::E2 x = gl::mul(gl::E2{d(CI_W_POINT), d(CI_W_POINT + 1)}, gl::inv(shift));
+      emit(0, x.a);
+      emit(1, x.b);
+      const u64 gen = gl::root_of_unity(4), inv16 = gl::inv(16);
+      gl::E2 eval{0, 0}, prod{1, 0};
+      u64 xi = 1;
+      for (int c = 0; c <= CI_INTER; c++) {
+        if (c > 0) {
+          emit(2 + 4 * (c - 1), eval.a);
+          emit(3 + 4 * (c - 1), eval.b);
+          emit(4 + 4 * (c - 1), prod.a);
+          emit(5 + 4 * (c - 1), prod.b);
+        }
+        const int end = c == 0 ? CI_DEGREE : (1 + (CI_DEGREE - 1) * (c + 1) < CI_POINTS ? 1 + (CI_DEGREE - 1) * (c + 1) : CI_POINTS);
+        for (int i = c == 0 ? 0 : 1 + (CI_DEGREE - 1) * c; i < end; i++) {
+          const gl::E2 v = gl::mul(gl::E2{d(1 + 2 * i), d(2 + 2 * i)}, gl::mul(xi, inv16));
+          const gl::E2 term{gl::sub(x.a, xi), x.b};
+          eval = gl::add(gl::mul(eval, term), gl::mul(v, prod));
+          prod = gl::mul(prod, term);
+          xi = gl::mul(xi, gen);
+        }
+      }
+      emit(2 + 4 * CI_INTER, eval.a);
+      emit(3 + 4 * CI_INTER, eval.b);
+      break;
+    }
     case GEN_U32_ARITHMETIC: {
       u64 o = gl::add(gl::mul(d(0), d(1)), d(2));
       u64 hi = o >> 32, lo = o & 0xFFFFFFFFull;

@@ -309,6 +309,40 @@ std::vector<Ext> eval_gate_circuit(CircuitBuilder& b, GateKind kind, const std::
       }
       break;
     }
+    case G_COSET_INTERP: {  // upstream gates/coset_interpolation.rs eval_unfiltered_circuit: the recurrence in the algebra
+      using Alg = std::array<Ext, 2>;                       // F_ext[X]/(X^2 - 7) over wire pairs
+      auto amul = [&](const Alg& x, const Alg& y) {
+        return Alg{b.mul_add_extension(x[0], y[0], b.mul_const_extension(7, b.mul_extension(x[1], y[1]))),
+                   b.mul_add_extension(x[0], y[1], b.mul_extension(x[1], y[0]))};
+      };
+      const Ext shift = w[0];
+      const Alg point{w[CI_W_POINT], w[CI_W_POINT + 1]}, x{w[CI_W_SHIFTED], w[CI_W_SHIFTED + 1]};
+      for (int d = 0; d < 2; d++) c.push_back(b.sub_extension(point[d], b.mul_extension(x[d], shift)));
+      const u64 g = gl::root_of_unity(4), inv16 = gl::inv(16);
+      Alg eval{b.zero_extension(), b.zero_extension()}, prod{one, b.zero_extension()};
+      u64 xi = 1;
+      for (int ch = 0; ch <= CI_INTER; ch++) {
+        if (ch > 0) {
+          const Alg ie{w[CI_W_INTER + 2 * (ch - 1)], w[CI_W_INTER + 2 * (ch - 1) + 1]};
+          const Alg ip{w[CI_W_INTER + 2 * (CI_INTER + ch - 1)], w[CI_W_INTER + 2 * (CI_INTER + ch - 1) + 1]};
+          for (int d = 0; d < 2; d++) c.push_back(b.sub_extension(ie[d], eval[d]));
+          for (int d = 0; d < 2; d++) c.push_back(b.sub_extension(ip[d], prod[d]));
+          eval = ie;
+          prod = ip;
+        }
+        for (int i = ci_chunk_begin(ch); i < ci_chunk_end(ch); i++) {
+          const u64 weight = gl::mul(xi, inv16);
+          const Alg v{b.mul_const_extension(weight, w[1 + 2 * i]), b.mul_const_extension(weight, w[2 + 2 * i])};
+          const Alg term{b.sub_extension(x[0], cext(b, xi)), x[1]};
+          const Alg e1 = amul(eval, term), e2 = amul(v, prod);
+          eval = Alg{b.add_extension(e1[0], e2[0]), b.add_extension(e1[1], e2[1])};
+          prod = amul(prod, term);
+          xi = gl::mul(xi, g);
+        }
+      }
+      for (int d = 0; d < 2; d++) c.push_back(b.sub_extension(w[CI_W_VALUE + d], eval[d]));
+      break;
+    }
     case G_POSEIDON: {  // upstream gates/poseidon.rs eval_unfiltered_circuit, rounds in the defining form: the MDS layer
                         // as mul_const_add chains on ArithmeticExtensionGate ops (upstream routes it through PoseidonMdsGate)
       Ext swap = w[24];
@@ -722,28 +756,34 @@ ProofTargets verify_one(CircuitBuilder& b, const Circuit& c, const Hash& digest,
         b.connect_extension(sel, old_eval);
       }
       // compute_evaluation: interpolate the 2^ab values on the coset {s w^i} and evaluate at beta.
-      //   P(beta) = (beta^m - s^m) / (m s^(m-1)) * sum_i v_i w^i / (beta - s w^i)   (barycentric form)
       {
         const u64 g = gl::root_of_unity(ab), g_inv = gl::inv(g);
         std::vector<BoolTarget> within_rev(within.rbegin(), within.rend());
         Target start = exp_from_bits_const_base(b, g_inv, within_rev);
-        Target s = b.mul(start, subgroup_x);
+        Target s = b.mul(start, subgroup_x);                                        // coset_start
         std::vector<Ext> ev(arity);
         for (int k = 0; k < arity; k++) ev[gl::bitrev((u32)k, ab)] = evals[k];   // reverse_index_bits
         const Ext beta = fri_betas[l];
-        Ext sum = b.zero_extension();
-        u64 wi = 1;
-        for (int i = 0; i < arity; i++) {
-          Ext point = b.convert_to_ext(b.mul(b.constant(wi), s));
-          Ext numer = b.mul_const_extension(wi, ev[i]);
-          sum = b.div_add_extension(numer, b.sub_extension(beta, point), sum);
-          wi = gl::mul(wi, g);
+        if (arity == CI_POINTS && c.cfg.max_quotient_degree_factor == 8) {
+          // "let interpolation_gate = CosetInterpolationGate::with_max_degree(arity_bits, max_quotient_degree_factor);
+          //  self.interpolate_coset(interpolation_gate, coset_start, &evals, beta)"
+          old_eval = b.interpolate_coset(s, ev, beta);
+        } else {
+          //   P(beta) = (beta^m - s^m) / (m s^(m-1)) * sum_i v_i w^i / (beta - s w^i)   (barycentric form on arithmetic gates)
+          Ext sum = b.zero_extension();
+          u64 wi = 1;
+          for (int i = 0; i < arity; i++) {
+            Ext point = b.convert_to_ext(b.mul(b.constant(wi), s));
+            Ext numer = b.mul_const_extension(wi, ev[i]);
+            sum = b.div_add_extension(numer, b.sub_extension(beta, point), sum);
+            wi = gl::mul(wi, g);
+          }
+          Target s_pow = b.exp_power_of_2(s, ab);                                    // s^m
+          Ext z_beta = b.sub_extension(b.exp_power_of_2_extension(beta, ab), b.convert_to_ext(s_pow));
+          // 1 / (m s^(m-1)) = s / (m s^m)
+          Target scale = b.mul(s, b.inverse(b.mul(b.constant((u64)arity), s_pow)));
+          old_eval = b.mul_extension(b.scalar_mul_ext(scale, z_beta), sum);
         }
-        Target s_pow = b.exp_power_of_2(s, ab);                                    // s^m
-        Ext z_beta = b.sub_extension(b.exp_power_of_2_extension(beta, ab), b.convert_to_ext(s_pow));
-        // 1 / (m s^(m-1)) = s / (m s^m)
-        Target scale = b.mul(s, b.inverse(b.mul(b.constant((u64)arity), s_pow)));
-        old_eval = b.mul_extension(b.scalar_mul_ext(scale, z_beta), sum);
       }
       std::vector<Target> flat;
       for (const Ext& e : evals) {

@@ -16,12 +16,15 @@
 //    hash/merkle_proofs.rs `verify_merkle_proof_to_cap_with_cap_index`, fri/recursive_verifier.rs).
 //
 // Gate set (round 3): cap entries and the evaluation compared at every FRI layer are selected with RandomAccessGate,
-// reductions with powers of a challenge run on ReducingGate / ReducingExtensionGate -- as upstream's verifier does.
-// DEVIATION (documented in DESIGN.md): upstream also uses CosetInterpolationGate (here: the barycentric formula on
-// arithmetic gates) and, when PoseidonGate is evaluated in-circuit, PoseidonMdsGate (here: multiply-add chains); and
-// upstream hands the RandomAccessGate's two extra constant wires to its constant allocator, this builder does not.
-// So the circuit uses upstream-standard gates only and proves the same statement, but it is NOT row-for-row the
-// circuit `builder.verify_proof::<C>()` would emit (5,464 rows per inner fib-64 proof).
+// reductions with powers of a challenge run on ReducingGate / ReducingExtensionGate, the fold of a FRI layer is one
+// CosetInterpolationGate row -- as upstream's verifier does (`random_access_hash`, `ReducingFactorTarget`,
+// `interpolate_coset`).
+// DEVIATION (documented in DESIGN.md): when PoseidonGate is evaluated in-circuit upstream routes the MDS layer through
+// PoseidonMdsGate and uses its fast partial rounds (here: the defining rounds on multiply-add chains); upstream hands
+// the RandomAccessGate's two extra constant wires to its constant allocator, this builder does not; and the order of
+// the gadget calls is this file's, not checked against upstream's.  So the circuit uses upstream's gate set and proves
+// the same statement, but it is NOT row-for-row the circuit `builder.verify_proof::<C>()` would emit
+// (4,950 rows per inner fib-64 proof, 3,650 of them PoseidonGate).
 #pragma once
 #include <vector>
 #include "builder.h"

@@ -15,7 +15,8 @@ from conftest import P, splitmix_field
 
 GATES = {1: "Constant", 2: "PublicInput", 3: "BaseSum", 4: "U32Interleave", 5: "UninterleaveToU32", 6: "Arithmetic",
          7: "MulExtension", 8: "Exponentiation", 9: "U32Arithmetic", 10: "Poseidon2", 11: "ArithmeticExtension",
-         12: "Poseidon", 13: "RandomAccess", 14: "Reducing", 15: "ReducingExtension"}
+         12: "Poseidon", 13: "RandomAccess", 14: "Reducing", 15: "ReducingExtension",
+         16: "CosetInterpolation"}
 
 
 @pytest.mark.parametrize("kind", sorted(GATES))
@@ -48,7 +49,7 @@ def test_eval_fns_base_extension_and_circuit_agree(p25, oracle, kind):
 
 
 def test_gate_eval_rejects_gates_without_evaluator(p25):
-    for kind in (16, 99, -1):
+    for kind in (17, 99, -1):
         with pytest.raises(p25.P25Error):
             p25.Circuit.build_gate_eval(kind)
 
@@ -138,6 +139,7 @@ def test_recursive_verifier_with_fri_layers(p25, oracle):
     assert st == 0, msg
     dg, cap = oi.digest()
     outer = inner.build_recursive_verifier(1, digest=dg, cs_cap=cap)
+    assert any(k.startswith("CosetInterpolationGate { subgroup_bits: 4, degree: 6") for k in outer.gate_counts())
     oo = oracle.load_circuit(outer.to_blob())
     wires, st, msg = oo.witness(proof, seed=1)
     assert st == 0, msg
