@@ -177,7 +177,7 @@ p25_status p25_circuit_build_recursive_verifier(p25_circuit* inner, const uint64
  * (`eval_unfiltered_circuit`) and connects each constraint to its expectation.  kind: 1 Constant 2 PublicInput
  * 3 BaseSum 4 U32Interleave 5 UninterleaveToU32 6 Arithmetic 7 MulExtension 8 Exponentiation 9 U32Arithmetic
  * 10 Poseidon2 11 ArithmeticExtension 12 Poseidon 13 RandomAccess 14 Reducing 15 ReducingExtension
- * 16 CosetInterpolation (the `kind` numbering of the circuit blob). */
+ * 16 CosetInterpolation 17 PoseidonMds (the `kind` numbering of the circuit blob). */
 p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out);
 /* p25_circuit_build_recursive_verifier whose circuit also REGISTERS FOUR PUBLIC INPUTS (upstream
  * `builder.register_public_inputs`): hash_no_pad over the identifiers of the proofs it verifies, a proof's identifier

@@ -286,6 +286,16 @@ void run_generator(const RCircuit& c, const RGenerator& g, const PartitionWitnes
       }
       break;
     }
+    case RGEN_POSEIDON_MDS: {  // upstream PoseidonMdsGenerator
+      static const u64 CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+      for (int r = 0; r < 12; r++)
+        for (int c2 = 0; c2 < 2; c2++) {
+          u64 acc = r == 0 ? rf_mul(d(c2), 8) : 0;
+          for (int i = 0; i < 12; i++) acc = rf_add(acc, rf_mul(d(2 * ((i + r) % 12) + c2), CIRC[i]));
+          out.push_back(acc);
+        }
+      break;
+    }
     case RGEN_COSET_INTERP: {  // upstream InterpolationGenerator: shift, 16 values, point -> shifted point, states, value
       const u64 shift = d(0);
       const RE2 x = re_muls(RE2{d(33), d(34)}, rf_inv(shift));

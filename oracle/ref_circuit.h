@@ -16,6 +16,7 @@ enum RGate {  // numbering = blob encoding
   RG_REDUCING,        // ReducingGate { num_coeffs: 43 }
   RG_REDUCING_EXT,    // ReducingExtensionGate { num_coeffs: 32 }
   RG_COSET_INTERP,    // CosetInterpolationGate { subgroup_bits: 4, degree: 6, .. }
+  RG_POSEIDON_MDS,    // PoseidonMdsGate
   RG_NUM
 };
 enum RGen {
@@ -23,7 +24,7 @@ enum RGen {
   RGEN_WIRE_SPLIT, RGEN_BASE_SUM, RGEN_LOW_HIGH, RGEN_EXPONENTIATION, RGEN_POSEIDON2,
   RGEN_U32_ARITHMETIC, RGEN_U32_INTERLEAVE, RGEN_U32_UNINTERLEAVE,
   RGEN_ARITH_EXT, RGEN_POSEIDON, RGEN_RANDOM_ACCESS, RGEN_REDUCING, RGEN_REDUCING_EXT,
-  RGEN_COSET_INTERP, RGEN_NUM
+  RGEN_COSET_INTERP, RGEN_POSEIDON_MDS, RGEN_NUM
 };
 struct RGenerator {
   u32 kind;

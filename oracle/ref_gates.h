@@ -312,6 +312,14 @@ static int ref_eval_gate(u32 kind, const F* w, const F* k, const F* pih, F* out)
       }
       return nc;
     }
+    case RG_POSEIDON_MDS:  // upstream gates/poseidon_mds.rs: the MDS layer on 12 algebra elements, component by component
+      for (int r = 0; r < 12; r++)
+        for (int d = 0; d < 2; d++) {
+          F acc = r == 0 ? w[d].smul(8) : F::from(0);
+          for (int i = 0; i < 12; i++) acc = acc + w[2 * ((i + r) % 12) + d].smul(refp1::MDS_CIRC[i]);
+          out[nc++] = w[24 + 2 * r + d] - acc;
+        }
+      return nc;
     case RG_COSET_INTERP: {  // upstream gates/coset_interpolation.rs eval_unfiltered, subgroup_bits 4, degree 6
       // wire pairs are elements of the algebra F[X]/(X^2 - 7); the shift and the domain points / weights are scalars
       struct Alg {

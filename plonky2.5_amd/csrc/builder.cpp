@@ -45,6 +45,7 @@ static const GateInfo GATE_INFOS[G_NUM_KINDS] = {
     {"ReducingGate { num_coeffs: 43 }", 2, 0, 2 * RED_COEFFS, 1},
     {"ReducingExtensionGate { num_coeffs: 32 }", 2, 0, 2 * REDX_COEFFS, 1},
     {nullptr /* coset_interp_id() */, CI_DEGREE, 0, 2 * (2 + 2 * CI_INTER), 1},
+    {"PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", 1, 0, 24, 1},
 };
 const GateInfo& gate_info(GateKind k) {
   if (k == G_COSET_INTERP) {
@@ -503,6 +504,16 @@ Ext CircuitBuilder::interpolate_coset(Target coset_shift, const std::vector<Ext>
   return Ext{wire(row, CI_W_VALUE), wire(row, CI_W_VALUE + 1)};
 }
 
+std::array<Ext, 12> CircuitBuilder::poseidon_mds_layer(const std::array<Ext, 12>& state) {
+  const int row = add_gate(G_POSEIDON_MDS);
+  std::array<Ext, 12> out;
+  for (int i = 0; i < 12; i++) {
+    connect_extension(state[i], Ext{wire(row, 2 * i), wire(row, 2 * i + 1)});
+    out[i] = Ext{wire(row, 24 + 2 * i), wire(row, 25 + 2 * i)};
+  }
+  return out;
+}
+
 // ---------------------------------------------------------------- build
 std::vector<int> fri_reduction_arity_bits(const CircuitConfig& cfg, int degree_bits) {
   std::vector<int> r;
@@ -555,6 +566,7 @@ int gate_generator_ops(GateKind k) {
     case G_REDUCING:
     case G_REDUCING_EXT:
     case G_COSET_INTERP:
+    case G_POSEIDON_MDS:
       return 1;
     default:
       return 0;
@@ -644,6 +656,11 @@ Generator gate_op_generator(GateKind kind, const u64 constants[2], int r, int i)
       }
       break;
     }
+    case G_POSEIDON_MDS:  // upstream PoseidonMdsGenerator
+      g.kind = GEN_POSEIDON_MDS;
+      for (int k = 0; k < 24; k++) g.deps.push_back(wire(r, k));
+      for (int k = 0; k < 24; k++) g.outs.push_back(wire(r, 24 + k));
+      break;
     case G_COSET_INTERP:  // upstream InterpolationGenerator
       g.kind = GEN_COSET_INTERP;
       for (int k = 0; k < CI_W_VALUE; k++) g.deps.push_back(wire(r, k));            // shift, 16 values, the point

@@ -69,6 +69,7 @@ enum GateKind : uint8_t {
   G_REDUCING,           // ReducingGate{num_coeffs: 43}: acc_{i+1} = acc_i * alpha + coeff_i, base-field coefficients
   G_REDUCING_EXT,       // ReducingExtensionGate{num_coeffs: 32}: the same with extension-field coefficients
   G_COSET_INTERP,       // CosetInterpolationGate{subgroup_bits: 4, degree: 6}: interpolant of 16 values on shift*H at a point
+  G_POSEIDON_MDS,       // PoseidonMdsGate: Poseidon's MDS layer on 12 extension elements (PoseidonGate evaluated in-circuit)
   G_NUM_KINDS
 };
 struct GateInfo {
@@ -118,6 +119,7 @@ enum GenKind : uint32_t {
   GEN_REDUCING,         // ReducingGenerator: alpha, old_acc (ext), 43 base coefficients -> 43 accumulators (ext)
   GEN_REDUCING_EXT,     // ReducingGenerator of the extension gate: 32 ext coefficients -> 32 accumulators
   GEN_COSET_INTERP,     // InterpolationGenerator: shift, 16 ext values, point -> shifted point, 2 x (eval, prod), value
+  GEN_POSEIDON_MDS,     // PoseidonMdsGenerator: 12 ext inputs -> 12 ext outputs
   GEN_NUM_KINDS
 };
 struct Generator {
@@ -250,6 +252,8 @@ class CircuitBuilder {
   // upstream gadgets/interpolation.rs `interpolate_coset`: the interpolant of (coset_shift * g^i, values[i]), i < 16,
   // evaluated at `evaluation_point`, on one CosetInterpolationGate row
   Ext interpolate_coset(Target coset_shift, const std::vector<Ext>& values, Ext evaluation_point);
+  // upstream hash/poseidon.rs `mds_layer_circuit`: the MDS layer of 12 extension targets on one PoseidonMdsGate row
+  std::array<Ext, 12> poseidon_mds_layer(const std::array<Ext, 12>& state);
 
   // ---- Poseidon (v1) in-circuit: upstream gates/poseidon.rs + hash/poseidon.rs `permute_swapped` ----
   std::array<Target, 12> poseidon_permute_swapped(const std::array<Target, 12>& in, BoolTarget swap);

@@ -69,6 +69,7 @@ GateTag gate_tag(GateKind k) {
     case G_RANDOM_ACCESS: return {T_RANDOM_ACCESS, 3, (u64)RA_BITS};
     case G_REDUCING: return {T_REDUCING, 1, (u64)RED_COEFFS};
     case G_REDUCING_EXT: return {T_REDUCING_EXT, 1, (u64)REDX_COEFFS};
+    case G_POSEIDON_MDS: return {T_POSEIDON_MDS, 0, 0};
     case G_COSET_INTERP: return {T_COSET_INTERP, 4, 4};   // subgroup_bits, degree, weights length, the 16 weights
     default: throw std::logic_error("gate kind without a serializer tag");
   }
@@ -299,6 +300,10 @@ void write_generator(W& w, const Circuit& c, const Generator& g) {
       w.usize(RA_BITS);
       w.usize(RA_COPIES);
       w.usize(RA_EXTRA_CONSTS);
+      break;
+    case GEN_POSEIDON_MDS:    // upstream PoseidonMdsGenerator { row }
+      w.u32(GT_POSEIDON_MDS);
+      w.usize(row_of(g.deps[0]));
       break;
     case GEN_COSET_INTERP:    // upstream InterpolationGenerator { row, gate }: row, gate.serialize
       w.u32(GT_INTERPOLATION);
@@ -614,7 +619,7 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
       case GT_BASE_SUM: { r.skip(8); u64 k = r.usize_max(64, "BaseSumGenerator limbs"); for (u64 j = 0; j < k; j++) skip_target(); break; }
       case GT_LOW_HIGH: skip_target(); r.skip(8); skip_target(); skip_target(); break;
       case GT_EXPONENTIATION: r.skip(16); break;
-      case GT_POSEIDON: case GT_POSEIDON2: r.skip(8); break;
+      case GT_POSEIDON: case GT_POSEIDON2: case GT_POSEIDON_MDS: r.skip(8); break;
       case GT_U32_ARITHMETIC: case GT_U32_INTERLEAVE: case GT_U32_UNINTERLEAVE: r.skip(24); break;
       case GT_RANDOM_ACCESS: r.skip(40); break;
       case GT_REDUCING: case GT_REDUCING_EXT: r.skip(16); break;
@@ -837,6 +842,11 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
           if (g.usize() != (u64)RA_BITS || g.usize() != (u64)RA_COPIES || g.usize() != (u64)RA_EXTRA_CONSTS) R::bad("RandomAccessGate shape");
           u64 k[2] = {0, 0};
           gen = gate_op_generator(G_RANDOM_ACCESS, k, row, (int)copy);
+          break;
+        }
+        case GT_POSEIDON_MDS: {
+          u64 k[2] = {0, 0};
+          gen = gate_op_generator(G_POSEIDON_MDS, k, row_kind(g.usize(), G_POSEIDON_MDS, "PoseidonMdsGenerator outside its gate"), 0);
           break;
         }
         case GT_INTERPOLATION: {

@@ -47,6 +47,7 @@ bool generator_shape_ok(GenKind k, size_t nd, size_t no, int aux) {
     case GEN_REDUCING: return nd == 4 + RED_COEFFS && no == 2 * RED_COEFFS;
     case GEN_REDUCING_EXT: return nd == 4 + 2 * REDX_COEFFS && no == 2 * REDX_COEFFS;
     case GEN_COSET_INTERP: return nd == (size_t)CI_W_VALUE && no == 4 + 4 * CI_INTER;
+    case GEN_POSEIDON_MDS: return nd == 24 && no == 24;
     default: return false;
   }
 }
@@ -177,7 +178,7 @@ Circuit circuit_from_blob(const uint8_t* data, size_t len) {
     // the evaluators index a row's wires by fixed column numbers
     static const int MIN_WIRES[G_NUM_KINDS] = {0, 2, 4, 1 + BASE_SUM_LIMBS, 6 + 96, 6 + 128, 80, 78, 2 + 2 * EXP_POWER_BITS,
                                                18 + 96, 135, 80, 135, RA_ROUTED + RA_BITS * RA_COPIES,
-                                               4 + 3 * RED_COEFFS, 4 + 4 * REDX_COEFFS, CI_WIRES};
+                                               4 + 3 * RED_COEFFS, 4 + 4 * REDX_COEFFS, CI_WIRES, 48};
     for (GateKind k : c.gates)
       if (MIN_WIRES[k] > c.cfg.num_wires) bad("a gate needs more wires than the circuit has");
   }

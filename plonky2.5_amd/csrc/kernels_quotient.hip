@@ -345,6 +345,15 @@ __device__ void gate_reducing(Ctx& cx) {
     acc = nxt;
   }
 }
+// upstream gates/poseidon_mds.rs: output_r - (sum_i circ[i] input_{(i + r) mod 12} + diag[r] input_r), per component
+__device__ void gate_poseidon_mds(Ctx& cx) {
+  for (int r = 0; r < 12; r++)
+    for (int d = 0; d < 2; d++) {
+      u64 acc = r == 0 ? gl::mul(cx.w(d), (u64)poseidon::MDS_DIAG0) : 0;
+      for (int i = 0; i < 12; i++) acc = gl::add(acc, gl::mul(cx.w(2 * ((i + r) % 12) + d), (u64)poseidon::MDS_CIRC[i]));
+      cx.at(2 * r + d, gl::sub(cx.w(24 + 2 * r + d), acc));
+    }
+}
 // upstream gates/coset_interpolation.rs eval_unfiltered_base_one (subgroup of order 16, degree 6, 2 intermediates):
 // the point divided by the shift is given on wires and checked; the barycentric recurrence
 //   eval' = eval (x - x_i) + w_i v_i prod,  prod' = prod (x - x_i)
@@ -555,6 +564,9 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
           break;
         case G_COSET_INTERP:
           if constexpr (REC) gate_coset_interp(cx);
+          break;
+        case G_POSEIDON_MDS:
+          if constexpr (REC) gate_poseidon_mds(cx);
           break;
         default: break;  // NoopGate: no constraints
       }

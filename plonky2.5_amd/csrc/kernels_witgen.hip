@@ -195,6 +195,14 @@ __device__ __forceinline__ void witgen_level_body(uint32_t block, const WitGen* 
       }
       break;
     }
+    case GEN_POSEIDON_MDS:  // upstream PoseidonMdsGenerator::run_once
+      for (int r = 0; r < 12; r++)
+        for (int c = 0; c < 2; c++) {
+          u64 acc = r == 0 ? gl::mul(d(c), (u64)poseidon::MDS_DIAG0) : 0;
+          for (int i = 0; i < 12; i++) acc = gl::add(acc, gl::mul(d(2 * ((i + r) % 12) + c), (u64)poseidon::MDS_CIRC[i]));
+          emit(2 * r + c, acc);
+        }
+      break;
     case GEN_COSET_INTERP: {  // upstream InterpolationGenerator::run_once
       const u64 shift = d(0);
       const gl::E2 x = gl::mul(gl::E2{d(CI_W_POINT), d(CI_W_POINT + 1)}, gl::inv(shift));

@@ -343,8 +343,16 @@ std::vector<Ext> eval_gate_circuit(CircuitBuilder& b, GateKind kind, const std::
       for (int d = 0; d < 2; d++) c.push_back(b.sub_extension(w[CI_W_VALUE + d], eval[d]));
       break;
     }
-    case G_POSEIDON: {  // upstream gates/poseidon.rs eval_unfiltered_circuit, rounds in the defining form: the MDS layer
-                        // as mul_const_add chains on ArithmeticExtensionGate ops (upstream routes it through PoseidonMdsGate)
+    case G_POSEIDON_MDS:  // upstream gates/poseidon_mds.rs eval_unfiltered_circuit (mds_layer_algebra_circuit)
+      for (int r = 0; r < 12; r++)
+        for (int d = 0; d < 2; d++) {
+          Ext acc = r == 0 ? b.mul_const_extension(poseidon::MDS_DIAG0, w[d]) : b.zero_extension();
+          for (int i = 0; i < 12; i++) acc = b.mul_const_add_extension(poseidon::MDS_CIRC[i], w[2 * ((i + r) % 12) + d], acc);
+          c.push_back(b.sub_extension(w[24 + 2 * r + d], acc));
+        }
+      break;
+    case G_POSEIDON: {  // upstream gates/poseidon.rs eval_unfiltered_circuit, rounds in the defining form (upstream: fast
+                        // partial rounds), the MDS layer of every round on a PoseidonMdsGate row as upstream's
       Ext swap = w[24];
       c.push_back(b.mul_sub_extension(swap, swap, swap));
       for (int i = 0; i < 4; i++) {
@@ -373,13 +381,7 @@ std::vector<Ext> eval_gate_circuit(CircuitBuilder& b, GateKind kind, const std::
           c.push_back(b.sub_extension(st[0], sb));
           st[0] = b.exp_u64_extension(sb, 7);
         }
-        St nx;
-        for (int row = 0; row < 12; row++) {  // out[row] = sum_i circ[i] * s[(i + row) % 12] + diag[row] * s[row]
-          Ext acc = row == 0 ? b.mul_const_extension(poseidon::MDS_DIAG0, st[0]) : b.zero_extension();
-          for (int i = 0; i < 12; i++) acc = b.mul_const_add_extension(poseidon::MDS_CIRC[i], st[(i + row) % 12], acc);
-          nx[row] = acc;
-        }
-        st = nx;
+        st = b.poseidon_mds_layer(st);   // upstream `mds_layer_circuit`: one PoseidonMdsGate row (48 wires <= 80 routed)
       }
       for (int i = 0; i < 12; i++) c.push_back(b.sub_extension(st[i], w[12 + i]));
       break;

@@ -19,10 +19,11 @@
 // reductions with powers of a challenge run on ReducingGate / ReducingExtensionGate, the fold of a FRI layer is one
 // CosetInterpolationGate row -- as upstream's verifier does (`random_access_hash`, `ReducingFactorTarget`,
 // `interpolate_coset`).
-// DEVIATION (documented in DESIGN.md): when PoseidonGate is evaluated in-circuit upstream routes the MDS layer through
-// PoseidonMdsGate and uses its fast partial rounds (here: the defining rounds on multiply-add chains); upstream hands
-// the RandomAccessGate's two extra constant wires to its constant allocator, this builder does not; and the order of
-// the gadget calls is this file's, not checked against upstream's.  So the circuit uses upstream's gate set and proves
+// When PoseidonGate is evaluated in-circuit (depth >= 2) every MDS layer is one PoseidonMdsGate row (`mds_layer_circuit`).
+// DEVIATION (documented in DESIGN.md): upstream's in-circuit PoseidonGate evaluator runs its FAST partial rounds
+// (here: the defining rounds, one PoseidonMdsGate row per round); upstream hands the RandomAccessGate's two extra
+// constant wires to its constant allocator, this builder does not; and the order of the gadget calls is this file's,
+// not checked against upstream's.  So the circuit uses upstream's gate set and proves
 // the same statement, but it is NOT row-for-row the circuit `builder.verify_proof::<C>()` would emit
 // (4,950 rows per inner fib-64 proof, 3,650 of them PoseidonGate).
 #pragma once

@@ -16,7 +16,7 @@ from conftest import P, splitmix_field
 GATES = {1: "Constant", 2: "PublicInput", 3: "BaseSum", 4: "U32Interleave", 5: "UninterleaveToU32", 6: "Arithmetic",
          7: "MulExtension", 8: "Exponentiation", 9: "U32Arithmetic", 10: "Poseidon2", 11: "ArithmeticExtension",
          12: "Poseidon", 13: "RandomAccess", 14: "Reducing", 15: "ReducingExtension",
-         16: "CosetInterpolation"}
+         16: "CosetInterpolation", 17: "PoseidonMds"}
 
 
 @pytest.mark.parametrize("kind", sorted(GATES))
@@ -49,7 +49,7 @@ def test_eval_fns_base_extension_and_circuit_agree(p25, oracle, kind):
 
 
 def test_gate_eval_rejects_gates_without_evaluator(p25):
-    for kind in (17, 99, -1):
+    for kind in (18, 99, -1):
         with pytest.raises(p25.P25Error):
             p25.Circuit.build_gate_eval(kind)
 
