@@ -12,9 +12,25 @@
 // Digests are stored as 4 consecutive u64 per node (32 B per lane, contiguous across lanes).
 #include "kernels.h"
 #include "poseidon.h"
-#include "poseidon2.h"
-#include "coop.h"
-#include "coop_lat.h"
+#include "poseidon_mfma.h"
+// Build switches (tools/hash_variants.sh builds the variants): which kernels take the wave-wide permutation of
+// poseidon_mfma.h (full-round MDS layers on the matrix cores) and the occupancy they are compiled for.
+// Measured on MI355X (profiles/r03_mfma_*.txt): the MFMA form executes 10 % fewer VALU instructions per permutation and
+// is 5 % faster standalone (2726 vs 2593 Mperm/s), but needs 128 VGPRs (4 waves per SIMD instead of 6) and each of its
+// 168 MFMAs holds the SIMD's VALU issue for ~13 cycles; in the 16-stream proving pipeline that is +0.4 % (leaf + tree)
+// to +0.9 % (leaf only) -- inside the run-to-run spread -- so the product default stays the VALU form at 6 waves per SIMD.
+#ifndef P25_LEAF_MX
+#define P25_LEAF_MX 0
+#endif
+#ifndef P25_TREE_MX
+#define P25_TREE_MX 0
+#endif
+#ifndef P25_LEAF_MINW
+#define P25_LEAF_MINW (P25_LEAF_MX ? 4 : 6)
+#endif
+#ifndef P25_TREE_MINW
+#define P25_TREE_MINW (P25_TREE_MX ? 4 : 6)
+#endif
 
 namespace p25 {
 
@@ -41,13 +57,40 @@ __global__ __launch_bounds__(256) void k_poseidon2_permute(u64* states, size_t n
 }
 
 // digests[l] = hash_or_noop(leaf l), leaf l = (cols[c*col_stride + l])_{c < width}
-// 64-lane workgroups: the kernel is a pure per-lane VALU loop (~230k instructions per lane for 135
+// 64-lane workgroups: the kernel is a pure per-lane VALU loop (~200k instructions per lane for 135
 // columns), and one wave per workgroup lets the dispatcher back-fill SIMDs as soon as a single wave
-// retires (tools/hashbench.hip: 5 % over 256-lane workgroups).  80 VGPRs (6 waves per SIMD) leave room
-// for other streams' waves next to it.
+// retires (tools/hashbench.hip: 5 % over 256-lane workgroups).
+// 80 VGPRs (6 waves per SIMD) leave room for other streams' waves next to it.
+// With P25_LEAF_MX a workgroup whose 64 leaves all exist runs the wave-wide permutation of poseidon_mfma.h (the MDS
+// layers of the full rounds on the matrix cores; 128 VGPRs, 4 waves per SIMD); a ragged last workgroup and leaves
+// of <= 4 words take the per-lane path.  Same digests either way.
 __device__ __forceinline__ void hash_leaf(const u64* __restrict__ cols, size_t col_stride, int width,
                                           size_t n_leaves, u64* __restrict__ digests) {
-  size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t l = (size_t)blockIdx.x * 64 + threadIdx.x;   // launched with 64 lanes per workgroup
+#if defined(__HIP_DEVICE_COMPILE__) && P25_LEAF_MX
+  if (((size_t)blockIdx.x + 1) * 64 <= n_leaves && width > 4) {
+    const poseidon::mx::Ctx c = poseidon::mx::make_ctx(threadIdx.x);
+    const u64* in = cols + l;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    for (int off = 0; off < width; off += poseidon::RATE) {
+      const int m = width - off < poseidon::RATE ? width - off : poseidon::RATE;
+#pragma unroll
+      for (int i = 0; i < poseidon::RATE; i++)
+        if (i < m) s[i] = in[(size_t)(off + i) * col_stride];
+      // the inputs land here, not somewhere inside the permutation (left to itself the compiler's placement of this
+      // wait costs 12 % of the kernel: tools/hashbench.hip "explicit wait")
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int next = width - (off + poseidon::RATE);
+      poseidon::mx::permute_wave(s, next <= 0 ? poseidon::ROWS_DIGEST : (next >= poseidon::RATE ? poseidon::ROWS_CAPACITY : poseidon::ROWS_ALL), c);
+    }
+    u64* d = digests + 4 * l;
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = s[i];
+    return;
+  }
+#endif
   if (l >= n_leaves) return;
   u64 out[4];
   poseidon::hash_or_noop_strided(cols + l, col_stride, width, out);
@@ -55,21 +98,35 @@ __device__ __forceinline__ void hash_leaf(const u64* __restrict__ cols, size_t c
 #pragma unroll
   for (int i = 0; i < 4; i++) d[i] = out[i];
 }
-__global__ __launch_bounds__(64, 6) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
+__global__ __launch_bounds__(64, P25_LEAF_MINW) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
                                                        int width, size_t n_leaves, u64* __restrict__ digests) {
   hash_leaf(cols, col_stride, width, n_leaves, digests);
 }
 // The same kernel under its own symbol for wide matrices (the 135-column wires LDE: the dominant launch
 // of a proof), so that profiler summaries list it separately from the 20- and 16-column commits.
-__global__ __launch_bounds__(64, 6) void k_hash_leaves_wide(const u64* __restrict__ cols, size_t col_stride,
+__global__ __launch_bounds__(64, P25_LEAF_MINW) void k_hash_leaves_wide(const u64* __restrict__ cols, size_t col_stride,
                                                             int width, size_t n_leaves, u64* __restrict__ digests) {
   hash_leaf(cols, col_stride, width, n_leaves, digests);
 }
 
 // parents[m] = two_to_one(children[2m], children[2m+1])
-__global__ __launch_bounds__(64, 6) void k_tree_level(const u64* __restrict__ children,
+__global__ __launch_bounds__(64, P25_TREE_MINW) void k_tree_level(const u64* __restrict__ children,
                                                     u64* __restrict__ parents, size_t n_parents) {
-  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t m = (size_t)blockIdx.x * 64 + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__) && P25_TREE_MX
+  if (((size_t)blockIdx.x + 1) * 64 <= n_parents) {   // whole wave: the wave-wide permutation (poseidon_mfma.h)
+    const poseidon::mx::Ctx c = poseidon::mx::make_ctx(threadIdx.x);
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = children[8 * m + i];
+#pragma unroll
+    for (int i = 8; i < 12; i++) s[i] = 0;
+    poseidon::mx::permute_wave(s, poseidon::ROWS_DIGEST, c);
+#pragma unroll
+    for (int i = 0; i < 4; i++) parents[4 * m + i] = s[i];
+    return;
+  }
+#endif
   if (m >= n_parents) return;
   u64 l[4], r[4], o[4];
 #pragma unroll

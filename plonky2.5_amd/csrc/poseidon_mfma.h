@@ -178,10 +178,11 @@ __device__ __forceinline__ void from_pairs(u64 s[WIDTH], u64 A[6], u64 B[6], u32
   asm volatile("s_nop 1");
 #pragma unroll
   for (int t = 0; t < 3; t++) {
-    if (!((rows >> (4 * t)) & 0xFu)) continue;  // wave-uniform: a word group the caller will not read
+    const bool want = (rows >> (4 * t)) & 0xFu;  // wave-uniform: a word group the caller will read
 #pragma unroll
     for (int sl = 0; sl < 2; sl++) {
-      swap_words(A[2 * t + sl], B[2 * t + sl]);
+      if (want) swap_words(A[2 * t + sl], B[2 * t + sl]);
+      // assigned either way (unspecified values for a group not wanted), so that the caller's old words are dead
       s[4 * t + sl] = A[2 * t + sl];
       s[4 * t + 2 + sl] = B[2 * t + sl];
     }
@@ -294,16 +295,18 @@ __device__ __forceinline__ void full_rounds(u64 A[6], u64 B[6], const Ctx& c, u3
   for (int l = 0; l < N; l++) {
     const bool last = l == N - 1;
     load_ctiles(ctile, c, L0 + l);
+    // the last layer issues every MFMA as well (they cost next to nothing; branches around them do) and only
+    // recombines the row tiles the caller reads
     const u32 umask = (last && !SBOX_AFTER) ? umask_last : 7u;
     xor_operand(A, b);
-    sbox6_mfma12(B, acc, b, c, ctile, umask);   // B's S-boxes of this round under A's layer
+    sbox6_mfma12(B, acc, b, c, ctile, 7);       // B's S-boxes of this round under A's layer
     recombine6(A, acc, c, umask);
     xor_operand(B, b);
     if (!last || SBOX_AFTER) {
       sbox6_mfma12(A, acc, b, c, ctile, 7);     // A's S-boxes of the NEXT round under B's layer
       recombine6(B, acc, c);
     } else {
-      mfma12(acc, b, c, ctile, umask);
+      mfma12(acc, b, c, ctile, 7);
       recombine6(B, acc, c, umask);
     }
   }

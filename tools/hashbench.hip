@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include "poseidon.h"
+#include "poseidon_mfma.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int BS>
@@ -51,6 +52,63 @@ __global__ __launch_bounds__(256) void k_regs(u64* dig, size_t n, int reps) {
   for (int r = 0; r < reps; r++) { s[0] ^= r; poseidon::permute(s); }
   for (int i = 0; i < 4; i++) dig[4 * l + i] = s[i];
 }
+// the wave-wide permutation (poseidon_mfma.h) in the leaf sponge; VAR 0: as in kernels_hash.hip, 1: inputs from
+// registers instead of memory, 2: every permutation computes all rows
+template <int MINW, int VAR>
+__global__ __launch_bounds__(64, MINW) void k_mx(const u64* __restrict__ cols, size_t stride, int width, size_t n, u64* __restrict__ dig) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  size_t l = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(threadIdx.x);
+  const u64* in = cols + l;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = 0;
+  for (int off = 0; off < width; off += 8) {
+    const int m = width - off < 8 ? width - off : 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (i < m) s[i] = VAR == 1 ? (u64)(l * 8 + off + i) : in[(size_t)(off + i) * stride];
+    if (VAR == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int next = width - (off + 8);
+    u32 rows = next <= 0 ? poseidon::ROWS_DIGEST : (next >= 8 ? poseidon::ROWS_CAPACITY : poseidon::ROWS_ALL);
+    if (VAR == 2) rows = poseidon::ROWS_ALL;
+    poseidon::mx::permute_wave(s, rows, c);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) dig[4 * l + i] = s[i];
+#endif
+}
+// where the time of a leaf goes: cycles waiting for the 8 column loads vs cycles in the permutation (wave 0 of every 64th block)
+template <int ALLROWS>
+__global__ __launch_bounds__(64, 4) void k_mx_t(const u64* __restrict__ cols, size_t stride, int width, size_t n, u64* __restrict__ dig, unsigned long long* tm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  size_t l = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(threadIdx.x);
+  const u64* in = cols + l;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = 0;
+  unsigned long long tl = 0, tp = 0;
+  for (int off = 0; off < width; off += 8) {
+    const int m = width - off < 8 ? width - off : 8;
+    unsigned long long c0 = __builtin_readcyclecounter();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (i < m) s[i] = in[(size_t)(off + i) * stride];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long c1 = __builtin_readcyclecounter();
+    const int next = width - (off + 8);
+    u32 rows = next <= 0 ? poseidon::ROWS_DIGEST : (next >= 8 ? poseidon::ROWS_CAPACITY : poseidon::ROWS_ALL);
+    if (ALLROWS) rows = poseidon::ROWS_ALL;
+    poseidon::mx::permute_wave(s, rows, c);
+    unsigned long long c2 = __builtin_readcyclecounter();
+    tl += c1 - c0; tp += c2 - c1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) dig[4 * l + i] = s[i];
+  if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { tm[2 * (blockIdx.x >> 6)] = tl; tm[2 * (blockIdx.x >> 6) + 1] = tp; }
+#endif
+}
 template <class F> float timeit(F f) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   f(); (void)hipDeviceSynchronize();
@@ -80,6 +138,30 @@ int main() {
     for (size_t i = 0; i < n * 4; i++) { sum += h[i] * (2 * i + 1); xr ^= h[i]; }
     printf("digest checksum (asm=%d): %016llx %016llx\n", P25_ASM_MUL, (unsigned long long)sum, (unsigned long long)xr);
     free(h);
+  }
+  rep("mx (64,4)", timeit([&] { hipLaunchKernelGGL((k_mx<4, 0>), dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
+  {
+    u64* h = (u64*)malloc(n * 32);
+    CK(hipMemcpy(h, dig, n * 32, hipMemcpyDeviceToHost));
+    u64 sum = 0, xr = 0;
+    for (size_t i = 0; i < n * 4; i++) { sum += h[i] * (2 * i + 1); xr ^= h[i]; }
+    printf("digest checksum (mx):    %016llx %016llx\n", (unsigned long long)sum, (unsigned long long)xr);
+    free(h);
+  }
+  rep("mx (64,3)", timeit([&] { hipLaunchKernelGGL((k_mx<3, 0>), dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
+  rep("mx (64,2)", timeit([&] { hipLaunchKernelGGL((k_mx<2, 0>), dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
+  rep("mx (64,4) inputs from registers", timeit([&] { hipLaunchKernelGGL((k_mx<4, 1>), dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
+  rep("mx (64,4) explicit wait after the loads", timeit([&] { hipLaunchKernelGGL((k_mx<4, 3>), dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
+  rep("mx (64,4) all rows", timeit([&] { hipLaunchKernelGGL((k_mx<4, 2>), dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
+  {
+    unsigned long long* tm; CK(hipMalloc(&tm, 128 * 16));
+    unsigned long long h[256];
+    for (int all = 0; all < 2; all++) {
+      float ms = timeit([&] { if (all) hipLaunchKernelGGL(k_mx_t<1>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig, tm); else hipLaunchKernelGGL(k_mx_t<0>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig, tm); });
+      CK(hipMemcpy(h, tm, sizeof(h), hipMemcpyDeviceToHost));
+      double a = 0, b = 0; for (int i = 0; i < 128; i++) { a += h[2 * i]; b += h[2 * i + 1]; }
+      printf("stamped mx, allrows=%d: %.3f ms; per wave per permutation: %.0f ticks waiting for loads, %.0f ticks permuting (100 MHz ticks x %d perms)\n", all, ms, a / 128 / 17, b / 128 / 17, 17);
+    }
   }
   rep("prefetch bs256",timeit([&] { hipLaunchKernelGGL(k_prefetch<256>, dim3(n / 256), dim3(256), 0, 0, cols, n, w, n, dig); }));
   rep("prefetch bs64", timeit([&] { hipLaunchKernelGGL(k_prefetch<64>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig); }));
