@@ -13,6 +13,9 @@
 #include "kernels.h"
 #include "poseidon.h"
 #include "poseidon_mfma.h"
+#include "poseidon2.h"
+#include "coop.h"
+#include "coop_lat.h"
 // Build switches (tools/hash_variants.sh builds the variants): which kernels take the wave-wide permutation of
 // poseidon_mfma.h (full-round MDS layers on the matrix cores) and the occupancy they are compiled for.
 // Measured on MI355X (profiles/r03_mfma_*.txt): the MFMA form executes 10 % fewer VALU instructions per permutation and
