@@ -1,6 +1,7 @@
 // Variants of the Merkle leaf-sponge kernel on a synthetic 2^19 x 135 column-major matrix.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <unistd.h>
 #include "poseidon.h"
 #include "poseidon_mfma.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -161,6 +162,23 @@ int main() {
       CK(hipMemcpy(h, tm, sizeof(h), hipMemcpyDeviceToHost));
       double a = 0, b = 0; for (int i = 0; i < 128; i++) { a += h[2 * i]; b += h[2 * i + 1]; }
       printf("stamped mx, allrows=%d: %.3f ms; per wave per permutation: %.0f ticks waiting for loads, %.0f ticks permuting (100 MHz ticks x %d perms)\n", all, ms, a / 128 / 17, b / 128 / 17, 17);
+    }
+  }
+  {
+    // does the leaf kernel run slower when the chip was idle just before it (a lone proof's latency-bound stretches)?
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int idle_ms : {0, 1, 3, 10, 30}) {
+      float tot = 0, mx = 0;
+      for (int it = 0; it < 6; it++) {
+        (void)hipDeviceSynchronize();
+        if (idle_ms) usleep(idle_ms * 1000);
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k_v0<64>, dim3(n / 64), dim3(64), 0, 0, cols, n, w, n, dig);
+        (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (it) { tot += ms; mx = ms > mx ? ms : mx; }
+      }
+      printf("leaf kernel after %2d ms of idle chip: %.3f ms (max %.3f)\n", idle_ms, tot / 5, mx);
     }
   }
   rep("prefetch bs256",timeit([&] { hipLaunchKernelGGL(k_prefetch<256>, dim3(n / 256), dim3(256), 0, 0, cols, n, w, n, dig); }));
