@@ -608,7 +608,7 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
 p25_status p25_circuit_set_streams(p25_circuit* c, int32_t n_streams) {
   return host_guarded([&]() -> p25_status {
     if (!c) throw std::invalid_argument("null argument");
-    if (n_streams < 1 || n_streams > 16) throw std::invalid_argument("n_streams must be in 1..16");
+    if (n_streams < 1 || n_streams > 32) throw std::invalid_argument("n_streams must be in 1..32");
     P25_LOCK(c);
     c->streams = n_streams;
     if (c->dev) c->dev->set_streams(n_streams);

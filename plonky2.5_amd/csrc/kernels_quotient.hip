@@ -494,27 +494,33 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
       res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + c]));
     }
   }
-  // --- partial-product checks: terms NC + c*nch + k
-  for (int c = 0; c < NC; c++) {
-    const u64 beta = a.chal[CH_BETAS + c], gamma = a.chal[CH_GAMMAS + c];
+  // --- partial-product checks: terms NC + c*nch + k.  Both challenges in ONE pass over the routed wires and their
+  // sigmas: every column is read once instead of once per challenge (160 of the kernel's ~850 column reads).
+  {
+    const u64 beta0 = a.chal[CH_BETAS], beta1 = a.chal[CH_BETAS + 1];
+    const u64 gamma0 = a.chal[CH_GAMMAS], gamma1 = a.chal[CH_GAMMAS + 1];
     for (int k = 0; k < nch; k++) {
-      u64 np = 1, dp = 1;
+      u64 np0 = 1, dp0 = 1, np1 = 1, dp1 = 1;
       // beta * k_j * x: k_j * beta comes from a per-proof table (k_alpha_pows fills it)
       for (int j = k * per; j < (k + 1) * per && j < RW; j++) {
-        u64 w = wr[(size_t)j * big];
-        u64 sg = cs[(size_t)(n_consts + 2 + j) * big];
-        u64 wg = gl::add(w, gamma);
-        np = gl::mul_nc(np, gl::mad_nc(kb[c * RW + j], x, wg));
-        dp = gl::mul_nc(dp, gl::mad_nc(beta, sg, wg));
+        const u64 w = wr[(size_t)j * big];
+        const u64 sg = cs[(size_t)(n_consts + 2 + j) * big];
+        const u64 wg0 = gl::add(w, gamma0), wg1 = gl::add(w, gamma1);
+        np0 = gl::mul_nc(np0, gl::mad_nc(kb[j], x, wg0));
+        dp0 = gl::mul_nc(dp0, gl::mad_nc(beta0, sg, wg0));
+        np1 = gl::mul_nc(np1, gl::mad_nc(kb[RW + j], x, wg1));
+        dp1 = gl::mul_nc(dp1, gl::mad_nc(beta1, sg, wg1));
       }
-      np = gl::canon(np);
-      dp = gl::canon(dp);
-      u64 prev = k == 0 ? zs[(size_t)c * big] : zs[(size_t)(NC + c * NP + k - 1) * big];
-      u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zs[(size_t)(NC + c * NP + k) * big];
-      u64 t = gl::sub(gl::mul(prev, np), gl::mul(next, dp));
-      int ti = NC + c * nch + k;
-      res[0] = gl::add(res[0], gl::mul(t, ap[ti]));
-      res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + ti]));
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const u64 np = gl::canon(c ? np1 : np0), dp = gl::canon(c ? dp1 : dp0);
+        u64 prev = k == 0 ? zs[(size_t)c * big] : zs[(size_t)(NC + c * NP + k - 1) * big];
+        u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zs[(size_t)(NC + c * NP + k) * big];
+        u64 t = gl::sub(gl::mul(prev, np), gl::mul(next, dp));
+        int ti = NC + c * nch + k;
+        res[0] = gl::add(res[0], gl::mul(t, ap[ti]));
+        res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + ti]));
+      }
     }
   }
   // --- gate constraints, terms NC*(1+nch) + j
@@ -598,6 +604,14 @@ void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bit
                      degree_bits + rate_bits, d_out);
 }
 
+// Occupancy cap of k_quotient through dynamic LDS (experiment knob, P25_Q_LDS_PAD bytes per workgroup; 0 = none).
+static size_t quotient_lds_pad() {
+  static const size_t pad = [] {
+    const char* e = getenv("P25_Q_LDS_PAD");
+    return e ? (size_t)atol(e) : (size_t)0;
+  }();
+  return pad;
+}
 void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   QuotientArgs a = a_in;
 #ifdef P25_PROFILE_GATE_MASK
@@ -620,7 +634,7 @@ void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   if (rec)
     hipLaunchKernelGGL(k_quotient_rec, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
   else
-    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), quotient_lds_pad(), st, a);
 }
 
 }  // namespace p25

@@ -91,7 +91,7 @@ class DeviceCircuit {
                        uint32_t* d_status, PhaseTimes* times, const u64* d_filler = nullptr);
   void sync();
   // proofs kept in flight by prove_batch* (one HIP stream + working set each), 1..16
-  void set_streams(int k) { streams_ = k < 1 ? 1 : (k > 16 ? 16 : k); }
+  void set_streams(int k) { streams_ = k < 1 ? 1 : (k > 32 ? 32 : k); }
   hipStream_t stream() const { return stream_; }
   // Isolated stages (host buffers; parity tests of SURVEY 8a7 / 8a8 through p25_partial_products / p25_quotient):
   // wires[num_wires][n] -> out[NC*(1+NP)][n];  wires + zs_pp values -> out[NC*8][n] quotient chunk coefficients
