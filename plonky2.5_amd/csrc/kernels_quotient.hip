@@ -494,11 +494,122 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
       res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + c]));
     }
   }
+  auto gate_filter = [&](uint32_t gi) {
+    const GateEntry ge = a.gates[gi];
+    const u64 s = cs[(size_t)ge.selector_index * big];
+    u64 filter = 1;
+    for (uint32_t k = ge.group_start; k < ge.group_end; k++)
+      if (k != gi) filter = gl::mul(filter, gl::sub((u64)k, s));
+    if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
+    return filter;
+  };
   // --- partial-product checks: terms NC + c*nch + k.  Both challenges in ONE pass over the routed wires and their
   // sigmas: every column is read once instead of once per challenge (160 of the kernel's ~850 column reads).
+  // FAST (the standard configuration: 80 routed wires): ONE more pass over the routed wires evaluates all the gates whose
+  // wires lie in that range and are read in ascending order -- Constant, PublicInput, BaseSum, Arithmetic, MulExtension:
+  // 80 column reads instead of their 228.  (Doing it inside the permutation pass itself was measured too: one read less
+  // per column, but 192 spilled registers instead of 116 and no gain.)  Those gates share ONE alpha-fold accumulator: each
+  // constraint is multiplied by its gate's filter first (116 multiplications, paid for by the five per-gate folds of the
+  // accumulator limbs that are no longer needed);  sum_g f_g sum_j alpha^j c_gj = sum_j alpha^j sum_g f_g c_gj.
+  const bool fast = !REC && per == 8 && RW == 80 && NP == 9 && a.num_wires >= 80;
+  uint32_t merged_mask = 0;   // gate kinds evaluated by the merged pass
+  u64 mg0 = 0, mg1 = 0;       // their filtered, alpha-folded sums
+  const u64 beta0 = a.chal[CH_BETAS], beta1 = a.chal[CH_BETAS + 1];
+  const u64 gamma0 = a.chal[CH_GAMMAS], gamma1 = a.chal[CH_GAMMAS + 1];
+  if (fast) {
+    for (uint32_t gi = 0; gi < a.n_gates; gi++) {
+      const uint32_t kind = a.gates[gi].kind;
+      if (kind == G_CONSTANT || kind == G_PUBLIC_INPUT || kind == G_BASE_SUM || kind == G_ARITHMETIC || kind == G_MUL_EXT) {
+        if ((merged_mask >> kind) & 1u) { merged_mask = 0xFFFFFFFFu; break; }   // a kind twice: not this path
+        merged_mask |= 1u << kind;
+      }
+    }
+  }
+  if (fast && merged_mask != 0xFFFFFFFFu) {
+    const bool h_const = (merged_mask >> G_CONSTANT) & 1u, h_pi = (merged_mask >> G_PUBLIC_INPUT) & 1u,
+               h_bsum = (merged_mask >> G_BASE_SUM) & 1u, h_arith = (merged_mask >> G_ARITHMETIC) & 1u,
+               h_mext = (merged_mask >> G_MUL_EXT) & 1u;
+    u64 f_const = 0, f_pi = 0, f_bsum = 0, f_arith = 0, f_mext = 0;
+    for (uint32_t gi = 0; gi < a.n_gates; gi++) {
+      const uint32_t kind = a.gates[gi].kind;
+      if (kind == G_CONSTANT) f_const = gate_filter(gi);
+      else if (kind == G_PUBLIC_INPUT) f_pi = gate_filter(gi);
+      else if (kind == G_BASE_SUM) f_bsum = gate_filter(gi);
+      else if (kind == G_ARITHMETIC) f_arith = gate_filter(gi);
+      else if (kind == G_MUL_EXT) f_mext = gate_filter(gi);
+    }
+    const u64 k0 = cs[(size_t)n_consts * big], k1 = cs[(size_t)(n_consts + 1) * big];
+    Ctx mc;          // the shared accumulator of the merged gates
+    mc.wires = wr;
+    mc.big = big;
+    mc.apl = apl;
+    mc.reset();
+    u64 bs_sum = 0, bs_w0 = 0;
+    SmallLin bs_acc;
+    u64 ar0 = 0, ar1 = 0, ar2 = 0;                    // arithmetic: multiplicand 0, multiplicand 1, addend of the current op
+    u64 mx0 = 0, mx1 = 0, mx2 = 0, mx3 = 0, mx4 = 0;  // mul-extension: a, b and output.a of the current op
+    // one routed wire: position JJ (compile time) of a block that starts at wire `base` (a multiple of 24, or 72)
+#define P25_Q_WIRE(JJ)                                                                                          \
+  {                                                                                                             \
+    const int j = base + (JJ);                                                                                  \
+    const u64 w = wr[(size_t)j * big];                                                                          \
+    if ((JJ) < 4 && base == 0) {                                                                                \
+      if (h_const && (JJ) < 2) mc.at((JJ), gl::mul_nc(gl::sub((JJ) == 0 ? k0 : k1, w), f_const));              \
+      if (h_pi) mc.at((JJ), gl::mul_nc(gl::sub(w, a.pi_hash[(JJ)]), f_pi));                                     \
+    }                                                                                                           \
+    if (h_bsum) {                                                                                               \
+      if (j == 0) bs_w0 = w;                                                                                    \
+      if (j >= 1 && j <= BASE_SUM_LIMBS) {                                                                      \
+        constexpr int t = ((JJ) + 7) % 8;   /* limb i = j - 1, position i mod 8 of its group of eight */          \
+        bs_acc.add(w, 1u << t);                                                                                 \
+        mc.at(j, gl::mul_nc(gl::mul_nc(w, gl::sub(w, 1)), f_bsum));                                             \
+        if (t == 7 || j == BASE_SUM_LIMBS) {                                                                    \
+          bs_sum = gl::mad_nc(bs_acc.value(), (u64)1 << (8 * (((j - 1) >> 3) & 7)), bs_sum);                          \
+          bs_acc = SmallLin();                                                                                  \
+        }                                                                                                       \
+      }                                                                                                         \
+    }                                                                                                           \
+    if (h_arith) {                                                                                              \
+      if ((JJ) % 4 == 0) ar0 = w;                                                                               \
+      else if ((JJ) % 4 == 1) ar1 = w;                                                                          \
+      else if ((JJ) % 4 == 2) ar2 = w;                                                                          \
+      else {                                                                                                    \
+        const u64 comp = gl::add(gl::mul(gl::mul(ar0, ar1), k0), gl::mul(ar2, k1));                             \
+        mc.at(j >> 2, gl::mul_nc(gl::sub(w, comp), f_arith));                                                   \
+      }                                                                                                         \
+    }                                                                                                           \
+    if (h_mext && j < 78) {                                                                                     \
+      if ((JJ) % 6 == 0) mx0 = w;                                                                               \
+      else if ((JJ) % 6 == 1) mx1 = w;                                                                          \
+      else if ((JJ) % 6 == 2) mx2 = w;                                                                          \
+      else if ((JJ) % 6 == 3) mx3 = w;                                                                          \
+      else if ((JJ) % 6 == 4) mx4 = w;                                                                          \
+      else {                                                                                                    \
+        const gl::E2 pr = gl::mul(gl::mul(gl::E2{mx0, mx1}, gl::E2{mx2, mx3}), k0);                             \
+        const int op = j / 6;                                                                                   \
+        mc.at(2 * op, gl::mul_nc(gl::sub(mx4, pr.a), f_mext));                                                  \
+        mc.at(2 * op + 1, gl::mul_nc(gl::sub(w, pr.b), f_mext));                                                \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+#define P25_Q_WIRES8(J0) P25_Q_WIRE(J0) P25_Q_WIRE(J0 + 1) P25_Q_WIRE(J0 + 2) P25_Q_WIRE(J0 + 3) \
+                         P25_Q_WIRE(J0 + 4) P25_Q_WIRE(J0 + 5) P25_Q_WIRE(J0 + 6) P25_Q_WIRE(J0 + 7)
+    for (int base = 0; base < 72; base += 24) {   // 24 = lcm of the op sizes 4 (arithmetic), 6 (mul-ext), 8 (chunks, limb groups)
+      P25_Q_WIRES8(0) P25_Q_WIRES8(8) P25_Q_WIRES8(16)
+    }
+    {
+      const int base = 72;
+      P25_Q_WIRES8(0)
+    }
+#undef P25_Q_WIRES8
+#undef P25_Q_WIRE
+    if (h_bsum) mc.at(0, gl::mul_nc(gl::sub(bs_sum, bs_w0), f_bsum));
+    mg0 = mc.acc0();
+    mg1 = mc.acc1();
+  } else {
+    merged_mask = 0;
+  }
   {
-    const u64 beta0 = a.chal[CH_BETAS], beta1 = a.chal[CH_BETAS + 1];
-    const u64 gamma0 = a.chal[CH_GAMMAS], gamma1 = a.chal[CH_GAMMAS + 1];
     for (int k = 0; k < nch; k++) {
       u64 np0 = 1, dp0 = 1, np1 = 1, dp1 = 1;
       // beta * k_j * x: k_j * beta comes from a per-proof table (k_alpha_pows fills it)
@@ -530,14 +641,11 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     cx.big = big;
     cx.apl = apl;
     const u64 k0 = cs[(size_t)n_consts * big], k1 = cs[(size_t)(n_consts + 1) * big];
-    u64 g0 = 0, g1 = 0;
+    u64 g0 = mg0, g1 = mg1;
     for (uint32_t gi = 0; gi < a.n_gates; gi++) {
       const GateEntry ge = a.gates[gi];
-      const u64 s = cs[(size_t)ge.selector_index * big];
-      u64 filter = 1;
-      for (uint32_t k = ge.group_start; k < ge.group_end; k++)
-        if (k != gi) filter = gl::mul(filter, gl::sub((u64)k, s));
-      if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
+      if ((merged_mask >> ge.kind) & 1u) continue;   // evaluated by the merged pass above
+      const u64 filter = gate_filter(gi);
       cx.reset();
 #ifdef P25_PROFILE_GATE_MASK  // profiling builds only (tools/qmask.sh); never compiled into libp25.so
       if (!((a.debug_gate_mask >> ge.kind) & 1u)) continue;
