@@ -441,13 +441,16 @@ def main():
                     "source": os.path.basename(vp), "csrc_sha": csrc_sha,
                     "shader_clock_hz": clock_hz, "shader_clock_source": clock_note,
                     "frac_of_plain_issue_2cyc": ach / peak2, "frac_of_quarter_rate_4cyc": ach / peak4,
-                    "frac_of_measured_mix_ceiling": ach / (peak4 * 0.88),
+                    "frac_of_measured_mix_ceiling": ach / (peak4 * (4.0 / 4.13)),
                     "leaf_hash_share": sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in per_kernel.items()
                                            if "k_hash_leaves" in k) / instr_per_proof,
                     "note": "ceilings: 1 wave-instruction / SIMD / 2 cycles is the guide's plain-VALU issue rate; every "
-                            "VOP3 / carry / v_mad_u64_u32 instruction (the whole mix here) measures 4.2-4.8 cycles "
-                            "(profiles/r01_instr_rates.txt), i.e. the 4-cycle class; v_mad_u64_u32 (60% of the mix) at "
-                            "4.7 cycles puts this mix's ceiling at 0.88 of the 4-cycle figure"}
+                            "VOP3 / carry / v_mad_u64_u32 instruction (the whole mix here) is of the 4-cycle class; the "
+                            "measured ceiling is what the hash kernels reach with 16 streams of them in flight and nothing "
+                            "else: 4.13 cycles per instruction (profiles/r03_pipeline_model_experiments.txt; a single "
+                            "launch, with its ragged last wave round, measures 4.6).  The proving pipeline stays below it "
+                            "because k_ntt_tile and k_quotient (57 % / 55 % VALU-busy alone) time-share the chip with the "
+                            "hash kernels rather than fill their issue slots"}
         # HBM view per phase and overall: algorithmic bytes of each phase -- inputs read
         # once, outputs written once -- over that phase's device time for one proof alone on the GPU, and
         # all phases x proofs/s for the batch run.
