@@ -125,14 +125,22 @@ __device__ void gate_mul_ext(Ctx& cx, u64 k0) {
     cx.at(2 * i + 1, gl::sub(cx.w(6 * i + 5), p.b));
   }
 }
+// Every evaluator below reads its wires ONE ITERATION AHEAD (`nb`, `ni`, `nxt` ...): left to itself the compiler emits
+// each column load right where its value is used, followed by s_waitcnt vmcnt(0) -- one exposed memory round trip per
+// wire and ~1,000 of them per wave (profiles/r03_pipeline_model_experiments.txt); with the next wire's load issued before
+// the current wire's 40-90 instructions of arithmetic, two loads per wave are in flight and the trip hides behind them.
 __device__ void gate_exponentiation(Ctx& cx) {
   const u64 base = cx.w(0);
   u64 prev_inter = 1;
+  u64 nb = cx.w(1 + (EXP_POWER_BITS - 1)), ni = cx.w(2 + EXP_POWER_BITS);
   for (int i = 0; i < EXP_POWER_BITS; i++) {
     u64 prev = i == 0 ? 1 : gl::mul_nc(prev_inter, prev_inter);  // intermediate values may stay non-canonical
-    u64 bit = cx.w(1 + (EXP_POWER_BITS - 1 - i));
+    const u64 bit = nb, inter = ni;
+    if (i + 1 < EXP_POWER_BITS) {
+      nb = cx.w(1 + (EXP_POWER_BITS - 2 - i));
+      ni = cx.w(3 + EXP_POWER_BITS + i);
+    }
     u64 sel = gl::mad_nc(bit, base, gl::sub(1, bit));              // bit * base + (1 - bit)
-    u64 inter = cx.w(2 + EXP_POWER_BITS + i);
     cx.at(i, gl::sub(gl::mul_nc(prev, sel), inter));
     prev_inter = inter;
   }
@@ -170,12 +178,14 @@ __device__ void gate_u32_arithmetic(Ctx& cx) {
     cx.at(cb + 1, gl::sub(combined, computed));
     // 32 base-4 limbs, most significant first: limbs 31..16 make the high word, 15..0 the low word
     u64 part[4];
+    u64 nxt = cx.w(18 + 32 * i + 31);
 #pragma unroll
     for (int q = 0; q < 4; q++) {  // limbs 31-8q .. 24-8q
       SmallLin acc;
       for (int t = 0; t < 8; t++) {
         const int j = 31 - 8 * q - t;
-        u64 l = cx.w(18 + 32 * i + j);
+        const u64 l = nxt;
+        if (j > 0) nxt = cx.w(18 + 32 * i + j - 1);
         u64 pr = gl::mul_nc(gl::mul_nc(l, gl::sub(l, 1)), gl::mul_nc(gl::sub(l, 2), gl::sub(l, 3)));
         cx.at(cb + 2 + (31 - j), pr);
         acc.add(l, 1u << (2 * (7 - t)));
@@ -191,12 +201,14 @@ __device__ void gate_u32_interleave(Ctx& cx) {
   for (int i = 0; i < 3; i++) {
     const int cb = 34 * i;
     u64 xq[4], xiq[4];  // bits 8q .. 8q+7, most significant first
+    u64 nxt = cx.w(6 + 32 * i);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       SmallLin ax, axi;
       for (int t = 0; t < 8; t++) {
         const int b = 8 * q + t;
-        u64 bit = cx.w(6 + 32 * i + b);
+        const u64 bit = nxt;
+        if (b < 31) nxt = cx.w(6 + 32 * i + b + 1);
         ax.add(bit, 1u << (7 - t));
         axi.add(bit, 1u << (2 * (7 - t)));
         cx.at(cb + 2 + b, gl::mul_nc(bit, gl::sub(bit, 1)));
@@ -212,12 +224,17 @@ __device__ void gate_u32_uninterleave(Ctx& cx) {
   for (int i = 0; i < 2; i++) {
     const int cb = 67 * i;
     u64 xq[4], evq[4], odq[4];  // bit pairs 8q .. 8q+7, most significant first
+    u64 ne = cx.w(6 + 64 * i), no = cx.w(6 + 64 * i + 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       SmallLin ax, aev, aod;
       for (int t = 0; t < 8; t++) {
         const int j = 8 * q + t;
-        u64 be = cx.w(6 + 64 * i + 2 * j), bo = cx.w(6 + 64 * i + 2 * j + 1);
+        const u64 be = ne, bo = no;
+        if (j < 31) {
+          ne = cx.w(6 + 64 * i + 2 * j + 2);
+          no = cx.w(6 + 64 * i + 2 * j + 3);
+        }
         ax.add(be, 2u << (2 * (7 - t)));
         ax.add(bo, 1u << (2 * (7 - t)));
         aev.add(be, 1u << (7 - t));
@@ -255,9 +272,11 @@ __device__ void gate_poseidon2(Ctx& cx) {
 #pragma unroll
     for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2_RC[12 * r + i]);
     if (r != 0) {
+      u64 nxt = cx.w(29 + 12 * (r - 1));
 #pragma unroll
       for (int i = 0; i < 12; i++) {
-        u64 sb = cx.w(29 + 12 * (r - 1) + i);
+        const u64 sb = nxt;
+        if (i < 11) nxt = cx.w(29 + 12 * (r - 1) + i + 1);
         cx.at(nc++, gl::sub(st[i], sb));
         st[i] = sb;
       }
@@ -266,9 +285,11 @@ __device__ void gate_poseidon2(Ctx& cx) {
     for (int i = 0; i < 12; i++) st[i] = sbox(st[i]);
     matmul_external(st);
   }
+  u64 nsb = cx.w(65);
   for (int r = 0; r < ROUND_P; r++) {
     st[0] = gl::add(st[0], P2_RC_MID[r]);
-    u64 sb = cx.w(65 + r);
+    const u64 sb = nsb;
+    if (r + 1 < ROUND_P) nsb = cx.w(66 + r);
     cx.at(nc++, gl::sub(st[0], sb));
     st[0] = sbox(sb);
     matmul_internal(st);
@@ -276,9 +297,11 @@ __device__ void gate_poseidon2(Ctx& cx) {
   for (int r = ROUND_F_BEGIN; r < ROUND_F_END; r++) {
 #pragma unroll
     for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2_RC[12 * r + i]);
+    u64 nxt = cx.w(87 + 12 * (r - ROUND_F_BEGIN));
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-      u64 sb = cx.w(87 + 12 * (r - ROUND_F_BEGIN) + i);
+      const u64 sb = nxt;
+      if (i < 11) nxt = cx.w(87 + 12 * (r - ROUND_F_BEGIN) + i + 1);
       cx.at(nc++, gl::sub(st[i], sb));
       st[i] = sb;
     }
@@ -545,6 +568,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     mc.apl = apl;
     mc.reset();
     u64 bs_sum = 0, bs_w0 = 0;
+    u64 wnext = wr[0];   // the wire read one position ahead
     SmallLin bs_acc;
     u64 ar0 = 0, ar1 = 0, ar2 = 0;                    // arithmetic: multiplicand 0, multiplicand 1, addend of the current op
     u64 mx0 = 0, mx1 = 0, mx2 = 0, mx3 = 0, mx4 = 0;  // mul-extension: a, b and output.a of the current op
@@ -552,7 +576,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
 #define P25_Q_WIRE(JJ)                                                                                          \
   {                                                                                                             \
     const int j = base + (JJ);                                                                                  \
-    const u64 w = wr[(size_t)j * big];                                                                          \
+    const u64 w = wnext;                                                                                        \
+    if (j + 1 < 80) wnext = wr[(size_t)(j + 1) * big];                                                          \
     if ((JJ) < 4 && base == 0) {                                                                                \
       if (h_const && (JJ) < 2) mc.at((JJ), gl::mul_nc(gl::sub((JJ) == 0 ? k0 : k1, w), f_const));              \
       if (h_pi) mc.at((JJ), gl::mul_nc(gl::sub(w, a.pi_hash[(JJ)]), f_pi));                                     \
@@ -610,12 +635,16 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     merged_mask = 0;
   }
   {
+    u64 wn = wr[0], sn = cs[(size_t)(n_consts + 2) * big];   // wire and sigma read one position ahead
     for (int k = 0; k < nch; k++) {
       u64 np0 = 1, dp0 = 1, np1 = 1, dp1 = 1;
       // beta * k_j * x: k_j * beta comes from a per-proof table (k_alpha_pows fills it)
       for (int j = k * per; j < (k + 1) * per && j < RW; j++) {
-        const u64 w = wr[(size_t)j * big];
-        const u64 sg = cs[(size_t)(n_consts + 2 + j) * big];
+        const u64 w = wn, sg = sn;
+        if (j + 1 < RW) {
+          wn = wr[(size_t)(j + 1) * big];
+          sn = cs[(size_t)(n_consts + 3 + j) * big];
+        }
         const u64 wg0 = gl::add(w, gamma0), wg1 = gl::add(w, gamma1);
         np0 = gl::mul_nc(np0, gl::mad_nc(kb[j], x, wg0));
         dp0 = gl::mul_nc(dp0, gl::mad_nc(beta0, sg, wg0));
