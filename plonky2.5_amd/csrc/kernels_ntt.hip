@@ -113,9 +113,8 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
 
   // coset pre-scale: one table entry per input coefficient (shift_c^k at the coefficient's address k)
   const u64* pre = a.pre ? a.pre + ((size_t)coset << (a.log_r + a.log_nt)) : nullptr;
-  for (int e = tid; e < T * R; e += nth) {
+  auto in_slot = [&](int e, size_t& addr, int& slot) {
     int t, i;
-    size_t addr;
     if (a.in_kind == 0) {
       t = e & (T - 1);
       i = e >> a.log_t;
@@ -128,9 +127,33 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
       u32 trow = a.in_br_t ? gl::bitrev(tg0 + t, a.log_nt) : tg0 + t;
       addr = (size_t)trow * R + off;
     }
+    slot = i * TP + t;
+  };
+  // Eight elements per lane at a time: their loads (value + pre-scale factor) are all issued before the first is used.
+  // (One element per iteration, as the loop was written first, is one exposed memory round trip per element: the
+  // compiler puts s_waitcnt vmcnt(0) right behind each load.)
+  constexpr int LB = 8;
+  int e = tid;
+  for (; e + (LB - 1) * nth < T * R; e += LB * nth) {
+    u64 xv[LB], pv[LB];
+    int slot[LB];
+#pragma unroll
+    for (int k = 0; k < LB; k++) {
+      size_t addr;
+      in_slot(e + k * nth, addr, slot[k]);
+      xv[k] = in[addr];
+      pv[k] = pre ? pre[addr] : 1;
+    }
+#pragma unroll
+    for (int k = 0; k < LB; k++) lds[slot[k]] = pre ? gl::mul(xv[k], pv[k]) : xv[k];
+  }
+  for (; e < T * R; e += nth) {
+    size_t addr;
+    int slot;
+    in_slot(e, addr, slot);
     u64 x = in[addr];
     if (pre) x = gl::mul(x, pre[addr]);
-    lds[i * TP + t] = x;
+    lds[slot] = x;
   }
   __syncthreads();
 
@@ -160,14 +183,12 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
     s0 += g;
   }
 
-  for (int e = tid; e < T * R; e += nth) {
+  auto out_slot = [&](int e, size_t& addr, int& slot, u32& tw, u32& j) {
     int t, q;
-    u32 j;  // frequency index held at LDS position q
-    size_t addr;
     if (a.out_kind == 0) {
       t = e & (T - 1);
       q = e >> a.log_t;
-      j = gl::bitrev(q, a.log_r);
+      j = gl::bitrev(q, a.log_r);   // frequency index held at LDS position q
       u32 ipos = a.out_br_i ? (u32)q : j;
       addr = (size_t)(tg0 + t) + (size_t)ipos * NT;
     } else {
@@ -178,9 +199,35 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
       u32 trow = a.out_br_t ? gl::bitrev(tg0 + t, a.log_nt) : tg0 + t;
       addr = (size_t)trow * R + off;
     }
-    u64 x = lds[q * TP + t];
-    if (a.use_twiddle) x = gl::mul(x, a.pow_table[(size_t)(tg0 + t) * j]);
-    if (a.post_t) x = gl::mul(x, gl::mul(a.post_t[tg0 + t], a.post_i[j]));
+    slot = q * TP + t;
+    tw = (u32)(tg0 + t);
+  };
+  // the four-step twiddles (a gather from the power table) likewise eight at a time
+  int eo = tid;
+  if (a.use_twiddle && !a.post_t) {
+    for (; eo + (LB - 1) * nth < T * R; eo += LB * nth) {
+      u64 wv[LB], xv[LB];
+      size_t addr[LB];
+#pragma unroll
+      for (int k = 0; k < LB; k++) {
+        int slot;
+        u32 tw, j;
+        out_slot(eo + k * nth, addr[k], slot, tw, j);
+        wv[k] = a.pow_table[(size_t)tw * j];
+        xv[k] = lds[slot];
+      }
+#pragma unroll
+      for (int k = 0; k < LB; k++) out[addr[k]] = gl::mul(xv[k], wv[k]);
+    }
+  }
+  for (; eo < T * R; eo += nth) {
+    size_t addr;
+    int slot;
+    u32 tw, j;
+    out_slot(eo, addr, slot, tw, j);
+    u64 x = lds[slot];
+    if (a.use_twiddle) x = gl::mul(x, a.pow_table[(size_t)tw * j]);
+    if (a.post_t) x = gl::mul(x, gl::mul(a.post_t[tw], a.post_i[j]));
     out[addr] = x;
   }
 }
