@@ -277,7 +277,8 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
                                p25_timings* timings);
 p25_status p25_circuit_sync(p25_circuit* c);
 /* Proofs kept in flight by the batch entry points: one HIP stream and one per-proof working set (~1.6 GB for the
- * fib-64 circuit) each; 1..16, default 16.  A library setting, not an environment variable. */
+ * fib-64 circuit) each; 1..32, default 16 (12 .. 20 measure the same, 24 and more are slower).  A library setting, not an
+ * environment variable. */
 p25_status p25_circuit_set_streams(p25_circuit* c, int32_t n_streams);
 /* Measurement hook for bench.py's roofline line: when enabled, HIP events on the proving stream
  * bracket every launch of the dominant kernel (the Poseidon leaf sponge over the 135-column wires

@@ -540,7 +540,7 @@ class Circuit:
         _check(lib().p25_circuit_sync(self._h))
 
     def set_streams(self, n):
-        """Proofs kept in flight by the batch entry points (1..16)."""
+        """Proofs kept in flight by the batch entry points (1..32, default 16)."""
         _check(lib().p25_circuit_set_streams(self._h, n))
 
     def kernel_stats(self, enable=True, reset=False):

@@ -240,10 +240,6 @@ void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st
   // not fit the 64 KB of LDS a block may take with it and keeps the half table and the radix-2 network
   q.full_table = p.log_r <= 10;
   size_t lds = ((size_t)R * TP + (q.full_table ? R : R / 2)) * sizeof(u64);
-  {  // occupancy cap through extra dynamic LDS (experiment knob, bytes per workgroup; 0 = none)
-    static const size_t pad = [] { const char* e = getenv("P25_NTT_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    if (lds + pad <= 64 * 1024) lds += pad;
-  }
   q.n_tiles = 1u << (p.log_nt - p.log_t);
   q.n_cosets = (uint32_t)n_cosets;
   q.xcd_map = n_cosets > 1 && (q.n_tiles & 7u) == 0;
@@ -256,10 +252,6 @@ void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st
 
 static int pick_log_t(int log_r, int log_nt) {
   int lt = 12 - log_r;
-  {  // experiment knob: tile width cap (log2 of adjacent sub-transforms per workgroup)
-    static const int cap = [] { const char* e = getenv("P25_NTT_LOG_T"); return e ? atoi(e) : 4; }();
-    if (lt > cap) lt = cap;
-  }
   if (lt > 4) lt = 4;
   if (lt > log_nt) lt = log_nt;
   if (lt < 0) lt = 0;

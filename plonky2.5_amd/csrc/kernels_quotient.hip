@@ -741,14 +741,6 @@ void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bit
                      degree_bits + rate_bits, d_out);
 }
 
-// Occupancy cap of k_quotient through dynamic LDS (experiment knob, P25_Q_LDS_PAD bytes per workgroup; 0 = none).
-static size_t quotient_lds_pad() {
-  static const size_t pad = [] {
-    const char* e = getenv("P25_Q_LDS_PAD");
-    return e ? (size_t)atol(e) : (size_t)0;
-  }();
-  return pad;
-}
 void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   QuotientArgs a = a_in;
 #ifdef P25_PROFILE_GATE_MASK
@@ -771,7 +763,7 @@ void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   if (rec)
     hipLaunchKernelGGL(k_quotient_rec, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
   else
-    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), quotient_lds_pad(), st, a);
+    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
 }
 
 }  // namespace p25
