@@ -181,17 +181,39 @@ static_assert(MDS_CIRC[0] == 17 && MDS_CIRC[1] == 15 && MDS_CIRC[2] == 41 && MDS
 #endif
 #include "poseidon_p3r.h"
 
-__device__ __forceinline__ void permute_dev(u64 s[WIDTH], u32 rows) {
+// x^7 of the round-0 constants of the capacity words: what the first S-box layer yields for them when the capacity
+// enters as zero (the first permutation of every sponge, every two_to_one) -- 4 of that layer's 12 S-boxes.
+constexpr u64 sbox_const(u64 x) {
+  const unsigned __int128 p = gl::P;
+  u64 x2 = (u64)((unsigned __int128)x * x % p), x4 = (u64)((unsigned __int128)x2 * x2 % p), x3 = (u64)((unsigned __int128)x * x2 % p);
+  return (u64)((unsigned __int128)x3 * x4 % p);
+}
+static constexpr u64 SBOX_RC0_CAP[4] = {sbox_const(RC[8]), sbox_const(RC[9]), sbox_const(RC[10]), sbox_const(RC[11])};
+
+// cap0 (wave-uniform): the caller guarantees s[8..11] == 0
+__device__ __forceinline__ void permute_dev(u64 s[WIDTH], u32 rows, bool cap0 = false) {
 #pragma unroll
-  for (int i = 0; i < WIDTH; i++) s[i] = add_rc(s[i], RC[i]);
+  for (int i = 0; i < RATE; i++) s[i] = add_rc(s[i], RC[i]);
   // Opaque base pointer: otherwise every one of the 24 scalar loads per round recomputes the table's
   // pc-relative address (s_getpc + 4 scalar adds each).
   rc_ptr rc = (rc_ptr)RC_SPLIT.v;
   asm("" : "+s"(rc));
   int r = 1;
 #if P25_PARTIAL3
-  // full rounds 0..2 with their MDS layers; round 3's S-boxes only -- its MDS is the first layer of the head block
-  for (int k = 0; k < HALF_FULL - 1; k++, r++) {
+  // full round 0: the capacity words' S-boxes are constants when the capacity is zero
+#pragma unroll
+  for (int i = 0; i < RATE; i++) s[i] = sbox(s[i]);
+  if (cap0) {
+#pragma unroll
+    for (int i = RATE; i < WIDTH; i++) s[i] = SBOX_RC0_CAP[i - RATE];
+  } else {
+#pragma unroll
+    for (int i = RATE; i < WIDTH; i++) s[i] = sbox(add_rc(s[i], RC[i]));
+  }
+  mds_rc(s, rc + 2 * WIDTH * r);
+  r++;
+  // full rounds 1, 2 with their MDS layers; round 3's S-boxes only -- its MDS is the first layer of the head block
+  for (int k = 1; k < HALF_FULL - 1; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
     mds_rc(s, rc + 2 * WIDTH * r);
@@ -206,6 +228,8 @@ __device__ __forceinline__ void permute_dev(u64 s[WIDTH], u32 rows) {
   p3r::two_rounds(s, tp);
   r = HALF_FULL + N_PARTIAL + 1;
 #else
+#pragma unroll
+  for (int i = RATE; i < WIDTH; i++) s[i] = add_rc(s[i], RC[i]);
   for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
@@ -234,11 +258,12 @@ __device__ __forceinline__ void permute_dev(u64 s[WIDTH], u32 rows) {
 // defined afterwards (the others hold unspecified canonical values).  In an overwrite-mode sponge every
 // absorbing permutation is followed by 8 fresh inputs, so only its capacity words 8..11 matter, and the
 // last one only yields the 4 digest words: 8 of the 12 rows of the final MDS layer are never computed.
-GL_HD void permute_rows(u64 s[WIDTH], u32 rows) {
+GL_HD void permute_rows(u64 s[WIDTH], u32 rows, bool cap0 = false) {
 #if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
-  permute_dev(s, rows);
+  permute_dev(s, rows, cap0);
 #else
   (void)rows;
+  (void)cap0;
   int r = 0;
   for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
@@ -275,7 +300,7 @@ GL_HD void two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
     s[4 + i] = r[i];
     s[8 + i] = 0;
   }
-  permute_rows(s, ROWS_DIGEST);
+  permute_rows(s, ROWS_DIGEST, true);
 #pragma unroll
   for (int i = 0; i < 4; i++) out[i] = s[i];
 }
@@ -289,7 +314,7 @@ GL_HD void hash_no_pad_strided(const u64* in, size_t stride, int n, u64 out[4]) 
     int m = n - off < RATE ? n - off : RATE;
     for (int i = 0; i < m; i++) s[i] = in[(size_t)(off + i) * stride];
     const int next = n - (off + RATE);  // inputs still to absorb after this permutation
-    permute_rows(s, next <= 0 ? ROWS_DIGEST : (next >= RATE ? ROWS_CAPACITY : ROWS_ALL));
+    permute_rows(s, next <= 0 ? ROWS_DIGEST : (next >= RATE ? ROWS_CAPACITY : ROWS_ALL), off == 0);
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) out[i] = s[i];
