@@ -20,6 +20,11 @@
 //   * six regular blocks for rounds 6..23;
 //   * a TAIL block of two rounds (24, 25) built on M^2.
 // so the MDS layer of full round 3 costs nothing extra and no single round is left over.
+// Round constants of words 1..11 are DEFERRED: between the head block and the tail block the registers hold
+// t = (true state) - o, o a constant vector with o[0] = 0 that each block pushes through its own linear map
+// (o' = M^3 o + K3, its word 0 taken out and added to the block's row 0), so that the head and the six regular blocks
+// add constants to the two S-box inputs and to row 0 only -- 22 multiply-adds per block less -- and the tail block's
+// twelve constants absorb M^2 o and make the state true again.  (Word 0 cannot be deferred: it goes through the S-box.)
 // The arithmetic is exact integer arithmetic mod p: results are bit-identical to the round-by-round form.
 #pragma once
 
@@ -49,24 +54,38 @@ constexpr u64 mulmod(u64 a, u64 b) { return (u64)((unsigned __int128)a * b % gl:
 constexpr u64 addmod(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % gl::P); }
 constexpr u64 mds_entry(int r, int j) { return MDS_CIRC[(j - r + WIDTH) % WIDTH] + (r == 0 && j == 0 ? MDS_DIAG0 : 0); }
 
-// constants of a block whose three linear layers are followed by the constants of rounds r0+1, r0+2, r0+3
-constexpr void block_constants(u32* out, int r0, const u64 (&M)[WIDTH][WIDTH], const u64 (&M2)[WIDTH][WIDTH]) {
+// constants of a block whose three linear layers are followed by the constants of rounds r0+1, r0+2, r0+3, given the
+// deferred offset o of the state entering it (o[0] == 0); on return o is the offset of the state leaving it
+constexpr void block_constants(u32* out, int r0, const u64 (&M)[WIDTH][WIDTH], const u64 (&M2)[WIDTH][WIDTH],
+                               const u64 (&M3)[WIDTH][WIDTH], u64 (&o)[WIDTH]) {
   const u64* c1 = RC + WIDTH * (r0 + 1);
   const u64* c2 = RC + WIDTH * (r0 + 2);
   const u64* c3 = RC + WIDTH * (r0 + 3);
   u64 k1 = c1[0];
   u64 k2 = c2[0];
-  for (int j = 0; j < WIDTH; j++) k2 = addmod(k2, mulmod(M[0][j], c1[j]));
+  for (int j = 0; j < WIDTH; j++) {
+    k1 = addmod(k1, mulmod(M[0][j], o[j]));
+    k2 = addmod(k2, addmod(mulmod(M[0][j], c1[j]), mulmod(M2[0][j], o[j])));
+  }
   out[0] = (u32)k1;
   out[1] = (u32)(k1 >> 32);
   out[2] = (u32)k2;
   out[3] = (u32)(k2 >> 32);
+  u64 on[WIDTH] = {};
   for (int r = 0; r < WIDTH; r++) {
     u64 k3 = c3[r];
-    for (int j = 0; j < WIDTH; j++) k3 = addmod(k3, addmod(mulmod(M2[r][j], c1[j]), mulmod(M[r][j], c2[j])));
-    out[4 + 2 * r] = (u32)k3;
-    out[5 + 2 * r] = (u32)(k3 >> 32);
+    for (int j = 0; j < WIDTH; j++)
+      k3 = addmod(k3, addmod(addmod(mulmod(M2[r][j], c1[j]), mulmod(M[r][j], c2[j])), mulmod(M3[r][j], o[j])));
+    on[r] = k3;
   }
+  out[4] = (u32)on[0];          // row 0 takes its constant now (it is the next S-box input)
+  out[5] = (u32)(on[0] >> 32);
+  for (int r = 1; r < WIDTH; r++) {
+    out[4 + 2 * r] = 0;          // rows 1..11: deferred
+    out[5 + 2 * r] = 0;
+  }
+  on[0] = 0;
+  for (int r = 0; r < WIDTH; r++) o[r] = on[r];
 }
 
 constexpr Tables make_tables() {
@@ -95,16 +114,19 @@ constexpr Tables make_tables() {
   for (int j = 0; j < WIDTH; j++) t.r2.c[j] = (u32)M2[0][j];
   t.r2.c[12] = (u32)M2[0][0];
   t.r2.c[13] = (u32)M[0][0];
-  for (int b = 0; b < BLOCKS; b++) block_constants(t.kc[b], FIRST_BLOCK + 3 * b, M, M2);
-  block_constants(t.kh, HEAD_ROUND, M, M2);
-  {  // tail: v2 = M^2 v + d0 (M m0) + d1 m0 + (M c1 + c2), c1 = RC[25], c2 = RC[26]
+  u64 o[WIDTH] = {};   // the deferred offset, in program order: head block, regular blocks, tail
+  block_constants(t.kh, HEAD_ROUND, M, M2, M3, o);
+  for (int b = 0; b < BLOCKS; b++) block_constants(t.kc[b], FIRST_BLOCK + 3 * b, M, M2, M3, o);
+  {  // tail: v2 = M^2 (t + o) + d0 (M m0) + d1 m0 + (M c1 + c2), c1 = RC[25], c2 = RC[26]: the state is true again
     const u64* c1 = RC + WIDTH * (TAIL_ROUND + 1);
     const u64* c2 = RC + WIDTH * (TAIL_ROUND + 2);
-    t.kt[0] = (u32)c1[0];
-    t.kt[1] = (u32)(c1[0] >> 32);
+    u64 k1 = c1[0];
+    for (int j = 0; j < WIDTH; j++) k1 = addmod(k1, mulmod(M[0][j], o[j]));
+    t.kt[0] = (u32)k1;
+    t.kt[1] = (u32)(k1 >> 32);
     for (int r = 0; r < WIDTH; r++) {
       u64 k = c2[r];
-      for (int j = 0; j < WIDTH; j++) k = addmod(k, mulmod(M[r][j], c1[j]));
+      for (int j = 0; j < WIDTH; j++) k = addmod(k, addmod(mulmod(M[r][j], c1[j]), mulmod(M2[r][j], o[j])));
       t.kt[4 + 2 * r] = (u32)k;
       t.kt[5 + 2 * r] = (u32)(k >> 32);
     }
@@ -133,10 +155,8 @@ constexpr void rounds_ref(u64 (&w)[WIDTH], int r0, int n, bool skip_first) {
     }
   }
 }
-constexpr bool block_consistent(const u32* kc, int r0, bool skip_first, int salt) {
-  u64 v[WIDTH] = {}, w[WIDTH] = {};
-  for (int i = 0; i < WIDTH; i++) v[i] = w[i] = mulmod(0x9E3779B97F4A7C15ull % gl::P, (u64)(i + 1 + 13 * salt));
-  rounds_ref(w, r0, 3, skip_first);
+// one block through the tables, exactly as three_rounds does it (rows 1..11 without a constant)
+constexpr void block_emulated(u64 (&v)[WIDTH], const u32* kc, bool skip_first) {
   u64 d[3] = {};
   u64 x = v[0];
   d[0] = skip_first ? 0 : addmod(sbox_ref(x), gl::P - x);
@@ -150,18 +170,16 @@ constexpr bool block_consistent(const u32* kc, int r0, bool skip_first, int salt
   a = addmod(a, addmod(mulmod(TBL.r2.c[12], d[0]), mulmod(TBL.r2.c[13], d[1])));
   x = a;
   d[2] = addmod(sbox_ref(x), gl::P - x);
+  u64 w[WIDTH] = {};
   for (int r = 0; r < WIDTH; r++) {
-    a = kpair(kc, 4 + 2 * r);
+    a = r == 0 ? kpair(kc, 4) : 0;
     for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.t3[r].c[j], v[j]));
     for (int e = 0; e < 3; e++) a = addmod(a, mulmod(TBL.t3[r].c[12 + e], d[e]));
-    if (a != w[r]) return false;
+    w[r] = a;
   }
-  return true;
+  for (int r = 0; r < WIDTH; r++) v[r] = w[r];
 }
-constexpr bool tail_consistent() {
-  u64 v[WIDTH] = {}, w[WIDTH] = {};
-  for (int i = 0; i < WIDTH; i++) v[i] = w[i] = mulmod(0x9E3779B97F4A7C15ull % gl::P, (u64)(i + 977));
-  rounds_ref(w, TAIL_ROUND, 2, false);
+constexpr void tail_emulated(u64 (&v)[WIDTH]) {
   u64 d[2] = {};
   u64 x = v[0];
   d[0] = addmod(sbox_ref(x), gl::P - x);
@@ -170,19 +188,30 @@ constexpr bool tail_consistent() {
   a = addmod(a, mulmod(mds_entry(0, 0), d[0]));
   x = a;
   d[1] = addmod(sbox_ref(x), gl::P - x);
+  u64 w[WIDTH] = {};
   for (int r = 0; r < WIDTH; r++) {
     a = kpair(TBL.kt, 4 + 2 * r);
     for (int j = 0; j < WIDTH; j++) a = addmod(a, mulmod(TBL.t2[r].c[j], v[j]));
     for (int e = 0; e < 2; e++) a = addmod(a, mulmod(TBL.t2[r].c[12 + e], d[e]));
-    if (a != w[r]) return false;
+    w[r] = a;
   }
+  for (int r = 0; r < WIDTH; r++) v[r] = w[r];
+}
+// the whole chain (MDS of round 3 + the 22 partial rounds) through the tables == the same rounds one at a time
+constexpr bool chain_consistent(int salt) {
+  u64 v[WIDTH] = {}, w[WIDTH] = {};
+  for (int i = 0; i < WIDTH; i++) v[i] = w[i] = mulmod(0x9E3779B97F4A7C15ull % gl::P, (u64)(i + 1 + 13 * salt));
+  rounds_ref(w, HEAD_ROUND, 3, true);
+  for (int b = 0; b < BLOCKS; b++) rounds_ref(w, FIRST_BLOCK + 3 * b, 3, false);
+  rounds_ref(w, TAIL_ROUND, 2, false);
+  block_emulated(v, TBL.kh, true);
+  for (int b = 0; b < BLOCKS; b++) block_emulated(v, TBL.kc[b], false);
+  tail_emulated(v);
+  for (int r = 0; r < WIDTH; r++)
+    if (v[r] != w[r]) return false;
   return true;
 }
-constexpr bool tables_consistent() {
-  for (int b = 0; b < BLOCKS; b++)
-    if (!block_consistent(TBL.kc[b], FIRST_BLOCK + 3 * b, false, b)) return false;
-  return block_consistent(TBL.kh, HEAD_ROUND, true, 101) && tail_consistent();
-}
+constexpr bool tables_consistent() { return chain_consistent(0) && chain_consistent(7) && chain_consistent(101); }
 static_assert(tables_consistent(), "poseidon_p3r.h: block tables disagree with the round-by-round definition");
 
 typedef const Tables __attribute__((address_space(4))) * tbl_ptr;
@@ -218,7 +247,7 @@ __device__ __forceinline__ u64 reduce_row(u64 al, u64 ah) {
 }
 
 // One row: sum_j coef[j] v_j + sum_{e in [E0, E0 + NEXTRA)} coef[12 + e] d_e + k, on 32-bit halves.
-template <int E0, int NEXTRA>
+template <int E0, int NEXTRA, bool WITH_K = true>
 __device__ __forceinline__ u64 row(const u32* lo, const u32* hi, const Row16& cf, const u32* dlo, const u32* dhi,
                                    u32 klo, u32 khi) {
   u64 al = mul_s(lo[0], cf.c[0]), ah = mul_s(hi[0], cf.c[0]);
@@ -232,8 +261,10 @@ __device__ __forceinline__ u64 row(const u32* lo, const u32* hi, const Row16& cf
     mad_s(al, dlo[e], cf.c[12 + e]);
     mad_s(ah, dhi[e], cf.c[12 + e]);
   }
-  add_s(al, klo);
-  add_s(ah, khi);
+  if (WITH_K) {
+    add_s(al, klo);
+    add_s(ah, khi);
+  }
   return reduce_row(al, ah);
 }
 // Row 0 of M (inline-constant entries 25, 15, 41, ..., 20) applied to the state, + 25 d (if WITH_D) + k
@@ -295,7 +326,10 @@ __device__ __forceinline__ void three_rounds(u64 s[WIDTH], tbl_ptr tp, k_ptr kc)
   for (int r = 0; r < WIDTH; r++) {
     Row16 cf;
     load_row(cf, &tp->t3[r]);
-    s[r] = row<HEAD ? 1 : 0, HEAD ? 2 : 3>(lo, hi, cf, dlo, dhi, kc[4 + 2 * r], kc[5 + 2 * r]);
+    if (r == 0)
+      s[r] = row<HEAD ? 1 : 0, HEAD ? 2 : 3, true>(lo, hi, cf, dlo, dhi, kc[4], kc[5]);
+    else   // constants of words 1..11 are deferred to the tail block
+      s[r] = row<HEAD ? 1 : 0, HEAD ? 2 : 3, false>(lo, hi, cf, dlo, dhi, 0, 0);
   }
 }
 // The last two partial rounds.
