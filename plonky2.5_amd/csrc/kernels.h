@@ -10,6 +10,22 @@
 #include <tuple>
 #include "gl.h"
 
+// Wave priority (s_setprio, 0..3) in the SIMDs' issue arbitration.  The bulk hash kernels (k_hash_leaves*, k_tree_level,
+// k_pow_search: 68 % of all VALU work, always enough of it resident to fill every issue slot) stay at 0; the kernels whose
+// waves spend their lives waiting for memory, LDS or barriers (NTT, quotient, partial products, openings, FRI) run at 2
+// and the single-wave chains (transcript, cooperative Merkle tops, witness levels) at 3, so that when they CAN issue they
+// do, finish, and give their registers and LDS back.  Measured: profiles/r03_pipeline_model_experiments.txt item 16.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define P25_WAVE_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define P25_WAVE_PRIO(n) ((void)0)
+#endif
+#ifndef P25_PRIO_BULK
+#define P25_PRIO_BULK 2
+#endif
+#ifndef P25_PRIO_CHAIN
+#define P25_PRIO_CHAIN 3
+#endif
 namespace p25 {
 
 struct HipError : std::runtime_error {

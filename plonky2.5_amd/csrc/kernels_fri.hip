@@ -17,6 +17,7 @@ namespace p25 {
 // out[t] = (scale * point)^t for t <= count (count+1 entries), as (a, b) pairs
 __global__ void k_ext_pows(const u64* __restrict__ point, u64 scale, uint32_t count, int invert,
                            u64* __restrict__ out) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > count) return;
   gl::E2 z = gl::mul(gl::E2{point[0], point[1]}, scale);
@@ -34,6 +35,7 @@ constexpr uint32_t EVAL_CHUNK_LOG = 16;  // polynomials longer than 2^16 are spl
 __global__ __launch_bounds__(1024) void k_eval_polys(const u64* __restrict__ coeffs, uint32_t log_n, uint32_t log_chunk,
                                                      const u64* __restrict__ pows /*[S+1] ext*/,
                                                      u64* __restrict__ out) {
+  P25_WAVE_PRIO(P25_PRIO_BULK);
   __shared__ u64 sa[EVAL_LANES], sb[EVAL_LANES];
   const uint32_t n = 1u << log_chunk;
   const uint32_t S = n < EVAL_LANES ? n : EVAL_LANES;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(1024) void k_eval_polys(const u64* __restrict__ coe
 // out[p] = sum_b part[p][b] (z^chunk)^b  (Horner over the chunks of polynomial p)
 __global__ void k_eval_combine(const u64* __restrict__ part, uint32_t n_polys, uint32_t chunks, uint32_t log_chunk,
                                const u64* __restrict__ point, u64 scale, u64* __restrict__ out) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_polys) return;
   gl::E2 y = gl::exp_pow2(gl::mul(gl::E2{point[0], point[1]}, scale), log_chunk);
@@ -106,6 +109,7 @@ struct CombineK {
   u64* comp;
 };
 __global__ __launch_bounds__(256) void k_fri_comp(CombineK a) {
+  P25_WAVE_PRIO(P25_PRIO_BULK);
   extern __shared__ u64 ap[];  // alpha^j as (a,b), j < total
   uint32_t total = a.n_polys[0] + a.n_polys[1] + a.n_polys[2] + a.n_polys[3];
   for (uint32_t i = threadIdx.x; i < 2 * total; i += blockDim.x) ap[i] = a.alpha_pows[i];
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void k_fri_comp(CombineK a) {
 // exclusive SUFFIX sums (field addition) of `count` arrays of length n, in place:
 // data[k] <- sum_{j > k} data[j].  Three phases; index reversed so that it is a prefix scan.
 __global__ __launch_bounds__(256) void k_sfx_block(u64* data, uint32_t n, u64* block_tot) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 sh[256];
   u64* d = data + (size_t)blockIdx.y * n;
   uint32_t i = blockIdx.x * 256 + threadIdx.x;  // reversed index
@@ -157,6 +162,7 @@ __global__ __launch_bounds__(256) void k_sfx_block(u64* data, uint32_t n, u64* b
   if (threadIdx.x == 255) block_tot[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = v;
 }
 __global__ __launch_bounds__(256) void k_sfx_totals(u64* block_tot, uint32_t n_blocks) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 sh[256];
   __shared__ u64 carry_s;
   u64* bt = block_tot + (size_t)blockIdx.x * n_blocks;
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(256) void k_sfx_totals(u64* block_tot, uint32_t n_b
   }
 }
 __global__ __launch_bounds__(256) void k_sfx_apply(u64* data, uint32_t n, const u64* block_tot) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   u64* d = data + (size_t)blockIdx.y * n;
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(256) void k_fri_final(const u64* __restrict__ S, ui
                                                    const u64* __restrict__ zinv0, const u64* __restrict__ zinv1,
                                                    const u64* __restrict__ alpha_pows, uint32_t nc,
                                                    u64* __restrict__ fa, u64* __restrict__ fb) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   if (k == n - 1) {
@@ -247,6 +255,7 @@ __global__ __launch_bounds__(256) void k_fri_fold(const u64* __restrict__ ca, co
                                                   uint32_t len_out, uint32_t arity_bits,
                                                   const u64* __restrict__ beta, u64* __restrict__ oa,
                                                   u64* __restrict__ ob) {
+  P25_WAVE_PRIO(P25_PRIO_BULK);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= len_out) return;
   const uint32_t arity = 1u << arity_bits;
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64* __restrict__ v
 __global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64* __restrict__ va, const u64* __restrict__ vb,
                                                             uint32_t n_leaves, uint32_t arity_bits,
                                                             u64* __restrict__ digests) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 rc_lds[360];
   coop::stage_poseidon_rc(rc_lds);
   size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / coop::GROUP;
@@ -327,6 +337,7 @@ void launch_fri_leaf_hash(const u64* va, const u64* vb, uint32_t n_leaves, uint3
 __device__ __forceinline__ size_t level_off(size_t n_leaves, uint32_t k) { return 8 * n_leaves - ((8 * n_leaves) >> k); }
 
 __global__ __launch_bounds__(256) void k_queries(QueryArgs a) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   const uint32_t q = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   const size_t big = (size_t)1 << a.lde_bits;
   size_t x = (size_t)(a.chal[CH_QUERIES + q] & (big - 1));  // challenge mod 2^lde_bits

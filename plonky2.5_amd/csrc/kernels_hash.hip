@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64, P25_TREE_MINW) void k_tree_level(const u64* __r
 // is a handful of hashes and its latency, not its throughput, is what the proof waits for.
 __global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__ children,
                                                          u64* __restrict__ parents, size_t n_parents) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 rc_lds[360];
   coop::stage_poseidon_rc(rc_lds);
   size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / coop::GROUP;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(256) void k_tree_level_coop(const u64* __restrict__
 constexpr int TOP_GROUPS = 16;                       // 256 lanes per block
 constexpr size_t TOP_MAX_NODES = 2 * TOP_GROUPS;     // nodes per cap entry at the level the kernel starts from
 __global__ __launch_bounds__(256) void k_tree_top_coop(u64* __restrict__ nodes, uint32_t per_block, uint32_t n_blocks) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 rc_lds[360];
   __shared__ u64 lvl[2][TOP_GROUPS * 4];
   coop::stage_poseidon_rc(rc_lds);

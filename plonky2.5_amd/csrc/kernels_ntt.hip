@@ -81,6 +81,7 @@ __device__ __forceinline__ void dif16_group(u64* col, const u64* wl, int step, i
 
 template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
+  P25_WAVE_PRIO(P25_PRIO_BULK);
   extern __shared__ u64 lds[];
   const int R = 1 << a.log_r, T = 1 << a.log_t;
   const int TP = T > 1 ? T + 1 : 1;  // row padding: conflict-free for both access directions

@@ -452,6 +452,7 @@ __device__ void gate_poseidon(Ctx& cx) {
 
 // alpha_pows[c][j] = alpha_c^j, j < ALPHA_POWS
 __global__ void k_alpha_pows(const u64* __restrict__ chal, u64* __restrict__ out) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   int c = blockIdx.x, j = threadIdx.x;
   if (j < ALPHA_POWS) out[c * ALPHA_POWS + j] = gl::pow(chal[CH_ALPHAS + c], (u64)j);
 }
@@ -724,12 +725,14 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   a.out[big + p] = gl::mul(res[1], zhi);
 }
 
-__global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) { quotient_body<false>(a); }
+__global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
+  P25_WAVE_PRIO(P25_PRIO_BULK); quotient_body<false>(a); }
 __global__ __launch_bounds__(128, 2) void k_quotient_rec(QuotientArgs a) { quotient_body<true>(a); }
 
 // out[p] = 1 / (n (x_p - 1)), x_p = g w_big^rev(p): the point-dependent factor of L_0(x) = Z_H(x) / (n (x - 1)).
 __global__ __launch_bounds__(256) void k_l0_inv(const u64* __restrict__ pow_big, uint32_t degree_bits,
                                                 uint32_t lde_bits, u64* __restrict__ out) {
+  P25_WAVE_PRIO(P25_PRIO_BULK);
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >> lde_bits) return;
   const u64 x = gl::mul(gl::GENERATOR, pow_big[gl::bitrev((u32)p, lde_bits)]);

@@ -48,6 +48,7 @@ struct Sponge {
 
 __global__ __launch_bounds__(64) void k_transcript(Transcript* tr, int init, const u64* __restrict__ obs,
                                                    uint32_t n_obs, u64* __restrict__ chal_out, uint32_t n_chal) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 rc_lds[360];
   coop::stage_poseidon_rc(rc_lds);
   const int lane = threadIdx.x;
@@ -106,13 +107,15 @@ __global__ __launch_bounds__(256) void k_pow_search(const Transcript* __restrict
   poseidon::permute(s);
   if (__clzll((long long)s[7]) >= pow_bits) atomicMin((unsigned long long*)result, (unsigned long long)cand);
 }
-__global__ void k_pow_init(u64* result) { *result = ~0ull; }
+__global__ void k_pow_init(u64* result) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN); *result = ~0ull; }
 
 // hash_no_pad of a proof's public inputs (overwrite-mode sponge, rate 8; hash/hashing.rs `hash_n_to_m_no_pad`): state
 // word r in lane r, one cooperative permutation per chunk of 8.
 __global__ __launch_bounds__(64) void k_public_inputs(const u64* __restrict__ vals, size_t B, uint32_t p,
                                                       const uint32_t* __restrict__ pi_slots, uint32_t n,
                                                       u64* __restrict__ values_out, u64* __restrict__ hash_out) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 rc_lds[360];
   coop::stage_poseidon_rc(rc_lds);
   const int lane = threadIdx.x;

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void k_witgen_level(const WitGen* __restrict__
                                                       uint32_t n_proofs, const u64* __restrict__ seeds,
                                                       uint32_t* __restrict__ status, uint32_t skip_kind,
                                                       const u64* __restrict__ filler, uint32_t n_filler) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   witgen_level_body(blockIdx.x, gens, args, g_begin, g_count, vals, B, n_proofs, seeds, status, skip_kind, filler,
                     n_filler);
 }
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __rest
                                                             uint32_t* __restrict__ status,
                                                             const u64* __restrict__ filler, uint32_t n_filler,
                                                             uint32_t coop_kind) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 k_lds[360];  // Poseidon round constants (360) or the Poseidon2 set (coop::P2_LDS_WORDS)
   __shared__ u64 tr_lds[(256 / coop::GROUP) * 106];  // S-box-input traces of the block's 16 permutations
   if (blockIdx.x < nb_level) {
@@ -375,6 +377,7 @@ __global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, const uint32
                                     const uint32_t* __restrict__ input_first, uint32_t n_inputs,
                                     u64* __restrict__ vals, size_t B, uint32_t n_proofs,
                                     uint32_t* __restrict__ status) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)(n_inputs + 1) * n_proofs) return;
   uint32_t i = (uint32_t)(idx / n_proofs), p = (uint32_t)(idx % n_proofs);
@@ -404,6 +407,7 @@ __global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, const uint32
 __global__ void k_witgen_fill_wires(const u64* __restrict__ vals, size_t B, uint32_t p,
                                     const uint32_t* __restrict__ wire_slot_cm, size_t n_elems,
                                     u64* __restrict__ wires) {
+  P25_WAVE_PRIO(P25_PRIO_BULK);
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_elems) return;
   wires[e] = vals[(size_t)wire_slot_cm[e] * B + p];

@@ -18,6 +18,7 @@ namespace p25 {
 
 
 __global__ __launch_bounds__(256) void k_zpp_chunks(ZppArgs a) {
+  P25_WAVE_PRIO(P25_PRIO_BULK);
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t c = blockIdx.y;
   if (r >= a.n) return;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void k_zpp_chunks(ZppArgs a) {
 
 // inclusive product scan within 256-row blocks; block totals to block_tot
 __global__ __launch_bounds__(256) void k_zpp_scan_block(ZppArgs a) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 sh[256];
   uint32_t c = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
   u64 v = r < a.n ? a.tot[(size_t)c * a.n + r] : 1;
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256) void k_zpp_scan_block(ZppArgs a) {
 }
 // exclusive product scan of the block totals (sequential over 256-wide tiles; one block per challenge)
 __global__ __launch_bounds__(256) void k_zpp_scan_totals(u64* block_tot, uint32_t n_blocks) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   __shared__ u64 sh[256];
   __shared__ u64 carry_s;
   u64* bt = block_tot + (size_t)blockIdx.x * n_blocks;
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void k_zpp_scan_totals(u64* block_tot, uint32_
 }
 // Z(r) = (product of all rows before r); pp_k(r) = Z(r) * prod_{j<=k} chunk_j(r)
 __global__ __launch_bounds__(256) void k_zpp_finish(ZppArgs a) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   uint32_t c = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
   if (r >= a.n) return;
   const int NP = (int)a.num_partial_products, nch = NP + 1;

@@ -70,11 +70,13 @@ ProofLayout make_proof_layout(const Circuit& c) {
 
 // ---------------------------------------------------------------- small glue kernels
 __global__ void k_check_zeta(const u64* chal, uint32_t degree_bits, uint32_t* status) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   gl::E2 z{chal[CH_ZETA], chal[CH_ZETA + 1]};
   gl::E2 zn = gl::exp_pow2(z, degree_bits);
   if (zn.a == 1 && zn.b == 0) set_status(status, 6);  // "Opening point is in the subgroup."
 }
 __global__ void k_interleave(const u64* a, const u64* b, uint32_t m, u64* out) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) {
     out[2 * i] = a[i];
@@ -82,6 +84,7 @@ __global__ void k_interleave(const u64* a, const u64* b, uint32_t m, u64* out) {
   }
 }
 __global__ void k_finish(const u64* chal, int pow_bits, u64* proof_pow, uint32_t* status) {
+  P25_WAVE_PRIO(P25_PRIO_CHAIN);
   u64 w = chal[CH_POW_WITNESS];
   *proof_pow = w;
   if (w == ~0ull || __clzll((long long)chal[CH_POW_RESPONSE]) < pow_bits) set_status(status, 7);
