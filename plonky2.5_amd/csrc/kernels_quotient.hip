@@ -463,9 +463,11 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
 // Occupancy target: unconstrained the kernel takes 255 VGPRs = 2 waves per SIMD, which fills the register
 // file, leaves the VALU half idle on memory latency and lets no other stream's waves co-reside.  Capped at
 // 96 VGPRs (5 waves per SIMD) the compiler spills ~580 B per lane to scratch, yet the kernel runs 2.49 ->
-// 1.78 ms and the batch 110 -> 119 proofs/s (3, 4, 6 waves: 2.15, 1.85, 1.77 ms).
+// 1.78 ms and the batch 110 -> 119 proofs/s (3, 4, 6 waves: 2.15, 1.85, 1.77 ms).  Round 3 (wires read one iteration
+// ahead, wave priority 2): 4 / 5 / 6 waves measure 137.3 / 136.7 / 135.8 proofs/s -- with its loads overlapped the kernel
+// no longer needs the fifth wave, and at 128 VGPRs it spills less.
 #ifndef P25_Q_WAVES
-#define P25_Q_WAVES 5
+#define P25_Q_WAVES 4
 #endif
 // REC: the gate set of recursive-verifier circuits (adds ArithmeticExtensionGate and PoseidonGate).  The fib-64 hot
 // path runs the REC = false instantiation, whose code is what it was before those gates existed.
