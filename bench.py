@@ -50,12 +50,15 @@ def parse_args():
                          "all, split across the ranks; overrides --batch")
     ap.add_argument("--aggregate", type=int, default=-1,
                     help="leaves of the aggregation-tree measurement after the timed region (recursive 2-to-1 verifier "
-                         "circuits down to ONE root proof); -1 = 64 on a single GPU, the gathered step otherwise is NOT "
-                         "folded (0 = off)")
+                         "circuits down to ONE root proof), PER RANK: every rank folds that many proofs of its own shard to one "
+                         "root, the N roots are gathered and rank 0 proves one N-to-1 aggregate on top; -1 = 64 (0 = off)")
     ap.add_argument("--aggregate-arity", type=int, default=8, choices=(2, 4, 8, 16), help="children per aggregation circuit")
     ap.add_argument("--extra-configs", choices=("auto", "none"), default="auto",
                     help="auto: also measure BASELINE configs 2 (single proof) and 5 (2^20-row inner STARK) and report "
                          "them in the `configs` block (N = 1 only)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the distributed branch even with --gpus 1: a world-size-1 RCCL process group on cuda:0, so "
+                         "init, the device-tensor gather and the float64 collectives execute on a one-GPU box")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL over xGMI, one GPU per rank (the real thing); gloo = test mode: every rank on GPU 0, "
                          "collectives on host copies (exercises the multi-rank path on a one-GPU box)")
@@ -69,13 +72,23 @@ def fail(msg, code=2):
     sys.exit(code)
 
 
-def visible_gpus():
+def visible_gpus(in_child=False):
+    """GPUs torch can use.  `in_child`: asked by the launcher parent, which must stay free of torch and HIP -- the count
+    is taken by a short-lived child process (sysfs/KFD topology would also list GPUs this container cannot open)."""
+    if in_child:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True)
+        try:
+            return int(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            return 0
     import torch  # counting devices does not initialise HIP on this image
     return torch.cuda.device_count()
 
 
 def spawn_ranks(args):
-    """--gpus N > 1 without a launcher: become the launcher.  Nothing has imported torch or touched HIP yet."""
+    """--gpus N > 1 without a launcher: become the launcher.  This process has not imported torch or touched HIP
+    (the GPU count came from a child process), and the ranks are a CHILD process too, never an exec of this one."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -110,50 +123,6 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
-
-
-def aggregation_tree(p25, circuit, leaves, verify_root, hash_no_pad, arity=8):
-    """North star's "final aggregation step" taken literally: fold `leaves` (flat proofs of `circuit`, a power of two)
-    into ONE root proof with `arity`-to-1 aggregation circuits (upstream builder.verify_proof for every child + four
-    registered public inputs committing to them), every level a plain batch prove on the GPU.  The last levels hold
-    one or two proofs each and cost a full single-proof latency whatever their size, so fewer, larger levels beat
-    many small ones (2-to-1: six levels of 2^14 rows; 8-to-1: two levels of 2^16 rows, the leaf circuit's own size).
-    Returns the per-level record; the root is checked by `verify_root(circuit, proof)`, and its public inputs are
-    recomputed here from the leaves: the Poseidon tree, of the tree's own shape, over hash_no_pad(wires cap) of every
-    leaf proof."""
-    import numpy as np
-    level, circ, levels, tree_s, build_s = leaves, circuit, [], 0.0, 0.0
-    ids = [hash_no_pad(p[:64]) for p in leaves]      # wires cap = the first 16 x 4 words of a flat proof
-    owned = []
-    while len(level) > 1:
-        k = min(arity, len(level))
-        t = time.perf_counter()
-        nxt = circ.build_aggregator(k)    # a recursive verifier of k proofs that registers a 4-word commitment to them
-        nxt.digest()
-        bs = time.perf_counter() - t
-        build_s += bs
-        owned.append(nxt)
-        groups = np.stack([np.concatenate(level[k * i:k * (i + 1)]) for i in range(len(level) // k)])
-        ids = [hash_no_pad(np.concatenate(ids[k * i:k * (i + 1)])) for i in range(len(ids) // k)]
-        nxt.prove(groups[:min(16, len(groups))], seeds=list(range(min(16, len(groups)))))   # warm-up: this circuit's contexts
-        t = time.perf_counter()
-        level, st = nxt.prove(groups, seeds=np.arange(len(groups), dtype=np.uint64))
-        dt = time.perf_counter() - t
-        if not (st == 0).all():
-            raise RuntimeError(f"aggregation level {len(levels) + 1}: statuses {st.tolist()}")
-        tree_s += dt
-        levels.append({"level": len(levels) + 1, "arity": k, "circuit_rows_log2": int(nxt.info.degree_bits),
-                       "rows_used": int(nxt.info.num_rows_used), "proofs": len(level), "prove_s": round(dt, 4),
-                       "circuit_build_s": round(bs, 2)})
-        circ = nxt
-    ok = verify_root(circ, level[0])
-    root_pis = [int(v) for v in circ.public_inputs(level[0])]
-    for c in owned:
-        c.close()
-    return {"levels": levels, "root_public_inputs": root_pis,
-            "root_public_inputs_commit_to_the_leaves": root_pis == [int(v) for v in ids[0]],
-            "tree_prove_s": round(tree_s, 4), "tree_circuit_build_s_once_per_shape": round(build_s, 2),
-            "root_proof_words": int(level[0].size), "oracle_verifier_accepts_root": bool(ok)}
 
 
 def bench_config5(p25, np, torch, dev, host_threads, verify):
@@ -200,11 +169,14 @@ def main():
     args = parse_args()
     if args.no_cpu_baseline:
         args.cpu_baseline = "none"
-    if args.dist_backend == "nccl" and visible_gpus() < args.gpus:
-        if int(os.environ.get("RANK", "0")) == 0:
-            fail(f"--gpus {args.gpus} but only {visible_gpus()} GPU(s) are visible")
-        sys.exit(2)
-    if args.gpus > 1 and "RANK" not in os.environ:
+    launcher = args.gpus > 1 and "RANK" not in os.environ
+    if args.dist_backend == "nccl":
+        n_vis = visible_gpus(in_child=launcher)
+        if n_vis < args.gpus:
+            if int(os.environ.get("RANK", "0")) == 0:
+                fail(f"--gpus {args.gpus} but only {n_vis} GPU(s) are visible")
+            sys.exit(2)
+    if launcher:
         sys.exit(spawn_ranks(args))
 
     # libp25 sets this itself when it is loaded; torch may initialise HIP first, so set it here too
@@ -216,12 +188,22 @@ def main():
     import torch.distributed as dist
     import __graft_entry__ as ge
 
+    if args.force_dist and args.gpus == 1 and "RANK" not in os.environ:
+        # a world of one, no launcher: the rendezvous variables torch.distributed's env:// store reads
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.dist_backend == "nccl" else 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
+    if local_rank >= torch.cuda.device_count():
+        # cannot join the process group without a device: say so (every rank prints its own line) and leave
+        fail(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -233,6 +215,7 @@ def main():
     p25 = ge.load_package()
     p25.device_init(local_rank)
     from plonky25_amd import dist as pdist
+    from plonky25_amd import aggregate as pagg
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
     host_threads = max(1, (os.cpu_count() or 1) // world)                 # host-side helpers: share the cores
@@ -285,34 +268,90 @@ def main():
     host_seeds = np.arange(B, dtype=np.uint64) + np.uint64(g_start)                          # distinct filler seeds
     d_inputs = torch.from_numpy(host_in.view(np.int64)).to(dev)                            # [B][ni]
     d_seeds = torch.from_numpy(host_seeds.view(np.int64)).to(dev)
-    d_proofs = torch.zeros((B, pw), dtype=torch.int64, device=dev)
-    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    gatherer = pdist.ProofGatherer(n_step_total, pw, cdev) if distributed else None   # receive buffers allocated once
+    # Step k writes proofs into buffer k & 1 and its statuses into row k of a per-step status array: the steps are
+    # pipelined (the library orders step k+1's proof i behind step k's proof i on the same stream, nothing else), so no
+    # step's statuses are erased before they are inspected, and -- with N > 1 -- step k's finished proofs are gathered
+    # on a side stream underneath step k+1's proving instead of draining the 16 proving streams at every step.
+    n_steps_all = args.warmup + args.steps
+    d_proofs = [torch.zeros((max(B, 1), pw), dtype=torch.int64, device=dev)[:B] for _ in range(2)]
+    d_status_all = torch.zeros((max(n_steps_all, 1), max(B, 1)), dtype=torch.int32, device=dev)[:, :B]
+    gatherer = pdist.ProofGatherer(n_step_total, pw, cdev, slots=2) if distributed else None   # buffers allocated once
+    # device memory: the library adapts the number of proofs in flight to what is free, which would silently change the
+    # schedule being measured -- refuse instead (one JSON error line, all ranks exit 2)
+    nW, NCh, NPp = int(info.num_wires), int(info.num_challenges), int(info.num_partial_products)
+    n_rows, n_lde = 1 << int(info.degree_bits), 1 << (int(info.degree_bits) + 3)
+    nzc, nqc = NCh * (1 + NPp), NCh * int(info.quotient_degree_factor)
+    ctx_est = 8 * (3 * nW * n_rows + nW * n_lde + 2 * nzc * n_rows + nzc * n_lde + 3 * NCh * n_lde + nqc * n_lde
+                   + 3 * p25.merkle_tree_words(n_lde, 4) + 16 * n_rows + 6 * n_lde)
+    free_b, total_b = torch.cuda.mem_get_info()
+    in_flight_fit = int(max(0, free_b - total_b // 20) // ctx_est)
+    want_in_flight = min(16, max(B, 1))
+    short = 1 if (args.log_n == 6 and in_flight_fit < want_in_flight) else 0
+    if distributed:
+        sh_t = torch.tensor([short], dtype=torch.int32, device=cdev)
+        dist.all_reduce(sh_t, op=dist.ReduceOp.MAX)
+        any_short = int(sh_t.item())
+    else:
+        any_short = short
+    if any_short:
+        if short:
+            sys.stderr.write(f"rank {rank}: {free_b / 1e9:.1f} GB free of {total_b / 1e9:.1f} GB holds {in_flight_fit} proof "
+                             f"contexts of {ctx_est / 1e9:.2f} GB, {want_in_flight} needed\n")
+        if rank == 0:
+            fail("a rank's GPU has too little free memory for the proofs-in-flight schedule (details on stderr)")
+        sys.exit(2)
+    nccl = distributed and args.dist_backend == "nccl"
+    side = [torch.cuda.Stream(device=dev) for _ in range(2)] if distributed else None
+    g_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps_all)] if nccl else None
     torch.cuda.synchronize()  # inputs are resident in HBM before anything is timed
 
-    gather_s = [0.0]
+    gather_host_s = [0.0]
     gathered = [None, None]
+    pending = []       # gloo test mode: (step, event) whose host-side gather has not run yet
+    step_no = [0]
+
+    def gather_on_host(k, ev):   # test mode only (every rank on GPU 0, collectives on host copies)
+        ev.synchronize()
+        g0 = time.perf_counter()
+        gathered[0], gathered[1] = gatherer.gather(d_proofs[k & 1].cpu(), d_status_all[k].cpu(), slot=k & 1)
+        gather_host_s[0] += time.perf_counter() - g0
 
     def step():
+        k = step_no[0]
+        step_no[0] += 1
+        buf = k & 1
+        if nccl and k >= 2:   # gather k-2 (the only work side[buf] holds) still reads the buffer this step overwrites
+            circuit.wait_stream(side[buf].cuda_stream)
         if B:
-            circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), d_proofs.data_ptr(), pw, d_status.data_ptr())
-        # On one GPU the steps are only enqueued here (the library's streams order step k+1's proof i behind step k's
-        # proof i, which it overwrites); the timed region is bracketed by device-wide synchronisations.  With N > 1
-        # the gather needs the finished proofs, so every step ends with a sync.
-        if distributed:  # the final aggregation step: finished proofs gathered onto rank 0 over RCCL/xGMI
-            circuit.sync()
-            g0 = time.perf_counter()
-            if args.dist_backend == "nccl":
-                gathered[0], gathered[1] = gatherer.gather(d_proofs, d_status)
+            circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), d_proofs[buf].data_ptr(), pw,
+                              d_status_all[k].data_ptr())
+        if not distributed:
+            return
+        # the final aggregation step of every batch: finished proofs gathered onto rank 0 (RCCL over xGMI).  The side
+        # stream waits for THIS step's proofs on the device; the host goes on to enqueue the next step.
+        with torch.cuda.stream(side[buf]):
+            circuit.stream_join(side[buf].cuda_stream)
+            if nccl:
+                g_ev[k][0].record(side[buf])
+                gathered[0], gathered[1] = gatherer.gather(d_proofs[buf], d_status_all[k], slot=buf)
+                g_ev[k][1].record(side[buf])
             else:
-                gathered[0], gathered[1] = gatherer.gather(d_proofs.cpu(), d_status.cpu())
-            torch.cuda.synchronize()
-            gather_s[0] += time.perf_counter() - g0
+                ev = torch.cuda.Event()
+                ev.record(side[buf])
+                pending.append((k, ev))
+        if not nccl and len(pending) > 1:   # host copies lag one step: step k is gathered while step k+1 proves
+            gather_on_host(*pending.pop(0))
+
+    def drain():
+        while pending:
+            gather_on_host(*pending.pop(0))
+        circuit.sync()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    circuit.sync()
-    gather_s[0] = 0.0
+    drain()
+    gather_host_s[0] = 0.0
     circuit.kernel_stats(enable=True, reset=True)
     if distributed:
         dist.barrier()
@@ -320,30 +359,47 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    circuit.sync()
-    torch.cuda.synchronize()
+    drain()
     local_elapsed = time.perf_counter() - t0
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     per_rank = None
     if distributed:
+        gather_s = (sum(e0.elapsed_time(e1) for e0, e1 in g_ev[args.warmup:]) * 1e-3) if nccl else gather_host_s[0]
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([local_elapsed, gather_s[0], float(B)], dtype=torch.float64, device=cdev)
+        mine = torch.tensor([local_elapsed, gather_s, float(B)], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "proofs_per_step": int(x[2]), "proofs_per_s": round(float(x[2]) * args.steps / float(x[0]), 2),
-                     "gather_ms_per_step": round(float(x[1]) / args.steps * 1e3, 3)} for r, x in enumerate(allr)]
+                     "gather_ms_per_step": round(float(x[1]) / max(1, args.steps) * 1e3, 3)} for r, x in enumerate(allr)]
     k_ms_busy, k_launches_busy = circuit.kernel_stats(enable=False, reset=True)
 
-    statuses = d_status.cpu().numpy()
+    # statuses of EVERY timed step (a failure in an early step must not be counted as proofs)
+    statuses = d_status_all[args.warmup:].cpu().numpy()
     ok = bool((statuses == 0).all())
     if distributed:
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
+    last = d_proofs[(n_steps_all - 1) & 1] if n_steps_all else d_proofs[0]
+
+    # --- the batch folded to ONE proof, sharded like the batch (outside the timed region; all ranks take part) ------
+    # Every rank folds the first n_agg proofs of ITS last step to one root on its own GPU, the N roots (not the leaves)
+    # are gathered over RCCL, rank 0 proves one N-to-1 aggregate on top.  Collectives only where every rank reaches them:
+    # a local failure is agreed on first.
+    agg_state = None
+    n_agg = min(args.aggregate if args.aggregate >= 0 else 64, B)
+    if distributed:
+        na_t = torch.tensor([n_agg], dtype=torch.int32, device=cdev)
+        dist.all_reduce(na_t, op=dist.ReduceOp.MIN)     # every shard folds the same shape
+        n_agg = int(na_t.item())
+    n_agg = pagg.largest_pow2(n_agg) if n_agg >= 1 else 0
+    if n_agg * world >= 2 and ok:
+        agg_state = pagg.fold_sharded(circuit, last[:n_agg].cpu().numpy().view(np.uint64), args.aggregate_arity, cdev,
+                                      distributed)
 
     if rank == 0:
         # --- outside the timed region ---------------------------------------------------------------
@@ -368,7 +424,7 @@ def main():
             all_p = np.concatenate(all_blocks) if all_blocks else np.zeros((0, pw), dtype=np.uint64)
             gathered_ok = bool(all(int((g.cpu() != 0).sum()) == 0 for g in gathered[1])) and all_p.shape[0] == n_step_total
         else:
-            all_p, gathered_ok = d_proofs.cpu().numpy().view(np.uint64), True
+            all_p, gathered_ok = last.cpu().numpy().view(np.uint64), True
         nver = max(1, min(args.verify, all_p.shape[0]))
         ver_idx = sorted({int(round(k * (all_p.shape[0] - 1) / max(1, nver - 1))) for k in range(nver)})
         ver_fail = []
@@ -528,25 +584,39 @@ def main():
                 dg, cap = circ.digest()
             return o2.verify(proof, dg, cap)[0] == 0
 
-        # --- the batch folded to ONE proof (recursive verifier circuits), outside the timed region --------------
-        n_agg = args.aggregate if args.aggregate >= 0 else (64 if world == 1 else 0)
-        n_agg = min(n_agg, all_p.shape[0])
-        while n_agg & (n_agg - 1):
-            n_agg &= n_agg - 1          # largest power of two
-        if n_agg >= 2 and ok:
-            try:
-                agg = aggregation_tree(p25, circuit, [all_p[i] for i in range(n_agg)], verify_with_oracle, ora.hash_no_pad,
-                                       arity=args.aggregate_arity)
-                leaf_s = n_agg / (total_proofs / elapsed)   # the leaves at the measured whole-job rate
-                agg.update({"leaves": n_agg, "leaf_prove_s_at_measured_rate": round(leaf_s, 4),
-                            "leaf_equivalent_proofs_per_s_including_aggregation": round(n_agg / (leaf_s + agg["tree_prove_s"]), 2),
-                            "note": "leaves = the first proofs of the last timed step (gathered ones when N > 1); tree on rank 0's "
-                                    "GPU; every level is an aggregation circuit (recursive verifier of its children + 4 public inputs "
-                                    "committing to them) proved as a batch; circuit builds are "
-                                    "once per shape and excluded like the reference's build()"})
-                out["aggregation"] = agg
-            except Exception as e:  # never lose the headline line to the optional block
-                out["aggregation"] = {"error": str(e)[:300]}
+        # --- the batch folded to ONE proof: rank 0 checks the root and reports ---------------------------------------
+        if agg_state is not None:
+            if agg_state.get("error"):
+                out["aggregation"] = {"error": agg_state["error"]}
+            else:
+                try:
+                    f, fin = agg_state["fold"], agg_state["final"]
+                    root, top = fin["root"], fin["top"]
+                    root_pis = [int(v) for v in top.public_inputs(root)]
+                    want = pagg.expected_commitment(list(agg_state["caps"]), args.aggregate_arity, ora.hash_no_pad, n_shards=world)
+                    leaves = agg_state["leaves_per_rank"] * world
+                    tree_total = agg_state["tree_s_max"] + agg_state["roots_gather_ms"] * 1e-3 + fin["tree_s"]
+                    leaf_s = leaves / (total_proofs / elapsed)   # the leaves at the measured whole-job rate
+                    out["aggregation"] = {
+                        "leaves": leaves, "leaves_per_rank": agg_state["leaves_per_rank"], "ranks": world,
+                        "levels": f["levels"] + fin["levels"], "root_public_inputs": root_pis,
+                        "root_public_inputs_commit_to_the_leaves": root_pis == want,
+                        "shard_tree_prove_s_max_over_ranks": round(agg_state["tree_s_max"], 4),
+                        "roots_gather_ms": round(agg_state["roots_gather_ms"], 3),
+                        "cross_rank_prove_s": round(fin["tree_s"], 4), "tree_prove_s": round(tree_total, 4),
+                        "tree_circuit_build_s_once_per_shape": round(f["build_s"] + fin["build_s"], 2),
+                        "root_proof_words": int(root.size), "oracle_verifier_accepts_root": bool(verify_with_oracle(top, root)),
+                        "leaf_prove_s_at_measured_rate": round(leaf_s, 4),
+                        "leaf_equivalent_proofs_per_s_including_aggregation": round(leaves / (leaf_s + tree_total), 2),
+                        "note": "every rank folds the first proofs of its last timed step to one root on its own GPU (levels "
+                                "proved as batches, the shard trees run concurrently); the N roots -- not the leaves -- are "
+                                "gathered over RCCL and rank 0 proves one N-to-1 aggregate on top; every level is an aggregation "
+                                "circuit (recursive verifier of its children + 4 public inputs committing to them); circuit "
+                                "builds are once per shape and excluded like the reference's build()"}
+                    for c in f["owned"] + fin["owned"]:
+                        c.close()
+                except Exception as e:  # never lose the headline line to the optional block
+                    out["aggregation"] = {"error": str(e)[:300]}
         # --- the other single-GPU BASELINE configs in the same record ----------------------------------------------
         if args.extra_configs == "auto" and world == 1 and args.log_n == 6 and not args.total:
             cfgs = {"config2_single_proof": {"workload": "one fib-64 verifier proof alone on the GPU (latency-oriented kernel forms)",

@@ -276,6 +276,16 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
                                uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status,
                                p25_timings* timings);
 p25_status p25_circuit_sync(p25_circuit* c);
+/* Device-side ordering between the circuit's proving streams and a stream of the caller's (a hipStream_t; NULL = the
+ * legacy default stream), with NO host synchronisation -- what a host needs to consume step k's proofs (copy them out,
+ * hand them to RCCL: the "final aggregation" of north_star, bench.py) underneath step k+1's proving:
+ *   p25_circuit_stream_join(c, s):  s waits for every proof the circuit has been asked for so far
+ *   p25_circuit_wait_stream(c, s):  proofs requested from now on start only after what s holds now (e.g. the gather
+ *                                   that still reads the buffer the next p25_prove_batch_dev overwrites)
+ * The reference has no counterpart (data.prove(pw), src/p3/mod.rs:260, is synchronous); these replace the
+ * host-blocking p25_circuit_sync between pipelined steps. */
+p25_status p25_circuit_stream_join(p25_circuit* c, void* stream);
+p25_status p25_circuit_wait_stream(p25_circuit* c, void* stream);
 /* Proofs kept in flight by the batch entry points: one HIP stream and one per-proof working set (~1.6 GB for the
  * fib-64 circuit) each; 1..32, default 16 (12 .. 20 measure the same, 24 and more are slower).  A library setting, not an
  * environment variable. */

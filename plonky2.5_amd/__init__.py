@@ -11,3 +11,4 @@ if libp25.so is missing or no HIP device is present.
 from .binding import *  # noqa: F401,F403
 from .binding import __all__  # noqa: F401
 from . import dist  # noqa: E402,F401
+from . import aggregate  # noqa: E402,F401

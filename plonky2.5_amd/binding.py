@@ -152,6 +152,8 @@ EXPORTED_SYMBOLS = {
     "p25_prove_batch_filler": (i32, [vp, vp, sz, vp, vp, sz, vp]),
     "p25_prove_batch_dev": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
     "p25_circuit_sync": (i32, [vp]),
+    "p25_circuit_stream_join": (i32, [vp, vp]),
+    "p25_circuit_wait_stream": (i32, [vp, vp]),
     "p25_circuit_kernel_stats": (i32, [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "p25_witness": (i32, [vp, vp, C.c_uint64, vp, C.POINTER(i32)]),
     "p25_transcript": (i32, [vp, vp, vp, sz, vp]),
@@ -538,6 +540,14 @@ class Circuit:
 
     def sync(self):
         _check(lib().p25_circuit_sync(self._h))
+
+    def stream_join(self, stream):
+        """`stream` (a raw hipStream_t, e.g. torch.cuda.Stream.cuda_stream) waits for every proof enqueued so far."""
+        _check(lib().p25_circuit_stream_join(self._h, C.c_void_p(stream)))
+
+    def wait_stream(self, stream):
+        """Proofs requested from now on start only after what `stream` holds now."""
+        _check(lib().p25_circuit_wait_stream(self._h, C.c_void_p(stream)))
 
     def set_streams(self, n):
         """Proofs kept in flight by the batch entry points (1..32, default 16)."""

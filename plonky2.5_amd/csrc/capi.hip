@@ -265,7 +265,7 @@ struct p25_circuit {
   // Entry points that touch the device state of ONE circuit are serialised: upstream's `prove(&self)` is re-entrant,
   // so a host with a thread pool may call into the same circuit concurrently; here those calls queue up instead of
   // racing for the circuit's streams and contexts.  Different circuits never contend.
-  std::recursive_mutex mu;
+  mutable std::recursive_mutex mu;   // mutable: the read-only entry points (const handles) lock too
   const p25::Circuit& c() const { return dev ? dev->circuit() : circuit; }
   p25::DeviceCircuit& device() {
     if (!dev) {
@@ -389,6 +389,7 @@ static p25_status build_recursive(p25_circuit* inner, const uint64_t* digest4, c
   auto body = [&]() -> p25_status {
     if (!inner || !out) throw std::invalid_argument("null argument");
     if ((digest4 == nullptr) != (cs_cap == nullptr)) throw std::invalid_argument("pass both digest4 and cs_cap, or neither");
+    P25_LOCK(inner);   // reads inner->c(): another thread's first device use moves the host tables
     const p25::Circuit& ic = inner->c();
     uint64_t dg[4];
     std::vector<u64> cap((size_t)4 << ic.cfg.cap_height);
@@ -428,6 +429,7 @@ p25_status p25_circuit_build_aggregator(p25_circuit* inner, const uint64_t* dige
 p25_status p25_circuit_export(const p25_circuit* c, uint8_t* buf, size_t cap, size_t* len_out) {
   return host_guarded([&]() -> p25_status {
     if (!c || !len_out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     std::vector<uint8_t> b = p25::circuit_to_blob(c->c());
     *len_out = b.size();
     if (buf) {
@@ -480,6 +482,7 @@ p25_status p25_circuit_from_bytes(const uint8_t* bytes, size_t len, const uint32
 p25_status p25_circuit_input_targets(const p25_circuit* c, uint32_t* targets_out, size_t cap, size_t* n_out) {
   return host_guarded([&]() -> p25_status {
     if (!c || !n_out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     const p25::Circuit& k = c->c();
     *n_out = k.input_targets.size();
     if (targets_out) {
@@ -508,6 +511,7 @@ void p25_circuit_destroy(p25_circuit* c) { delete c; }
 p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out) {
   return host_guarded([&]() -> p25_status {
     if (!c || !out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);   // reads c->c() and builds wp_info lazily: serialised with a concurrent first prove()
     const p25::Circuit& k = c->c();
     memset(out, 0, sizeof(*out));
     out->degree_bits = k.degree_bits;
@@ -537,6 +541,7 @@ p25_status p25_circuit_info(p25_circuit* c, p25_circuit_info_t* out) {
 p25_status p25_circuit_gate_counts(const p25_circuit* c, uint64_t* counts_out, size_t cap, char* ids_out, size_t ids_cap) {
   return host_guarded([&]() -> p25_status {
     if (!c || !counts_out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     const p25::Circuit& k = c->c();
     if (cap < k.gates.size()) throw std::invalid_argument("buffer too small");
     std::string ids;
@@ -620,6 +625,22 @@ p25_status p25_circuit_sync(p25_circuit* c) {
     if (!c) throw std::invalid_argument("null argument");
     P25_LOCK(c);
     c->device().sync();
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_stream_join(p25_circuit* c, void* stream) {
+  return guarded([&]() -> p25_status {
+    if (!c) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
+    c->device().stream_join((hipStream_t)stream);
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_wait_stream(p25_circuit* c, void* stream) {
+  return guarded([&]() -> p25_status {
+    if (!c) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
+    c->device().wait_stream((hipStream_t)stream);
     return P25_OK;
   });
 }
@@ -886,6 +907,7 @@ p25_status p25_p3_inputs_to_json(const uint64_t* inputs, size_t n, const p25_p3_
 p25_status p25_proof_to_json(p25_circuit* c, const uint64_t* proof, char* buf, size_t cap, size_t* len_out) {
   return host_guarded([&]() -> p25_status {
     if (!c || !proof || !len_out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     const p25::Circuit& k = c->c();
     std::string s = p25::proof_to_json(k, p25::make_proof_layout(k), proof);
     *len_out = s.size();
@@ -900,6 +922,7 @@ p25_status p25_proof_to_json(p25_circuit* c, const uint64_t* proof, char* buf, s
 p25_status p25_proof_to_bytes(p25_circuit* c, const uint64_t* proof, uint8_t* buf, size_t cap, size_t* len_out) {
   return host_guarded([&]() -> p25_status {
     if (!c || !proof || !len_out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     const p25::Circuit& k = c->c();
     std::vector<uint8_t> b = p25::proof_to_bytes(k, p25::make_proof_layout(k), proof);
     *len_out = b.size();
@@ -913,6 +936,7 @@ p25_status p25_proof_to_bytes(p25_circuit* c, const uint64_t* proof, uint8_t* bu
 p25_status p25_proof_from_bytes(p25_circuit* c, const uint8_t* bytes, size_t len, uint64_t* proof_out, size_t cap_words) {
   return host_guarded([&]() -> p25_status {
     if (!c || !bytes || !proof_out) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
     const p25::Circuit& k = c->c();
     p25::ProofLayout L = p25::make_proof_layout(k);
     if (cap_words < L.total) throw std::invalid_argument("buffer too small");

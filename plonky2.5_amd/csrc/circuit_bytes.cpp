@@ -194,6 +194,7 @@ void read_fri_config(R& r, Circuit& c) {
   c.cfg.cap_height = (int)r.usize_max(16, "cap_height");
   c.cfg.num_query_rounds = (int)r.usize_max(64, "num_query_rounds");
   c.cfg.proof_of_work_bits = (int)r.u32();
+  if (c.cfg.proof_of_work_bits < 0 || c.cfg.proof_of_work_bits > 64) R::bad("proof_of_work_bits out of range");
   if (r.u8() != 1) R::bad("only FriReductionStrategy::ConstantArityBits is supported");
   c.cfg.fri_arity_bits = (int)r.usize_max(8, "arity bits");
   c.cfg.fri_final_poly_bits = (int)r.usize_max(32, "final poly bits");
@@ -638,6 +639,8 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
   // constants_sigmas_commitment
   const u64 ncs = r.usize_max(4096, "polynomial count");
   if (ncs != (u64)c.num_selectors + c.cfg.num_constants + RW) R::bad("constants_sigmas count != selectors + constants + routed wires");
+  // sizes come from untrusted header fields: the input must hold that much data BEFORE anything is allocated for it
+  if ((len - r.off) / (8 + 8 * (u64)n) < ncs) R::bad("truncated (constants/sigmas polynomials)");
   c.constants_sigmas.assign(ncs, std::vector<u64>(n));
   for (u64 p = 0; p < ncs; p++) {
     if (r.usize() != n) R::bad("polynomial length != 2^degree_bits");
@@ -678,6 +681,7 @@ Circuit circuit_data_from_bytes(const uint8_t* data, size_t len, const uint32_t*
     u64 nt = r.usize_max((u64)1 << 31, "representative map");
     if (nt < n * Wn) R::bad("representative map shorter than the wire grid");
     c.num_virtual_targets = nt - n * Wn;
+    if ((len - r.off) / 8 < nt) R::bad("truncated (representative map)");
     c.rep.resize(nt);
     for (u64 i = 0; i < nt; i++) {
       u64 v = r.usize();

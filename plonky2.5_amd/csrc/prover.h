@@ -90,6 +90,12 @@ class DeviceCircuit {
   void prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs, size_t proof_stride,
                        uint32_t* d_status, PhaseTimes* times, const u64* d_filler = nullptr);
   void sync();
+  // Device-side ordering against a caller's stream, no host synchronisation (the multi-GPU gather runs on a side
+  // stream underneath the next step's proofs):
+  //   stream_join(ext):  `ext` waits for everything this circuit has enqueued so far (all proving streams)
+  //   wait_stream(ext):  everything this circuit enqueues from now on waits for what `ext` holds now
+  void stream_join(hipStream_t ext);
+  void wait_stream(hipStream_t ext);
   // proofs kept in flight by prove_batch* (one HIP stream + working set each), 1..16
   void set_streams(int k) { streams_ = k < 1 ? 1 : (k > 32 ? 32 : k); }
   hipStream_t stream() const { return stream_; }
@@ -124,6 +130,7 @@ class DeviceCircuit {
   hipStream_t stream_ = nullptr;
   std::vector<std::unique_ptr<Ctx>> ctxs_;   // proofs in flight: one working set + HIP stream each
   hipEvent_t ev_witness_[2] = {nullptr, nullptr};  // witness pass into vals_[b] finished
+  hipEvent_t ev_ext_ = nullptr, ev_main_ = nullptr;  // stream_join / wait_stream
   int streams_ = 16;
   bool single_proof_ = false;  // set per prove call: one proof in flight -> latency-oriented kernel forms
   DevMem vals_[2];             // witness values of a pass, slot-major [slot][proof of the pass]; double-buffered

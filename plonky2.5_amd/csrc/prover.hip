@@ -176,12 +176,14 @@ struct DeviceCircuit::Ctx {
   hipStream_t st = nullptr;
   // done[b]: recorded after the context's latest read of witness-value buffer b (DeviceCircuit::vals_[b])
   hipEvent_t done[2] = {nullptr, nullptr};
+  hipEvent_t join = nullptr;   // DeviceCircuit::stream_join
   bool have_events = false;
   ~Ctx() {
     if (have_events)
       for (auto& e : ev) (void)hipEventDestroy(e);
     for (auto& e : done)
       if (e) (void)hipEventDestroy(e);
+    if (join) (void)hipEventDestroy(join);
     if (st) (void)hipStreamDestroy(st);
   }
 };
@@ -318,6 +320,8 @@ DeviceCircuit::~DeviceCircuit() {
   ctxs_.clear();
   for (auto& e : ev_witness_)
     if (e) (void)hipEventDestroy(e);
+  if (ev_ext_) (void)hipEventDestroy(ev_ext_);
+  if (ev_main_) (void)hipEventDestroy(ev_main_);
   for (auto* v : {&kstats_pending_, &kstats_free_})
     for (auto& pr : *v) {
       (void)hipEventDestroy(pr.first);
@@ -398,6 +402,25 @@ void DeviceCircuit::ensure_vals(int buf, size_t batch) {
 void DeviceCircuit::sync() {
   P25_HIP(hipStreamSynchronize(stream_));
   for (auto& c : ctxs_) P25_HIP(hipStreamSynchronize(c->st));
+}
+
+void DeviceCircuit::stream_join(hipStream_t ext) {
+  // one event per proving stream: a context's `join` event is re-recorded here, after the stream's latest work
+  if (!ev_main_) P25_HIP(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
+  P25_HIP(hipEventRecord(ev_main_, stream_));
+  P25_HIP(hipStreamWaitEvent(ext, ev_main_, 0));
+  for (auto& c : ctxs_) {
+    if (!c->join) P25_HIP(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
+    P25_HIP(hipEventRecord(c->join, c->st));
+    P25_HIP(hipStreamWaitEvent(ext, c->join, 0));
+  }
+}
+void DeviceCircuit::wait_stream(hipStream_t ext) {
+  // the main stream waits; every proving stream waits for a witness event the main stream records AFTER this point
+  // before it touches a proof of a later call
+  if (!ev_ext_) P25_HIP(hipEventCreateWithFlags(&ev_ext_, hipEventDisableTiming));
+  P25_HIP(hipEventRecord(ev_ext_, ext));
+  P25_HIP(hipStreamWaitEvent(stream_, ev_ext_, 0));
 }
 
 void DeviceCircuit::kernel_stats(double* ms, u64* launches, bool reset) {
@@ -665,6 +688,9 @@ void DeviceCircuit::quotient(const u64* wires, const u64* zs_pp, const u64* beta
   ntt_lde_bitrev(tables_, x.zs_coeffs.p, n, x.zs_lde.p, B, db, rb, nz, gl::GENERATOR, st);
   enqueue_quotient(x, st);
   P25_HIP(hipMemcpyAsync(out, x.q_coeffs.p, (size_t)NC * B * 8, hipMemcpyDeviceToHost, st));
+  // context 0 goes back to proving: a circuit without registered public inputs never rewrites the hash words, so put
+  // hash_no_pad([]) back instead of leaving the caller's (possibly arbitrary) wires there
+  if (c_.pi_row >= 0) P25_HIP(hipMemcpyAsync(x.preamble.p + 4, preamble_.p + 4, 32, hipMemcpyDeviceToDevice, st));
   P25_HIP(hipStreamSynchronize(st));
   P25_HIP(hipGetLastError());
 }

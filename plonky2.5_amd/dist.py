@@ -22,9 +22,11 @@ class ProofGatherer:
     """The final aggregation step with every buffer allocated ONCE: per-rank proofs [n_local, words] (int64) and
     statuses [n_local] (int32) are gathered onto `dst` in global proof order.  Shards may differ in size by one; the
     collective runs on blocks padded to the largest shard.  `device` is where the collective's tensors live (the
-    rank's GPU for RCCL, "cpu" for gloo)."""
+    rank's GPU for RCCL, "cpu" for gloo).  `slots`: gathers of consecutive steps are in flight together when the steps
+    are pipelined (bench.py), so the padded staging blocks exist once per slot; the receive buffers are shared (the
+    collectives of one process group execute in issue order) and always hold the LATEST gather."""
 
-    def __init__(self, n_total, words, device, dst=0, proof_dtype=torch.int64, status_dtype=torch.int32):
+    def __init__(self, n_total, words, device, dst=0, proof_dtype=torch.int64, status_dtype=torch.int32, slots=1):
         self.world, self.rank, self.dst = dist.get_world_size(), dist.get_rank(), dst
         self.n_total, self.words = n_total, words
         self.sizes = shard_sizes(n_total, self.world)
@@ -32,24 +34,28 @@ class ProofGatherer:
         self.n_local = self.sizes[self.rank]
         self.even = all(s == self.m for s in self.sizes)
         # send side: the caller's own tensors when every shard is full-size, a padded staging block otherwise
-        self.pad_p = None if self.even else torch.zeros((self.m, words), dtype=proof_dtype, device=device)
-        self.pad_s = None if self.even else torch.full((self.m,), -1, dtype=status_dtype, device=device)
+        self.pad_p = None if self.even else [torch.zeros((self.m, words), dtype=proof_dtype, device=device)
+                                             for _ in range(slots)]
+        self.pad_s = None if self.even else [torch.full((self.m,), -1, dtype=status_dtype, device=device)
+                                             for _ in range(slots)]
         if self.rank == dst:
             self.gp = [torch.zeros((self.m, words), dtype=proof_dtype, device=device) for _ in range(self.world)]
             self.gs = [torch.zeros((self.m,), dtype=status_dtype, device=device) for _ in range(self.world)]
         else:
             self.gp = self.gs = None
 
-    def gather(self, local_proofs, local_status):
+    def gather(self, local_proofs, local_status, slot=0):
         """Returns (list of per-rank proof blocks, list of per-rank status blocks) on dst -- views of the
-        pre-allocated receive buffers trimmed to each shard's size -- and (None, None) elsewhere."""
+        pre-allocated receive buffers trimmed to each shard's size -- and (None, None) elsewhere.  The collectives are
+        issued on the CURRENT stream's order (torch's process group makes its own stream wait for it and the current
+        stream wait for the result), so a caller on a side stream does not block the host."""
         assert local_proofs.shape == (self.n_local, self.words), (local_proofs.shape, self.n_local, self.words)
         if self.even:
             sp, ss = local_proofs.contiguous(), local_status.contiguous()
         else:
-            self.pad_p[: self.n_local].copy_(local_proofs)
-            self.pad_s[: self.n_local].copy_(local_status)
-            sp, ss = self.pad_p, self.pad_s
+            sp, ss = self.pad_p[slot], self.pad_s[slot]
+            sp[: self.n_local].copy_(local_proofs)
+            ss[: self.n_local].copy_(local_status)
         dist.gather(sp, self.gp, dst=self.dst)
         dist.gather(ss, self.gs, dst=self.dst)
         if self.rank != self.dst:

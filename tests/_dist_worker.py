@@ -44,6 +44,12 @@ def main_standin(n_total):
         if rank == 0:
             assert torch.equal(torch.cat(blocks), fake_prove(all_inputs, words) + step)
             assert [b.shape[0] for b in blocks] == pd.shard_sizes(n_total, world)
+    # pipelined steps (bench.py): two gathers in flight, one staging slot each
+    g2 = pd.ProofGatherer(n_total, words, torch.device("cpu"), slots=2)
+    for step in range(4):
+        blocks, sts = g2.gather(local + 10 * step, status, slot=step & 1)
+        if rank == 0:
+            assert torch.equal(torch.cat(blocks), fake_prove(all_inputs, words) + 10 * step)
     # inputs generated on rank 0 only and broadcast (bench.py's plonky3 proof variants)
     src = np.arange(12, dtype=np.uint64).reshape(3, 4) * np.uint64(0x1000000000000001) if rank == 0 else None
     got = pd.broadcast_int64(src, (3, 4), torch.device("cpu"))
@@ -101,9 +107,87 @@ def main_real(n_total):
     dist.destroy_process_group()
 
 
+def fake_hash(words):
+    """A 4-word stand-in for hash_no_pad (order-sensitive, length-sensitive)."""
+    w = np.asarray(words, dtype=np.uint64)
+    acc = np.array([len(w), 1, 2, 3], dtype=np.uint64)
+    for i, v in enumerate(w):
+        acc = acc * np.uint64(6364136223846793005) + np.uint64(v) + np.uint64(i * 4 + 1) * np.array([1, 3, 5, 7], dtype=np.uint64)
+        acc = np.roll(acc, 1)
+    return acc
+
+
+class StandInCircuit:
+    """Has the surface plonky25_amd.aggregate touches.  A "proof" of an aggregator holds fake_hash over its children's
+    identifiers as its 4 public inputs (what the real aggregation circuit registers); a leaf has a 64-word cap."""
+    WORDS = 80
+
+    class Info:
+        degree_bits, num_rows_used = 4, 9
+
+    def __init__(self, child=None, k=0):
+        self.child, self.k, self.info = child, k, self.Info()
+        self.n_pi = 4 if child is not None else 0
+
+    def build_aggregator(self, k):
+        return StandInCircuit(self, k)
+
+    def digest(self):
+        return None
+
+    def close(self):
+        pass
+
+    def public_inputs(self, proof):
+        return proof[-4:].copy()
+
+    def prove(self, groups, seeds=None):
+        from plonky25_amd import aggregate as ag
+        groups = np.asarray(groups, dtype=np.uint64).reshape(-1, self.k * self.WORDS)
+        out = np.zeros((groups.shape[0], self.WORDS), dtype=np.uint64)
+        for g in range(groups.shape[0]):
+            kids = groups[g].reshape(self.k, self.WORDS)
+            ids = np.concatenate([fake_hash(ag.leaf_identifier_words(c, self.child.n_pi)) if not self.child.n_pi
+                                  else ag.leaf_identifier_words(c, 4) for c in kids])
+            out[g, :8] = 777 + g
+            out[g, -4:] = fake_hash(ids)
+        return out, np.zeros(groups.shape[0], dtype=np.int32)
+
+
+def main_aggregate(n_per_rank, arity):
+    """The sharded aggregation of bench.py on stand-in circuits: shard trees, ONE root per rank gathered, cross-rank
+    aggregate on rank 0, and the commitment recomputed from all ranks' leaves."""
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ge.load_package()
+    from plonky25_amd import aggregate as ag
+    rng = np.random.default_rng(1234)                 # the same global batch on every rank
+    all_leaves = rng.integers(0, 1 << 62, size=(world * n_per_rank, StandInCircuit.WORDS), dtype=np.uint64)
+    mine = all_leaves[rank * n_per_rank:(rank + 1) * n_per_rank]
+    st = ag.fold_sharded(StandInCircuit(), mine, arity, torch.device("cpu"), True)
+    assert st["error"] is None and st["ranks"] == world and st["leaves_per_rank"] == n_per_rank
+    assert [l["arity"] for l in st["fold"]["levels"]] == ag.level_plan(n_per_rank, arity)
+    if rank == 0:
+        fin = st["final"]
+        assert [l["arity"] for l in fin["levels"]] == [world]
+        got = [int(v) for v in fin["top"].public_inputs(fin["root"])]
+        want = ag.expected_commitment(list(all_leaves[:, :ag.CAP_WORDS]), arity, fake_hash, n_shards=world)
+        assert (st["caps"] == all_leaves[:, :ag.CAP_WORDS]).all()
+        assert got == want, (got, want)
+        # a leaf moved across the shard boundary changes the commitment (the order is the global proof order)
+        swapped = all_leaves[:, :ag.CAP_WORDS].copy()
+        swapped[[n_per_rank - 1, n_per_rank]] = swapped[[n_per_rank, n_per_rank - 1]]
+        assert ag.expected_commitment(list(swapped), arity, fake_hash, n_shards=world) != want
+        print("DIST_AGG_OK", n_per_rank, arity)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1])
-    if "--real" in sys.argv:
+    if "--agg" in sys.argv:
+        main_aggregate(n, int(sys.argv[sys.argv.index("--agg") + 1]))
+    elif "--real" in sys.argv:
         main_real(n)
     else:
         main_standin(n)

@@ -27,3 +27,17 @@ def test_gather_world2_gloo(n_total):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert f"DIST_OK {n_total}" in out.stdout
+
+
+@pytest.mark.parametrize("n_per_rank,arity", [(8, 8), (16, 4), (1, 8)])
+def test_sharded_aggregation_world2_gloo(n_per_rank, arity):
+    """Every rank folds its own shard, ONE root per rank is gathered, rank 0 proves the cross-rank aggregate; the final
+    public inputs equal the hash tree over ALL ranks' leaves (stand-in circuits: libp25 has no CPU path; the real
+    prover runs the same code in tests/test_gpu_bench_contract.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29551 + n_per_rank + arity),
+           os.path.join(ROOT, "tests", "_dist_worker.py"), str(n_per_rank), "--agg", str(arity)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert f"DIST_AGG_OK {n_per_rank} {arity}" in out.stdout

@@ -53,9 +53,9 @@ def test_bench_multi_rank_path_bare_launch():
     or HIP is touched).  Test mode: both ranks share GPU 0 and the collectives run on host copies (gloo) -- the rank
     bookkeeping, barriers, max-over-ranks timing, gather and JSON assembly are the code the 8-GPU run executes."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "1",
-                        "--warmup", "1", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=1500,
-                       cwd=ROOT, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "2",
+                        "--warmup", "1", "--dist-backend", "gloo", "--aggregate", "4", "--aggregate-arity", "2"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -64,6 +64,12 @@ def test_bench_multi_rank_path_bare_launch():
     assert d["config"]["oracle_verifier_accepts"] and "cpu_baseline" not in d
     assert len(d["per_rank"]) == 2 and all(p["proofs_per_s"] > 0 for p in d["per_rank"])
     assert abs(d["value"] - 2 * 8 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # the sharded aggregation: each rank folds 4 of its proofs to one root (two 2-to-1 levels), the two roots are
+    # gathered, rank 0 proves the 2-to-1 cross-rank aggregate; the root commits to all 8 leaves of both ranks
+    ag = d["aggregation"]
+    assert ag["leaves"] == 8 and ag["ranks"] == 2 and [l["arity"] for l in ag["levels"]] == [2, 2, 2]
+    assert ag["levels"][-1]["level"] == "cross-rank"
+    assert ag["root_public_inputs_commit_to_the_leaves"] is True and ag["oracle_verifier_accepts_root"] is True
 
 
 def test_bench_strong_scaling_mode_two_ranks():
