@@ -79,8 +79,8 @@ __device__ __forceinline__ void dif16_group(u64* col, const u64* wl, int step, i
   for (int k = 0; k < 16; k++) col[k * step] = x[k];
 }
 
-template <bool INV>
-__global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
+template <bool INV, int NTH>
+__global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
   P25_WAVE_PRIO(P25_PRIO_BULK);
   extern __shared__ u64 lds[];
   const int R = 1 << a.log_r, T = 1 << a.log_t;
@@ -233,26 +233,62 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass a) {
   }
 }
 
+// LDS bytes of a tile: R rows of T (+1 padding) words + the sub-transform's twiddle table
+static size_t tile_lds_bytes(int log_r, int log_t) {
+  const size_t R = (size_t)1 << log_r, T = (size_t)1 << log_t, TP = T > 1 ? T + 1 : 1;
+  return (R * TP + (log_r <= 10 ? R : R / 2)) * sizeof(u64);
+}
+
 void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st) {
-  const int R = 1 << p.log_r, T = 1 << p.log_t;
-  const int TP = T > 1 ? T + 1 : 1;
   NttPass q = p;
   // the radix-16 groups index a full table of R twiddles; a 2^11-point sub-transform (2^22-point transforms) would
-  // not fit the 64 KB of LDS a block may take with it and keeps the half table and the radix-2 network
+  // not fit the LDS a block may take with it and keeps the half table and the radix-2 network
   q.full_table = p.log_r <= 10;
-  size_t lds = ((size_t)R * TP + (q.full_table ? R : R / 2)) * sizeof(u64);
+  const size_t lds = tile_lds_bytes(p.log_r, p.log_t);
   q.n_tiles = 1u << (p.log_nt - p.log_t);
   q.n_cosets = (uint32_t)n_cosets;
   q.xcd_map = n_cosets > 1 && (q.n_tiles & 7u) == 0;
   dim3 grid = q.xcd_map ? dim3(q.n_tiles * (uint32_t)n_polys * (uint32_t)n_cosets) : dim3(q.n_tiles, n_polys, n_cosets);
-  if (q.inverse)
-    hipLaunchKernelGGL(k_ntt_tile<true>, grid, dim3(256), lds, st, q);
-  else
-    hipLaunchKernelGGL(k_ntt_tile<false>, grid, dim3(256), lds, st, q);
+  // tiles of 2^13 elements (16-wide tiles of 512-point sub-transforms: 2^19-point transforms, BASELINE config 5) take
+  // 512 threads, so that a CU's two resident blocks still give every SIMD four waves; above 64 KB of dynamic LDS the
+  // function attribute has to allow it (a workgroup may take up to 160 KB on gfx950)
+  const bool wide = p.log_r + p.log_t >= 13;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    const int cap = 160 * 1024;
+    P25_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    P25_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    P25_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    P25_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    attr_set = true;
+  }
+  if (wide) {
+    if (q.inverse)
+      hipLaunchKernelGGL((k_ntt_tile<true, 512>), grid, dim3(512), lds, st, q);
+    else
+      hipLaunchKernelGGL((k_ntt_tile<false, 512>), grid, dim3(512), lds, st, q);
+  } else {
+    if (q.inverse)
+      hipLaunchKernelGGL((k_ntt_tile<true, 256>), grid, dim3(256), lds, st, q);
+    else
+      hipLaunchKernelGGL((k_ntt_tile<false, 256>), grid, dim3(256), lds, st, q);
+  }
 }
 
-static int pick_log_t(int log_r, int log_nt) {
+// Tile width.  A pass whose tile is STRIDED in memory (kind 0: T adjacent words per row of the tile, rows NT words
+// apart -- pass 1 of every two-pass transform, reads and writes alike) wants T * 8 B = a whole 128-byte line: the
+// widest tile, up to 16, that still lets two blocks share a CU's 160 KB of LDS (R = 256: 37 KB, R = 512: 74 KB; wider
+// sub-transforms fall back to 2^12-element tiles: 32-byte segments cost the 2^19-row circuits of BASELINE config 5 an 8x
+// over-fetch while their pass 1 was the 1024-point one).  A pass over contiguous rows (kind 1) is coalesced at any
+// width and keeps 2^12-element tiles.
+static int pick_log_t(int log_r, int log_nt, bool strided) {
   int lt = 12 - log_r;
+  if (strided)
+    for (int w = 4; w > lt; w--)
+      if (tile_lds_bytes(log_r, w) <= 79 * 1024) {
+        lt = w;
+        break;
+      }
   if (lt > 4) lt = 4;
   if (lt > log_nt) lt = log_nt;
   if (lt < 0) lt = 0;
@@ -305,8 +341,8 @@ static void split(int log_n, int& log_r1, int& log_r2) {
     log_r1 = 0;
     log_r2 = log_n;
   } else {
-    log_r2 = (log_n + 1) / 2;  // pass-1 sub-transform (over k2)
-    log_r1 = log_n - log_r2;   // pass-2 sub-transform (over k1)
+    log_r2 = log_n / 2;        // pass-1 sub-transform (over k2): the strided pass gets the SMALLER one (wider tiles fit)
+    log_r1 = log_n - log_r2;   // pass-2 sub-transform (over k1): contiguous rows
   }
   // sub-transforms of up to 2^11 points (56 KB of LDS with a 2-wide tile): transforms up to 2^22,
   // i.e. the 8n-point quotient iNTT of a 2^19-row circuit (BASELINE config 5)
@@ -339,7 +375,7 @@ void ntt_inverse(NttTables& tb, const u64* d_in, size_t in_stride, bool in_bitre
   // pass 1: t = k1 (NT = R1), i = k2 (R = R2); writes Y[k1][j2] at k1 + R1*j2
   p.in = d_in; p.out = d_tmp;
   p.in_poly_stride = in_stride; p.out_poly_stride = tmp_stride;
-  p.log_r = l2; p.log_nt = l1; p.log_t = pick_log_t(l2, l1);
+  p.log_r = l2; p.log_nt = l1; p.log_t = pick_log_t(l2, l1, true);
   if (in_bitrev) { p.in_kind = 1; p.in_br_t = 1; p.in_br_i = 1; } else { p.in_kind = 0; }
   p.out_kind = 0; p.out_br_i = 0;
   p.use_twiddle = 1;
@@ -350,7 +386,7 @@ void ntt_inverse(NttTables& tb, const u64* d_in, size_t in_stride, bool in_bitre
   q.inverse = 1;
   q.in = d_tmp; q.out = d_out;
   q.in_poly_stride = tmp_stride; q.out_poly_stride = out_stride;
-  q.log_r = l1; q.log_nt = l2; q.log_t = pick_log_t(l1, l2);
+  q.log_r = l1; q.log_nt = l2; q.log_t = pick_log_t(l1, l2, false);
   q.in_kind = 1;
   q.out_kind = 0; q.out_br_i = 0;
   q.post_t = tb.geom_table(n_inv, s_inv, (size_t)1 << l2);
@@ -399,7 +435,7 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
     return;
   }
   // pass 1: scale, length-R2 transforms over k2, twiddle, store row rev(j2)
-  p.log_r = l2; p.log_nt = l1; p.log_t = pick_log_t(l2, l1);
+  p.log_r = l2; p.log_nt = l1; p.log_t = pick_log_t(l2, l1, true);
   p.in_kind = 0; p.out_kind = 0; p.out_br_i = 1;
   p.use_twiddle = 1;
   launch_ntt_pass(p, n_polys, nc, st);
@@ -408,7 +444,7 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
   q.pow_table = pw; q.log_n_table = log_n;
   q.in = d_lde; q.out = d_lde;
   q.in_poly_stride = lde_stride; q.out_poly_stride = lde_stride;
-  q.log_r = l1; q.log_nt = l2 + rate_bits; q.log_t = pick_log_t(l1, l2 + rate_bits);
+  q.log_r = l1; q.log_nt = l2 + rate_bits; q.log_t = pick_log_t(l1, l2 + rate_bits, false);
   q.in_kind = 1; q.out_kind = 1; q.out_br_i = 1;
   launch_ntt_pass(q, n_polys, 1, st);
 }

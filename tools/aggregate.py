@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """Aggregation tree over a batch of fib-64 plonky3-verifier proofs (the north star's "final aggregation"
-taken literally): N leaf proofs -> N/2 proofs of a 2-to-1 recursive verifier -> ... -> one root proof, every level a
-plain batch prove on the GPU.  Prints one JSON line with the per-level circuit sizes and times; the root is checked
-by the oracle's verifier.   usage: aggregate.py [N = 64, a power of two]"""
+taken literally): N leaf proofs folded `arity` at a time (plonky25_amd.aggregate.fold, the code bench.py runs on every
+rank) down to one root proof, every level a plain batch prove on the GPU.  Prints one JSON line with the per-level
+circuit sizes and times; the root is checked by the oracle's verifier.  The profiling target for the aggregator's
+kernels: `rocprofv3 --kernel-trace --stats -- python3 tools/aggregate.py 64 8`.
+usage: aggregate.py [N = 64, a power of two] [arity = 8] [--no-leaves: read nothing, prove the leaves untimed]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import __graft_entry__ as ge
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if len(args) > 0 else 64
+arity = int(args[1]) if len(args) > 1 else 8
 assert n >= 2 and n & (n - 1) == 0
 p25 = ge.load_package(); p25.device_init(0)
+from plonky25_amd import aggregate as ag
 with open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")) as f:
     base, cfg = p25.p3_proof_from_json(f.read())
 variants = [base] + [p25.p3_prove_fibonacci(6, 100, 16, pow_start=v << 24)[0] for v in range(1, 8)]
@@ -21,21 +26,17 @@ batch = np.stack([variants[i % 8] for i in range(n)])
 circ.prove(batch[:16], seeds=list(range(16)))                      # warm-up: contexts, tables
 t = time.perf_counter(); level, st = circ.prove(batch, seeds=np.arange(n, dtype=np.uint64)); dt = time.perf_counter() - t
 assert (st == 0).all()
-levels = [{"level": 0, "circuit_rows_log2": int(circ.info.degree_bits), "proofs": n, "prove_s": round(dt, 3)}]
-total = dt
-while len(level) > 1:
-    t = time.perf_counter(); circ = circ.build_aggregator(2); circ.digest(); build = time.perf_counter() - t
-    pairs = np.stack([np.concatenate([level[2 * i], level[2 * i + 1]]) for i in range(len(level) // 2)])
-    circ.prove(pairs[:min(16, len(pairs))], seeds=list(range(min(16, len(pairs)))))   # warm-up: this circuit's contexts
-    t = time.perf_counter(); level, st = circ.prove(pairs, seeds=np.arange(len(pairs), dtype=np.uint64)); dt = time.perf_counter() - t
-    assert (st == 0).all(), st
-    total += dt
-    levels.append({"level": len(levels), "circuit_rows_log2": int(circ.info.degree_bits), "rows_used": int(circ.info.num_rows_used),
-                   "proofs": len(level), "prove_s": round(dt, 3), "circuit_build_s": round(build, 2)})
+f = ag.fold(circ, [level[i] for i in range(n)], arity=arity)
 from oracle_binding import Oracle
-oc = Oracle().load_circuit(circ.to_blob())
-dg, cap = circ.digest()
-code, msg = oc.verify(level[0], dg, cap)
-print(json.dumps({"leaf_proofs": n, "levels": levels, "gpu_prove_s_total": round(total, 3),
+ora = Oracle()
+oc = ora.load_circuit(f["top"].to_blob())
+dg, cap = f["top"].digest()
+code, msg = oc.verify(f["root"], dg, cap)
+want = ag.expected_commitment([level[i][:ag.CAP_WORDS] for i in range(n)], arity, ora.hash_no_pad)
+total = dt + f["tree_s"]
+print(json.dumps({"leaf_proofs": n, "arity": arity, "leaf_prove_s": round(dt, 4), "levels": f["levels"],
+                  "tree_prove_s": round(f["tree_s"], 4), "gpu_prove_s_total": round(total, 4),
                   "leaf_equivalent_proofs_per_s_including_aggregation": round(n / total, 2),
-                  "root_proof_words": int(level[0].size), "oracle_verifier_accepts_root": code == 0, "msg": msg}))
+                  "root_proof_words": int(f["root"].size), "oracle_verifier_accepts_root": code == 0,
+                  "root_public_inputs_commit_to_the_leaves": [int(v) for v in f["top"].public_inputs(f["root"])] == want,
+                  "msg": msg}))
