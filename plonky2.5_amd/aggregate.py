@@ -7,14 +7,14 @@ hash_no_pad(its wires cap) otherwise (a leaf proof of the plonky3-verifier circu
 /root/reference/src/p3/mod.rs:264), so the root exposes the root of a Poseidon tree over the whole batch.
 
 With N ranks every rank folds ITS OWN shard down to one proof on its own GPU (`fold`), the N shard roots -- not the
-N x 256 leaves -- cross xGMI (`gather_roots`, one RCCL gather of N proofs), and rank 0 proves one N-to-1 aggregate on top
-(`fold_roots`).  `expected_commitment` recomputes what the final root's public inputs must be from the leaves alone; the
+N x 256 leaves -- cross xGMI (`fold_sharded`: one RCCL gather of N proofs), and rank 0 proves one N-to-1 aggregate on top
+(`fold_roots`).  `DeviceTree` is the same tree kept on the device and pipelined under the next step's leaf proving.  `expected_commitment` recomputes what the final root's public inputs must be from the leaves alone; the
 hash is passed in (tests and bench.py hand it the oracle's, as the checker)."""
 import time
 
 import numpy as np
 
-__all__ = ["fold", "fold_roots", "fold_sharded", "expected_commitment", "leaf_identifier_words", "largest_pow2"]
+__all__ = ["fold", "fold_roots", "fold_sharded", "DeviceTree", "expected_commitment", "leaf_identifier_words", "largest_pow2"]
 
 CAP_WORDS = 64   # wires cap = the first 2^cap_height x 4 words of a flat proof (cap_height 4, include/p25.h proof layout)
 
@@ -162,3 +162,81 @@ def fold_sharded(circuit, local_leaves, arity, cdev, distributed):
             state["error"] = str(e)[:300]
     state.update({"caps": caps, "tree_s_max": tree_s_max, "roots_gather_ms": gather_ms})
     return state
+
+
+class DeviceTree:
+    """The aggregation tree of one shard kept RESIDENT ON THE DEVICE and only ever enqueued: an aggregation circuit's
+    inputs are its k children's flat proofs back to back, i.e. exactly k consecutive rows of the buffer the level
+    below writes its proofs into (proof stride = proof words), so a level is `p25_prove_batch_dev` straight on the
+    previous level's output -- no host round trip, no synchronisation.  Ordering between the circuits' streams is
+    device-side (`p25_circuit_stream_join` / `p25_circuit_wait_stream`), so the tree of step j runs underneath the leaf
+    proving of step j+1 and its latency-bound top (one or two proofs per level) costs no idle machine.
+
+    Buffers are `slots`-deep: step j uses slot j % slots.  A level's proofs of step j are overwritten by step j+slots,
+    which first waits (on the device) for the level ABOVE to have finished step j."""
+
+    def __init__(self, circuit, n_leaves, arity, device, slots=2):
+        import torch
+        if n_leaves < 2 or n_leaves & (n_leaves - 1):
+            raise ValueError("DeviceTree needs a power-of-two number of leaves >= 2")
+        self.torch, self.dev, self.slots, self.n_leaves, self.arity = torch, device, slots, n_leaves, arity
+        self.leaf, self.levels, self.build_s = circuit, [], 0.0
+        circ, n = circuit, n_leaves
+        for k in level_plan(n_leaves, arity):
+            t = time.perf_counter()
+            nxt = circ.build_aggregator(k)
+            nxt.digest()
+            self.build_s += time.perf_counter() - t
+            n //= k
+            pw = int(nxt.info.proof_words)
+            assert int(nxt.info.num_inputs) == k * int(circ.info.proof_words)
+            self.levels.append({
+                "circ": nxt, "n": n, "k": k, "pw": pw,
+                "seeds": torch.arange(n, dtype=torch.int64, device=device),
+                "out": [torch.zeros((n, pw), dtype=torch.int64, device=device) for _ in range(slots)],
+                "status": [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(slots)],
+                # marker[s]: a stream that holds "this level's work up to the latest step of slot s"
+                "marker": [torch.cuda.Stream(device=device) for _ in range(slots)],
+            })
+            circ = nxt
+        self.top = circ
+        self.hop = [torch.cuda.Stream(device=device) for _ in self.levels]   # carry "the level below is done" upwards
+        self.aggregates_per_step = sum(L["n"] for L in self.levels)
+        self.steps = 0
+
+    def before_leaves(self):
+        """Call before enqueuing the leaf proofs of the next step into its slot: they overwrite the buffer level 1 read
+        `slots` steps ago."""
+        if self.steps >= self.slots:
+            self.leaf.wait_stream(self.levels[0]["marker"][self.steps % self.slots].cuda_stream)
+
+    def enqueue(self, d_leaf_proofs):
+        """Enqueue the whole tree over the leaf proofs just enqueued (`d_leaf_proofs`: [n_leaves, leaf proof words]
+        int64, contiguous, being written by the leaf circuit's streams).  Returns the slot."""
+        s = self.steps % self.slots
+        below_c, below_buf = self.leaf, d_leaf_proofs
+        for i, L in enumerate(self.levels):
+            c = L["circ"]
+            below_c.stream_join(self.hop[i].cuda_stream)       # everything the level below has been asked for ...
+            c.wait_stream(self.hop[i].cuda_stream)             # ... before this level's witness generation reads it
+            if self.steps >= self.slots and i + 1 < len(self.levels):   # the level above still reads out[s] of step - slots
+                c.wait_stream(self.levels[i + 1]["marker"][s].cuda_stream)
+            c.prove_dev(below_buf.data_ptr(), L["n"], L["seeds"].data_ptr(), L["out"][s].data_ptr(), L["pw"],
+                        L["status"][s].data_ptr())
+            c.stream_join(L["marker"][s].cuda_stream)
+            below_c, below_buf = c, L["out"][s]
+        self.steps += 1
+        return s
+
+    def sync(self):
+        for L in self.levels:
+            L["circ"].sync()
+
+    def root(self, slot):
+        """(root proof, all statuses zero) of a finished step (host copies)."""
+        ok = all(int((L["status"][slot] != 0).sum().item()) == 0 for L in self.levels)
+        return self.levels[-1]["out"][slot][0].cpu().numpy().view(np.uint64), ok
+
+    def close(self):
+        for L in self.levels:
+            L["circ"].close()

@@ -38,12 +38,33 @@ struct AlphaLimbs {
 };
 constexpr int MAX_TERMS_PER_FOLD = 512;
 
+// A committed matrix (column-major, leaf order) seen from ONE lane: column c at this lane's point.  Read through a
+// buffer descriptor per column -- base (a kernel argument) + c * big on the scalar unit, the lane's share a 32-bit BYTE
+// offset -- so a column read is `buffer_load_dwordx2 v, v_off, s[desc], 0 offen`: its address lives in SGPRs.  The
+// per-lane pointer form (`(base + p)[c * big]`) cost a 64-bit VALU add and a VGPR pair per read, and the compiler hoisted
+// those column addresses out of the loop over the gates: hundreds of live registers, i.e. the kernel's spills.
+struct LaneCols {
+  const u64* base;
+  u32 boff;  // 8 * point index (the LDE has at most 2^22 points)
+  size_t big;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  __device__ __forceinline__ u64 col(size_t c) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t r =
+        __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<u64*>(base + c * big), 0, (int)(big * 8), 0x00020000);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)boff, 0, 0);
+    return ((u64)v.y << 32) | v.x;
+#else
+    return 0;
+#endif
+  }
+};
 struct Ctx {
-  const u64* wires;  // column base for this point: wires[col * big]
+  LaneCols wires;  // wires.col(c) = wire column c at this point
   size_t big;
   const AlphaLimbs* apl;  // LDS
   u64 acc[2][2][3];       // [challenge][half of c][limb of alpha]
-  __device__ __forceinline__ u64 w(int col) const { return wires[(size_t)col * big]; }
+  __device__ __forceinline__ u64 w(int col) const { return wires.col((size_t)col); }
   __device__ __forceinline__ void reset() {
 #pragma unroll
     for (int c = 0; c < 2; c++)
@@ -315,11 +336,21 @@ __device__ void gate_poseidon2(Ctx& cx) {
 
 // upstream gates/arithmetic_extension.rs: out - (c0 * m0 * m1 + c1 * addend) in F_p^2, 10 ops of 8 wires
 __device__ void gate_arith_ext(Ctx& cx, u64 k0, u64 k1) {
+  u64 nx[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) nx[k] = cx.w(k);
   for (int i = 0; i < 10; i++) {
-    gl::E2 a{cx.w(8 * i), cx.w(8 * i + 1)}, b{cx.w(8 * i + 2), cx.w(8 * i + 3)}, ad{cx.w(8 * i + 4), cx.w(8 * i + 5)};
+    u64 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = nx[k];
+    if (i + 1 < 10) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) nx[k] = cx.w(8 * (i + 1) + k);
+    }
+    gl::E2 a{w[0], w[1]}, b{w[2], w[3]}, ad{w[4], w[5]};
     gl::E2 r = gl::add(gl::mul(gl::mul(a, b), k0), gl::mul(ad, k1));
-    cx.at(2 * i, gl::sub(cx.w(8 * i + 6), r.a));
-    cx.at(2 * i + 1, gl::sub(cx.w(8 * i + 7), r.b));
+    cx.at(2 * i, gl::sub(w[6], r.a));
+    cx.at(2 * i + 1, gl::sub(w[7], r.b));
   }
 }
 // upstream gates/random_access.rs eval_unfiltered_base_one: per copy the index bits are boolean and recompose the
@@ -357,12 +388,20 @@ __device__ void gate_reducing(Ctx& cx) {
   constexpr int NCO = EXT ? REDX_COEFFS : RED_COEFFS, CW = EXT ? 2 : 1, START_ACCS = 6 + NCO * CW;
   const gl::E2 alpha{cx.w(2), cx.w(3)};
   gl::E2 acc{cx.w(4), cx.w(5)};
+  auto acc_wire = [](int i) { return i == NCO - 1 ? 0 : START_ACCS + 2 * i; };
+  u64 na = cx.w(acc_wire(0)), nb = cx.w(acc_wire(0) + 1), nc0 = cx.w(6), nc1 = EXT ? cx.w(7) : 0;
   for (int i = 0; i < NCO; i++) {
-    const int aw = i == NCO - 1 ? 0 : START_ACCS + 2 * i;
-    const gl::E2 nxt{cx.w(aw), cx.w(aw + 1)};
+    const gl::E2 nxt{na, nb};
+    const u64 c0 = nc0, c1 = nc1;
+    if (i + 1 < NCO) {
+      na = cx.w(acc_wire(i + 1));
+      nb = cx.w(acc_wire(i + 1) + 1);
+      nc0 = cx.w(6 + CW * (i + 1));
+      if (EXT) nc1 = cx.w(6 + CW * (i + 1) + 1);
+    }
     gl::E2 t = gl::mul(acc, alpha);
-    t.a = gl::add(t.a, cx.w(6 + CW * i));
-    if (EXT) t.b = gl::add(t.b, cx.w(6 + CW * i + 1));
+    t.a = gl::add(t.a, c0);
+    if (EXT) t.b = gl::add(t.b, c1);
     cx.at(2 * i, gl::sub(t.a, nxt.a));
     cx.at(2 * i + 1, gl::sub(t.b, nxt.b));
     acc = nxt;
@@ -370,12 +409,22 @@ __device__ void gate_reducing(Ctx& cx) {
 }
 // upstream gates/poseidon_mds.rs: output_r - (sum_i circ[i] input_{(i + r) mod 12} + diag[r] input_r), per component
 __device__ void gate_poseidon_mds(Ctx& cx) {
-  for (int r = 0; r < 12; r++)
-    for (int d = 0; d < 2; d++) {
-      u64 acc = r == 0 ? gl::mul(cx.w(d), (u64)poseidon::MDS_DIAG0) : 0;
-      for (int i = 0; i < 12; i++) acc = gl::add(acc, gl::mul(cx.w(2 * ((i + r) % 12) + d), (u64)poseidon::MDS_CIRC[i]));
-      cx.at(2 * r + d, gl::sub(cx.w(24 + 2 * r + d), acc));
+  for (int d = 0; d < 2; d++) {
+    u64 in[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) in[i] = cx.w(2 * i + d);
+    u64 nxt = cx.w(24 + d);
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+      const u64 o = nxt;
+      if (r + 1 < 12) nxt = cx.w(24 + 2 * (r + 1) + d);
+      // 12 terms with coefficients < 2^6 on the 32-bit halves: carry-free, one reduction (cf. SmallLin)
+      SmallLin acc;
+#pragma unroll
+      for (int i = 0; i < 12; i++) acc.add(in[(i + r) % 12], (u32)poseidon::MDS_CIRC[i] + (i == 0 && r == 0 ? (u32)poseidon::MDS_DIAG0 : 0u));
+      cx.at(2 * r + d, gl::sub(o, gl::canon(acc.value())));   // sub wants a canonical subtrahend
     }
+  }
 }
 // upstream gates/coset_interpolation.rs eval_unfiltered_base_one (subgroup of order 16, degree 6, 2 intermediates):
 // the point divided by the shift is given on wires and checked; the barycentric recurrence
@@ -420,31 +469,44 @@ __device__ void gate_poseidon(Ctx& cx) {
   u64 swap = cx.w(24);
   cx.at(nc++, gl::mul_nc(swap, gl::sub(swap, 1)));
   u64 st[12];
+#pragma unroll
   for (int i = 0; i < 4; i++) {
     u64 lhs = cx.w(i), rhs = cx.w(i + 4), delta = cx.w(25 + i);
     cx.at(nc++, gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
     st[i] = gl::add(lhs, delta);
     st[i + 4] = gl::sub(rhs, delta);
   }
+#pragma unroll
   for (int i = 8; i < 12; i++) st[i] = cx.w(i);
   int tr = 29;
+  u64 nsb = cx.w(tr);   // the S-box input wire read one position ahead (wires 29 .. 29 + 117, in round order)
+  constexpr int TR_END = 29 + 12 * (2 * poseidon::HALF_FULL - 1) + poseidon::N_PARTIAL;
   for (int r = 0; r < poseidon::N_ROUNDS; r++) {
+#pragma unroll
     for (int i = 0; i < 12; i++) st[i] = poseidon::add_rc(st[i], poseidon::RC[12 * r + i]);
     if (r < poseidon::HALF_FULL || r >= poseidon::HALF_FULL + poseidon::N_PARTIAL) {
-      if (r != 0)
+      if (r != 0) {
+#pragma unroll
         for (int i = 0; i < 12; i++) {
-          u64 sb = cx.w(tr++);
+          const u64 sb = nsb;
+          tr++;
+          if (tr < TR_END) nsb = cx.w(tr);
           cx.at(nc++, gl::sub(gl::canon(st[i]), sb));
           st[i] = sb;
         }
+      }
+#pragma unroll
       for (int i = 0; i < 12; i++) st[i] = poseidon::sbox(st[i]);
     } else {
-      u64 sb = cx.w(tr++);
+      const u64 sb = nsb;
+      tr++;
+      if (tr < TR_END) nsb = cx.w(tr);
       cx.at(nc++, gl::sub(gl::canon(st[0]), sb));
       st[0] = poseidon::sbox(sb);
     }
     poseidon::mds(st);
   }
+#pragma unroll
   for (int i = 0; i < 12; i++) cx.at(nc++, gl::sub(gl::canon(st[i]), cx.w(12 + i)));
 }
 
@@ -468,6 +530,17 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
 // no longer needs the fifth wave, and at 128 VGPRs it spills less.
 #ifndef P25_Q_WAVES
 #define P25_Q_WAVES 4
+#endif
+// The recursion instantiation (k_quotient_rec: aggregation circuits): waves per SIMD, and whether the merged pass over
+// the routed wires (below) is compiled in for it too
+#ifndef P25_QREC_WAVES
+#define P25_QREC_WAVES 2
+#endif
+#ifndef P25_QREC_MERGED
+#define P25_QREC_MERGED 1
+#endif
+#ifndef P25_QREC_PRIO
+#define P25_QREC_PRIO P25_PRIO_BULK
 #endif
 // REC: the gate set of recursive-verifier circuits (adds ArithmeticExtensionGate and PoseidonGate).  The fib-64 hot
 // path runs the REC = false instantiation, whose code is what it was before those gates existed.
@@ -505,9 +578,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   const int NC = 2, NP = (int)a.num_partial_products, RW = (int)a.num_routed;
   // chunks of max_quotient_degree_factor routed wires (upstream partial_products.rs), NP + 1 of them
   const int nch = NP + 1, per = (int)a.quotient_degree_factor;
-  const u64* cs = a.cs_lde + p;
-  const u64* wr = a.wires_lde + p;
-  const u64* zs = a.zs_lde + p;
+  const u32 boff = (u32)p * 8u;
+  const LaneCols csc{a.cs_lde, boff, big}, wrc{a.wires_lde, boff, big}, zsc{a.zs_lde, boff, big};
   const int n_consts = (int)a.num_selectors;  // selectors first, then the 2 gate constants
 
   u64 res[2] = {0, 0};
@@ -515,14 +587,14 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   {
     u64 l0 = gl::mul(zhx, a.l0_inv[p]);  // 1 / (n (x - 1)), per circuit (k_l0_inv)
     for (int c = 0; c < NC; c++) {
-      u64 t = gl::mul(l0, gl::sub(zs[(size_t)c * big], 1));
+      u64 t = gl::mul(l0, gl::sub(zsc.col(c), 1));
       res[0] = gl::add(res[0], gl::mul(t, ap[c]));
       res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + c]));
     }
   }
   auto gate_filter = [&](uint32_t gi) {
     const GateEntry ge = a.gates[gi];
-    const u64 s = cs[(size_t)ge.selector_index * big];
+    const u64 s = csc.col(ge.selector_index);
     u64 filter = 1;
     for (uint32_t k = ge.group_start; k < ge.group_end; k++)
       if (k != gi) filter = gl::mul(filter, gl::sub((u64)k, s));
@@ -537,7 +609,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   // per column, but 192 spilled registers instead of 116 and no gain.)  Those gates share ONE alpha-fold accumulator: each
   // constraint is multiplied by its gate's filter first (116 multiplications, paid for by the five per-gate folds of the
   // accumulator limbs that are no longer needed);  sum_g f_g sum_j alpha^j c_gj = sum_j alpha^j sum_g f_g c_gj.
-  const bool fast = !REC && per == 8 && RW == 80 && NP == 9 && a.num_wires >= 80;
+  const bool fast = (!REC || P25_QREC_MERGED) && per == 8 && RW == 80 && NP == 9 && a.num_wires >= 80;
   uint32_t merged_mask = 0;   // gate kinds evaluated by the merged pass
   u64 mg0 = 0, mg1 = 0;       // their filtered, alpha-folded sums
   const u64 beta0 = a.chal[CH_BETAS], beta1 = a.chal[CH_BETAS + 1];
@@ -564,14 +636,14 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
       else if (kind == G_ARITHMETIC) f_arith = gate_filter(gi);
       else if (kind == G_MUL_EXT) f_mext = gate_filter(gi);
     }
-    const u64 k0 = cs[(size_t)n_consts * big], k1 = cs[(size_t)(n_consts + 1) * big];
+    const u64 k0 = csc.col(n_consts), k1 = csc.col(n_consts + 1);
     Ctx mc;          // the shared accumulator of the merged gates
-    mc.wires = wr;
+    mc.wires = wrc;
     mc.big = big;
     mc.apl = apl;
     mc.reset();
     u64 bs_sum = 0, bs_w0 = 0;
-    u64 wnext = wr[0];   // the wire read one position ahead
+    u64 wnext = wrc.col(0);   // the wire read one position ahead
     SmallLin bs_acc;
     u64 ar0 = 0, ar1 = 0, ar2 = 0;                    // arithmetic: multiplicand 0, multiplicand 1, addend of the current op
     u64 mx0 = 0, mx1 = 0, mx2 = 0, mx3 = 0, mx4 = 0;  // mul-extension: a, b and output.a of the current op
@@ -580,7 +652,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   {                                                                                                             \
     const int j = base + (JJ);                                                                                  \
     const u64 w = wnext;                                                                                        \
-    if (j + 1 < 80) wnext = wr[(size_t)(j + 1) * big];                                                          \
+    if (j + 1 < 80) wnext = wrc.col(j + 1);                                                                      \
     if ((JJ) < 4 && base == 0) {                                                                                \
       if (h_const && (JJ) < 2) mc.at((JJ), gl::mul_nc(gl::sub((JJ) == 0 ? k0 : k1, w), f_const));              \
       if (h_pi) mc.at((JJ), gl::mul_nc(gl::sub(w, a.pi_hash[(JJ)]), f_pi));                                     \
@@ -638,15 +710,15 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     merged_mask = 0;
   }
   {
-    u64 wn = wr[0], sn = cs[(size_t)(n_consts + 2) * big];   // wire and sigma read one position ahead
+    u64 wn = wrc.col(0), sn = csc.col(n_consts + 2);   // wire and sigma read one position ahead
     for (int k = 0; k < nch; k++) {
       u64 np0 = 1, dp0 = 1, np1 = 1, dp1 = 1;
       // beta * k_j * x: k_j * beta comes from a per-proof table (k_alpha_pows fills it)
       for (int j = k * per; j < (k + 1) * per && j < RW; j++) {
         const u64 w = wn, sg = sn;
         if (j + 1 < RW) {
-          wn = wr[(size_t)(j + 1) * big];
-          sn = cs[(size_t)(n_consts + 3 + j) * big];
+          wn = wrc.col(j + 1);
+          sn = csc.col(n_consts + 3 + j);
         }
         const u64 wg0 = gl::add(w, gamma0), wg1 = gl::add(w, gamma1);
         np0 = gl::mul_nc(np0, gl::mad_nc(kb[j], x, wg0));
@@ -657,8 +729,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
 #pragma unroll
       for (int c = 0; c < NC; c++) {
         const u64 np = gl::canon(c ? np1 : np0), dp = gl::canon(c ? dp1 : dp0);
-        u64 prev = k == 0 ? zs[(size_t)c * big] : zs[(size_t)(NC + c * NP + k - 1) * big];
-        u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zs[(size_t)(NC + c * NP + k) * big];
+        u64 prev = k == 0 ? zsc.col(c) : zsc.col(NC + c * NP + k - 1);
+        u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zsc.col(NC + c * NP + k);
         u64 t = gl::sub(gl::mul(prev, np), gl::mul(next, dp));
         int ti = NC + c * nch + k;
         res[0] = gl::add(res[0], gl::mul(t, ap[ti]));
@@ -669,16 +741,24 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   // --- gate constraints, terms NC*(1+nch) + j
   {
     Ctx cx;
-    cx.wires = wr;
+    cx.wires = wrc;
     cx.big = big;
     cx.apl = apl;
-    const u64 k0 = cs[(size_t)n_consts * big], k1 = cs[(size_t)(n_consts + 1) * big];
+    const u64 k0 = csc.col(n_consts), k1 = csc.col(n_consts + 1);
     u64 g0 = mg0, g1 = mg1;
     for (uint32_t gi = 0; gi < a.n_gates; gi++) {
       const GateEntry ge = a.gates[gi];
       if ((merged_mask >> ge.kind) & 1u) continue;   // evaluated by the merged pass above
       const u64 filter = gate_filter(gi);
       cx.reset();
+      {
+        // Column descriptors are loop-invariant and the compiler would hoist ALL of them (every column of every
+        // evaluator) out of this loop, into hundreds of spilled scalar registers; an opaque copy of the stride per
+        // iteration keeps each one next to its load.
+        size_t bg = big;
+        asm volatile("" : "+s"(bg));
+        cx.wires.big = bg;
+      }
 #ifdef P25_PROFILE_GATE_MASK  // profiling builds only (tools/qmask.sh); never compiled into libp25.so
       if (!((a.debug_gate_mask >> ge.kind) & 1u)) continue;
 #endif
@@ -729,7 +809,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
 
 __global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
   P25_WAVE_PRIO(P25_PRIO_BULK); quotient_body<false>(a); }
-__global__ __launch_bounds__(128, 2) void k_quotient_rec(QuotientArgs a) { quotient_body<true>(a); }
+__global__ __launch_bounds__(128, P25_QREC_WAVES) void k_quotient_rec(QuotientArgs a) {
+  P25_WAVE_PRIO(P25_QREC_PRIO); quotient_body<true>(a); }
 
 // out[p] = 1 / (n (x_p - 1)), x_p = g w_big^rev(p): the point-dependent factor of L_0(x) = Z_H(x) / (n (x - 1)).
 __global__ __launch_bounds__(256) void k_l0_inv(const u64* __restrict__ pow_big, uint32_t degree_bits,

@@ -9,8 +9,10 @@ from conftest import P, splitmix_field
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", [3, 8, 9, 10, 11])
+@pytest.mark.parametrize("kind", list(range(1, 18)))
 def test_gate_eval_circuits_gpu_equals_oracle(gpu, oracle, kind):
+    """The in-circuit evaluator of EVERY gate kind (1-10 the inner circuits', 11-17 what recursion adds), as a circuit
+    proved on the GPU: byte-equal to the oracle's proof, a wrong expectation has no witness."""
     wires = splitmix_field(270, seed=100 + kind).reshape(135, 2)
     consts = splitmix_field(4, seed=200 + kind).reshape(2, 2)
     pih = splitmix_field(4, seed=300 + kind)
@@ -27,6 +29,85 @@ def test_gate_eval_circuits_gpu_equals_oracle(gpu, oracle, kind):
     assert (proofs[0] == po).all()
     dg, cap = c.digest()
     assert oc.verify(proofs[0], dg, cap)[0] == 0
+
+
+@pytest.fixture(scope="module")
+def rec_small(gpu, oracle):
+    """Depth-2 recursion over the and(x, y) gadget circuit: the verifier (2^12 rows) of a recursive verifier (2^11
+    rows).  It holds EVERY gate recursion adds -- ArithmeticExtension, Poseidon, RandomAccess, Reducing,
+    ReducingExtension, CosetInterpolation (the inner proof has FRI layers) and PoseidonMds (the inner circuit has
+    PoseidonGate rows, whose in-circuit evaluator puts its MDS layers on such rows)."""
+    inner = gpu.Circuit.build_gadget(0, 0)
+    x, y = 0x0123456789ABCDEF % P, 0x0FEDCBA987654321 % P
+    inp = np.array([x, y, (x & y) % P], dtype=np.uint64)
+    inner_proofs, st = inner.prove(inp[None, :], seeds=[5])
+    assert st.tolist() == [0]
+    outer1 = inner.build_recursive_verifier(1)
+    p1, st = outer1.prove(inner_proofs[:1], seeds=[6])
+    assert st.tolist() == [0]
+    outer = outer1.build_recursive_verifier(1)
+    oo = oracle.load_circuit(outer.to_blob())
+    wires, st, msg = oo.witness(p1[0], seed=9)
+    assert st == 0, msg
+    return outer, oo, wires
+
+
+def _chal(seed):
+    return splitmix_field(6, seed=seed).reshape(3, 2)
+
+
+def _row_kinds(blob):
+    """Gate kind of every row, from the circuit blob (magic, 32 header words, the gate table
+    of header[14] entries x 4 words, header[10] FRI arity words, then u32[n])."""
+    hdr = np.frombuffer(blob, dtype=np.uint64, count=32, offset=8)
+    off = 8 + 32 * 8 + int(hdr[14]) * 32 + int(hdr[10]) * 8
+    return np.frombuffer(blob, dtype=np.uint32, count=1 << int(hdr[0]), offset=off).copy()
+
+
+def test_quotient_rec_evaluators_vs_oracle_on_arbitrary_wires(rec_small):
+    """k_quotient_rec DIRECTLY (p25_quotient, the stage entry point) against the oracle's ref_quotient_chunks on a
+    recursion circuit: on the satisfied witness, and on ARBITRARY wires -- every row's evaluator then produces non-zero
+    constraints from every wire it reads, so each of the recursion gates' evaluators (kinds 11-17) is compared value
+    for value, not only through a proof whose constraints vanish on the subgroup."""
+    outer, oo, wires = rec_small
+    counts = outer.gate_counts()
+    present = [name for name, k in counts.items() if k]
+    for need in ("ArithmeticExtensionGate", "PoseidonGate(", "RandomAccessGate", "ReducingGate", "ReducingExtensionGate",
+                 "CosetInterpolationGate", "PoseidonMdsGate"):
+        assert any(need in name for name in present), (need, present)
+    betas, gammas, alphas = _chal(31)
+    zs = oo.partial_products(wires, betas, gammas)
+    assert (outer.partial_products(wires, betas, gammas) == zs).all()
+    qg, qo = outer.quotient(wires, zs, betas, gammas, alphas), oo.quotient(wires, zs, betas, gammas, alphas)
+    assert qg.shape == qo.shape and (qg == qo).all() and qg.any()
+    # arbitrary wires (canonical field elements everywhere): same words on both sides
+    rnd = splitmix_field(wires.size, seed=4242).reshape(wires.shape)
+    zs_r = oo.partial_products(rnd, betas, gammas)
+    qg, qo = outer.quotient(rnd, zs_r, betas, gammas, alphas), oo.quotient(rnd, zs_r, betas, gammas, alphas)
+    assert (qg == qo).all(), np.argwhere(qg != qo)[:5]
+    # and a proof on the same context afterwards is still the oracle's (the stage call leaves no state behind)
+    assert (qg != outer.quotient(wires, zs, betas, gammas, alphas)).any()
+
+
+def test_quotient_rec_sees_every_wire_of_every_recursion_gate(rec_small):
+    """One wire column at a time, on the first row of each gate type of the recursion circuit: changing it changes the
+    GPU's quotient exactly as it changes the oracle's."""
+    outer, oo, wires = rec_small
+    betas, gammas, alphas = _chal(32)
+    zs = oo.partial_products(wires, betas, gammas)
+    base = oo.quotient(wires, zs, betas, gammas, alphas)
+    kinds = _row_kinds(outer.to_blob())
+    assert set(range(11, 18)) <= set(np.unique(kinds).tolist())
+    rows = sorted({int(np.nonzero(kinds == k)[0][0]) for k in np.unique(kinds) if k != 0})
+    rng = np.random.default_rng(77)
+    for row in rows:
+        for col in rng.choice(wires.shape[0], size=6, replace=False):
+            bad = wires.copy()
+            bad[col, row] = (int(bad[col, row]) + 1) % P
+            qg = outer.quotient(bad, zs, betas, gammas, alphas)
+            qo = oo.quotient(bad, zs, betas, gammas, alphas)
+            assert (qg == qo).all(), (row, col)
+    assert base.any()
 
 
 def test_recursive_verifier_small_gpu_equals_oracle(gpu, oracle):

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""A/B of library builds on ONE box, back to back: the batch proving loop of bench.py (device-resident inputs, steps
+only enqueued, one sync at the end) for each library given, each in its own child process, `--rounds` times
+interleaved.  Prints proofs/s per library and round, and the single-proof phase times of each.
+usage: ab_bench.py [--batch 256] [--steps 3] [--rounds 2] [--agg N] name=path/to/libp25_x.so ...   (name "base" = the product)"""
+import json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child(lib, batch, steps, agg):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    import numpy as np, torch
+    import __graft_entry__ as ge
+    p25 = ge.load_package()
+    if lib != "base":
+        sys.modules["plonky25_amd.binding"].lib_path = lib
+    p25.device_init(0)
+    dev = torch.device("cuda", 0)
+    with open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")) as f:
+        base, cfg = p25.p3_proof_from_json(f.read())
+    variants = [base] + [p25.p3_prove_fibonacci(6, 100, 16, pow_start=v << 24)[0] for v in range(1, 8)]
+    c = p25.Circuit.build_p3_verifier(cfg)
+    c.digest()
+    pw = int(c.info.proof_words)
+    d_in = torch.from_numpy(np.stack([variants[i % 8] for i in range(batch)]).view(np.int64)).to(dev)
+    d_seeds = torch.arange(batch, dtype=torch.int64, device=dev)
+    d_p = [torch.zeros((batch, pw), dtype=torch.int64, device=dev) for _ in range(2)]
+    d_s = torch.zeros((steps + 1, batch), dtype=torch.int32, device=dev)
+    out = {}
+    for k in range(steps + 1):
+        if k == 1:
+            c.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        c.prove_dev(d_in.data_ptr(), batch, d_seeds.data_ptr(), d_p[k & 1].data_ptr(), pw, d_s[k].data_ptr())
+    c.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["proofs_per_s"] = round(batch * steps / dt, 2)
+    out["ok"] = bool((d_s.cpu().numpy() == 0).all())
+    tm = None
+    for i in range(4):
+        _p, _s, tm = c.prove(variants[i], seeds=[i], timings=True)
+    out["single"] = {k: round(v, 3) for k, v in tm.as_dict().items()}
+    if agg:
+        from plonky25_amd import aggregate as ag
+        leaves = d_p[steps & 1][:agg].cpu().numpy().view(np.uint64)
+        f = ag.fold(c, [leaves[i] for i in range(agg)], arity=8)
+        out["agg"] = {"tree_s": round(f["tree_s"], 4), "levels_ms_per_proof": [l["ms_per_proof"] for l in f["levels"]]}
+        a1 = f["owned"][0]                        # the level-1 aggregator alone: per-phase device times of one proof
+        grp = np.concatenate([leaves[i] for i in range(8)])
+        for i in range(3):
+            _p, _s, tm1 = a1.prove(grp, seeds=[i], timings=True)
+        out["agg"]["single"] = {k: round(v, 3) for k, v in tm1.as_dict().items()}
+    print("AB " + json.dumps(out), flush=True)
+
+
+def main():
+    a = sys.argv[1:]
+    if a and a[0] == "--child":
+        return child(a[1], int(a[2]), int(a[3]), int(a[4]))
+    batch, steps, rounds, agg, libs = 256, 3, 2, 0, []
+    i = 0
+    while i < len(a):
+        if a[i] == "--batch": batch = int(a[i + 1]); i += 2
+        elif a[i] == "--steps": steps = int(a[i + 1]); i += 2
+        elif a[i] == "--rounds": rounds = int(a[i + 1]); i += 2
+        elif a[i] == "--agg": agg = int(a[i + 1]); i += 2
+        else:
+            name, _, path = a[i].partition("=")
+            libs.append((name, path or "base")); i += 1
+    for r in range(rounds):
+        for name, path in libs:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path, str(batch), str(steps), str(agg)],
+                               capture_output=True, text=True)
+            line = [l for l in p.stdout.splitlines() if l.startswith("AB ")]
+            print(f"round {r} {name:16s} {line[0][3:] if line else 'FAILED ' + p.stderr[-400:]}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
