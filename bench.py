@@ -161,6 +161,33 @@ def bench_config5(p25, np, torch, dev, host_threads, verify):
            "all_statuses_ok": ok, "oracle_verifier_accepts": bool(acc),
            "single_proof_latency_ms": round(tm.as_dict()["total_ms"], 2), "circuit_build_s": round(build_s, 2),
            "native_p3_prover_s_two_proofs": round(p3_s, 2)}
+    # VALU view of this configuration, from a PMC pass collected for exactly the current kernel sources
+    # (tools/pmc_config5.sh writes profiles/*_config5_pmc_SQ_INSTS_VALU.json with the sources' hash)
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "plonky2.5_amd", "csrc")
+    hh = hashlib.sha256()
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h", ".inc")):
+            hh.update(open(os.path.join(csrc, fn), "rb").read())
+    sha = hh.hexdigest()[:16]
+    out["valu"] = {"stale": True, "note": f"no profiles/*_config5_pmc_SQ_INSTS_VALU.json for the current kernel sources ({sha})"}
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_config5_pmc_SQ_INSTS_VALU.json")), reverse=True):
+        try:
+            pk = json.load(open(cand))
+        except Exception:
+            continue
+        if pk.get("_meta", {}).get("csrc_sha") == sha:
+            instr = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in pk.items() if k != "_meta")
+            try:
+                hz = p25.shader_clock_hz()
+            except Exception:
+                hz = NOMINAL_CLOCK_HZ
+            ach = instr * out["proofs_per_s"]
+            out["valu"] = {"wave_instr_per_proof": instr, "achieved_wave_instr_per_s": ach, "source": os.path.basename(cand),
+                           "shader_clock_hz": hz, "frac_of_quarter_rate_4cyc": ach / (N_SIMD * hz / 4),
+                           "per_row_vs_config3": "config 3 issues 3.97 G per proof of 2^16 rows; this circuit has 2^19"}
+            break
     circ.close()
     return out
 
@@ -484,6 +511,7 @@ def main():
         ms_alone = k_ms_alone / max(1, k_launches_alone)
         ms_busy = k_ms_busy / max(1, k_launches_busy)
         achieved = algo_bytes / (ms_alone * 1e-3) / 1e9 if ms_alone > 0 else 0.0
+        ms_all = (k_ms_alone + k_ms_busy) / max(1, k_launches_alone + k_launches_busy)
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
         traffic, traffic_note = None, "no PMC file"
         tp = os.path.join(ROOT, "profiles", "pmc_hash_leaves.json")
@@ -613,6 +641,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "avg_launch_ms": ms_alone, "launches": int(k_launches_alone), "algorithmic_bytes": algo_bytes,
                          "avg_launch_ms_timed_region": ms_busy, "launches_timed_region": int(k_launches_busy),
+                         # the figure a rocprofv3 --stats AverageNs over the WHOLE run gives: every launch, overlapped or not
+                         "avg_launch_ms_all_launches": ms_all,
+                         "frac_all_launches": (algo_bytes / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_all > 0 else 0.0,
                          "note": "integer-VALU bound (17 Poseidon permutations per 1,080-B leaf), not HBM bound. achieved/frac "
                                  "use avg_launch_ms = the kernel with the GPU to itself (single-proof passes after the timed "
                                  "region, HIP events on the proving stream; this is what rocprofv3's per-kernel duration "

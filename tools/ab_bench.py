@@ -2,12 +2,12 @@
 """A/B of library builds on ONE box, back to back: the batch proving loop of bench.py (device-resident inputs, steps
 only enqueued, one sync at the end) for each library given, each in its own child process, `--rounds` times
 interleaved.  Prints proofs/s per library and round, and the single-proof phase times of each.
-usage: ab_bench.py [--batch 256] [--steps 3] [--rounds 2] [--agg N] name=path/to/libp25_x.so ...   (name "base" = the product)"""
+usage: ab_bench.py [--batch 256] [--steps 3] [--rounds 2] [--agg N] [--pipe K] name=path/to/libp25_x.so ...   (name "base" = the product)"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(lib, batch, steps, agg):
+def child(lib, batch, steps, agg, pipe=0):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     import numpy as np, torch
@@ -50,26 +50,45 @@ def child(lib, batch, steps, agg):
         for i in range(3):
             _p, _s, tm1 = a1.prove(grp, seeds=[i], timings=True)
         out["agg"]["single"] = {k: round(v, 3) for k, v in tm1.as_dict().items()}
+    if pipe:   # the pipelined device-resident tree (bench.py's `aggregation.pipelined`): 1 warm-up step + `pipe` timed steps
+        from plonky25_amd import aggregate as ag
+        tree = ag.DeviceTree(c, ag.largest_pow2(batch), 8, dev)
+        d_sp = torch.zeros((pipe + 1, batch), dtype=torch.int32, device=dev)
+
+        def pstep(k):
+            tree.before_leaves()
+            c.prove_dev(d_in.data_ptr(), batch, d_seeds.data_ptr(), d_p[k & 1].data_ptr(), pw, d_sp[k].data_ptr())
+            return tree.enqueue(d_p[k & 1][:tree.n_leaves])
+        pstep(0); c.sync(); tree.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(1, pipe + 1):
+            slot = pstep(k)
+        c.sync(); tree.sync(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        _root, rok = tree.root(slot)
+        out["pipe"] = {"steps": pipe, "leaf_eq_proofs_per_s": round(batch * pipe / dt, 2), "ms_per_step": round(dt / pipe * 1e3, 1),
+                       "ok": bool(rok and (d_sp.cpu().numpy() == 0).all())}
     print("AB " + json.dumps(out), flush=True)
 
 
 def main():
     a = sys.argv[1:]
     if a and a[0] == "--child":
-        return child(a[1], int(a[2]), int(a[3]), int(a[4]))
-    batch, steps, rounds, agg, libs = 256, 3, 2, 0, []
+        return child(a[1], int(a[2]), int(a[3]), int(a[4]), int(a[5]))
+    batch, steps, rounds, agg, pipe, libs = 256, 3, 2, 0, 0, []
     i = 0
     while i < len(a):
         if a[i] == "--batch": batch = int(a[i + 1]); i += 2
         elif a[i] == "--steps": steps = int(a[i + 1]); i += 2
         elif a[i] == "--rounds": rounds = int(a[i + 1]); i += 2
         elif a[i] == "--agg": agg = int(a[i + 1]); i += 2
+        elif a[i] == "--pipe": pipe = int(a[i + 1]); i += 2
         else:
             name, _, path = a[i].partition("=")
             libs.append((name, path or "base")); i += 1
     for r in range(rounds):
         for name, path in libs:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path, str(batch), str(steps), str(agg)],
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path, str(batch), str(steps), str(agg), str(pipe)],
                                capture_output=True, text=True)
             line = [l for l in p.stdout.splitlines() if l.startswith("AB ")]
             print(f"round {r} {name:16s} {line[0][3:] if line else 'FAILED ' + p.stderr[-400:]}", flush=True)
