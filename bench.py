@@ -336,6 +336,7 @@ def main():
     gathered = [None, None]
     pending = []       # gloo test mode: (step, event) whose host-side gather has not run yet
     step_no = [0]
+    gather_issued = [0]      # steps whose gather has been issued (it lags the step by one)
 
     def gather_on_host(k, ev):   # test mode only (every rank on GPU 0, collectives on host copies)
         ev.synchronize()
@@ -343,21 +344,14 @@ def main():
         gathered[0], gathered[1] = gatherer.gather(d_proofs[k & 1].cpu(), d_status_all[k].cpu(), slot=k & 1)
         gather_host_s[0] += time.perf_counter() - g0
 
-    def step():
-        k = step_no[0]
-        step_no[0] += 1
+    GATHER_MARK = 6     # mark slots 6, 7: the gather's (0..5 are the pipelined tree's, plonky25_amd.aggregate.DeviceTree)
+
+    def issue_gather(k):
+        """The final aggregation step of batch k: finished proofs gathered onto rank 0 (RCCL over xGMI) on a side stream
+        that waits -- on the device -- for the mark taken when step k had been enqueued."""
         buf = k & 1
-        if nccl and k >= 2:   # gather k-2 (the only work side[buf] holds) still reads the buffer this step overwrites
-            circuit.wait_stream(side[buf].cuda_stream)
-        if B:
-            circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), d_proofs[buf].data_ptr(), pw,
-                              d_status_all[k].data_ptr())
-        if not distributed:
-            return
-        # the final aggregation step of every batch: finished proofs gathered onto rank 0 (RCCL over xGMI).  The side
-        # stream waits for THIS step's proofs on the device; the host goes on to enqueue the next step.
         with torch.cuda.stream(side[buf]):
-            circuit.stream_join(side[buf].cuda_stream)
+            circuit.stream_wait_mark(GATHER_MARK + buf, side[buf].cuda_stream)
             if nccl:
                 g_ev[k][0].record(side[buf])
                 gathered[0], gathered[1] = gatherer.gather(d_proofs[buf], d_status_all[k], slot=buf)
@@ -366,10 +360,32 @@ def main():
                 ev = torch.cuda.Event()
                 ev.record(side[buf])
                 pending.append((k, ev))
-        if not nccl and len(pending) > 1:   # host copies lag one step: step k is gathered while step k+1 proves
+
+    def step():
+        k = step_no[0]
+        step_no[0] += 1
+        buf = k & 1
+        if nccl and k >= 2:   # gather k-2 (the only work side[buf] holds) still reads the buffer this step overwrites
+            circuit.wait_stream(side[buf].cuda_stream)
+        while pending and pending[0][0] <= k - 2:   # test mode (host copies): the same protection, on the host
             gather_on_host(*pending.pop(0))
+        if B:
+            circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), d_proofs[buf].data_ptr(), pw,
+                              d_status_all[k].data_ptr())
+        if not distributed:
+            return
+        # The gather of step k is issued ONE STEP LATE, after step k+1 has been enqueued: streams share hardware queues,
+        # and a wait that is not yet satisfied when it reaches the head of its queue would hold up the next step's
+        # kernels enqueued behind it; the host never blocks either way.
+        circuit.mark(GATHER_MARK + buf)
+        while gather_issued[0] < k:
+            issue_gather(gather_issued[0])
+            gather_issued[0] += 1
 
     def drain():
+        while distributed and gather_issued[0] < step_no[0]:   # the last step's gather
+            issue_gather(gather_issued[0])
+            gather_issued[0] += 1
         while pending:
             gather_on_host(*pending.pop(0))
         circuit.sync()
@@ -428,26 +444,25 @@ def main():
         agg_state = pagg.fold_sharded(circuit, last[:n_agg].cpu().numpy().view(np.uint64), args.aggregate_arity, cdev,
                                       distributed)
 
-    # --- the same tree PIPELINED: device-resident, enqueue-only, step j's tree underneath step j+1's leaves -----------
-    # What a production batch prover runs: every step = B leaf proofs + the aggregation tree over them (B -> B/8 -> ...
-    # -> 1 per rank), nothing synchronised until the end.  Measures leaf proofs/s INCLUDING their aggregation directly.
+    # --- the same tree PIPELINED: device-resident, enqueue-only, lagged one step per level -----------------------------
+    # What a production batch prover runs: every step = B leaf proofs + one instance of every level of the aggregation
+    # tree (B -> B/8 -> ... -> 1 per rank, over the leaves of earlier steps), nothing synchronised until the end.
+    # Measures leaf proofs/s INCLUDING their aggregation directly, in steady state.
     pipe = None
     nl = pagg.largest_pow2(B) if B >= 1 else 0
     if args.aggregate != 0 and ok and nl >= 2 and (agg_state is None or not agg_state.get("error")):
         perr, tree = None, None
+        K_pipe = 3
         try:
-            tree = pagg.DeviceTree(circuit, nl, args.aggregate_arity, dev)
-            K_pipe = 2
-            d_status_pipe = torch.zeros((K_pipe + 1, B), dtype=torch.int32, device=dev)
+            tree = pagg.DeviceTree(circuit, nl, args.aggregate_arity, dev, leaf_batch=B)
+            d_status_pipe = torch.zeros((len(tree.levels) + 1 + K_pipe, B), dtype=torch.int32, device=dev)
 
-            def pstep(k):
-                tree.before_leaves()
-                circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), d_proofs[k & 1].data_ptr(), pw,
-                                  d_status_pipe[k].data_ptr())
-                return tree.enqueue(d_proofs[k & 1][:nl])
+            def pleaves(buf, j):
+                circuit.prove_dev(d_inputs.data_ptr(), B, d_seeds.data_ptr(), buf.data_ptr(), pw, d_status_pipe[j].data_ptr())
 
-            pstep(0)                       # warm-up: the contexts of every level's circuit
-            circuit.sync(); tree.sync(); torch.cuda.synchronize()
+            for _ in range(len(tree.levels) + 1):      # fill the pipeline: every level has run once (contexts, tables)
+                tree.step(pleaves)
+            tree.sync(); torch.cuda.synchronize()
         except Exception as e:
             perr = str(e)[:300]
         fine = perr is None
@@ -460,18 +475,19 @@ def main():
         if fine:
             torch.cuda.synchronize()
             tp0 = time.perf_counter()
-            slot = 0
-            for k in range(1, K_pipe + 1):
-                slot = pstep(k)
-            circuit.sync(); tree.sync(); torch.cuda.synchronize()
+            for _ in range(K_pipe):
+                tree.step(pleaves)
+            tree.sync(); torch.cuda.synchronize()
             p_elapsed = time.perf_counter() - tp0
             if distributed:
                 p_elapsed = pdist.max_over_ranks(p_elapsed, cdev)
-            root, root_ok = tree.root(slot)
+            tree.flush(); tree.sync(); torch.cuda.synchronize()       # the levels still owed to the last steps, untimed
+            last_step = tree.leaf_steps - 1
+            root, root_ok = tree.root(last_step)
             leaves_ok = bool((d_status_pipe.cpu().numpy() == 0).all())
             pipe = {"tree": tree, "elapsed": p_elapsed, "steps": K_pipe, "leaves": nl, "root": root,
                     "statuses_ok": bool(root_ok and leaves_ok),
-                    "caps": d_proofs[K_pipe & 1][:nl, :pagg.CAP_WORDS].cpu().numpy().view(np.uint64).copy()}
+                    "caps": tree.leaf_proofs(last_step)[:nl, :pagg.CAP_WORDS].cpu().numpy().view(np.uint64).copy()}
         else:
             pipe = {"error": perr or "another rank's pipelined tree failed"}
 
@@ -715,10 +731,11 @@ def main():
                         "all_statuses_ok": pipe["statuses_ok"], "root_public_inputs_commit_to_the_leaves": got == want,
                         "oracle_verifier_accepts_root": bool(verify_with_oracle(tree.top, pipe["root"])),
                         "tree_circuit_build_s_once_per_shape": round(tree.build_s, 2),
-                        "note": "every step = the leaf batch + the whole aggregation tree over it, device-resident (a level proves "
-                                "straight on the buffer the level below writes: an aggregator's inputs are its children's flat "
-                                "proofs back to back), enqueue-only, ordered by p25_circuit_stream_join / p25_circuit_wait_stream; "
-                                "the tree of step j runs underneath the leaves of step j+1; rank 0's root of the last step checked"}
+                        "note": "steady state: every timed step = one leaf batch + one instance of every level of the aggregation tree "
+                                "(over the leaves of earlier steps: level l lags l steps), device-resident (a level proves straight "
+                                "on the buffer the level below writes: an aggregator's inputs are its children's flat proofs back "
+                                "to back), enqueue-only, ordered by events (p25_circuit_mark / p25_circuit_wait_mark); rank 0's "
+                                "root of the last step checked after the pipeline has been flushed"}
                     tree.close()
                 except Exception as e:
                     out["aggregation"]["pipelined"] = {"error": str(e)[:300]}

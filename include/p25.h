@@ -286,6 +286,21 @@ p25_status p25_circuit_sync(p25_circuit* c);
  * host-blocking p25_circuit_sync between pipelined steps. */
 p25_status p25_circuit_stream_join(p25_circuit* c, void* stream);
 p25_status p25_circuit_wait_stream(p25_circuit* c, void* stream);
+/* The same between two circuits, through events only -- chaining provers on the device, e.g. an aggregation circuit
+ * (p25_circuit_build_aggregator) proving straight on the buffer its children's proofs are being written to: its inputs
+ * are those flat proofs back to back, so `d_inputs` of its p25_prove_batch_dev is the producer's `d_proofs`.
+ *   p25_circuit_mark(c, slot):            remember the tail of every proving stream of c under `slot` (0..7)
+ *   p25_circuit_wait_mark(c, producer, slot):  what c is asked for from now on starts only after the producer's mark
+ * Marks are events: recording one never blocks, and a wait issued long after the mark (plonky25_amd.aggregate.DeviceTree
+ * issues a level's wait one step late) finds it already satisfied, so no hardware queue stalls on it.  Upstream's
+ * counterpart is host code: `builder.verify_proof` circuits proved one after the other by `data.prove(pw)`
+ * (src/p3/mod.rs:260) with the proofs passed through `PartialWitness`. */
+p25_status p25_circuit_mark(p25_circuit* c, uint32_t slot);
+p25_status p25_circuit_wait_mark(p25_circuit* c, p25_circuit* producer, uint32_t slot);
+/* ... and a stream of the caller's waiting for a mark: p25_circuit_stream_join that can be issued late (bench.py marks
+ * step k when it has enqueued it and lets the gather's side stream wait for that mark only after step k+1 has been
+ * enqueued, so the wait never sits unsatisfied at the head of a hardware queue shared with a proving stream). */
+p25_status p25_circuit_stream_wait_mark(p25_circuit* c, uint32_t slot, void* stream);
 /* Proofs kept in flight by the batch entry points: one HIP stream and one per-proof working set (~1.6 GB for the
  * fib-64 circuit) each; 1..32, default 16 (12 .. 20 measure the same, 24 and more are slower).  A library setting, not an
  * environment variable. */

@@ -168,74 +168,103 @@ class DeviceTree:
     """The aggregation tree of one shard kept RESIDENT ON THE DEVICE and only ever enqueued: an aggregation circuit's
     inputs are its k children's flat proofs back to back, i.e. exactly k consecutive rows of the buffer the level
     below writes its proofs into (proof stride = proof words), so a level is `p25_prove_batch_dev` straight on the
-    previous level's output -- no host round trip, no synchronisation.  Ordering between the circuits' streams is
-    device-side (`p25_circuit_stream_join` / `p25_circuit_wait_stream`), so the tree of step j runs underneath the leaf
-    proving of step j+1 and its latency-bound top (one or two proofs per level) costs no idle machine.
+    previous level's output -- no host round trip, no synchronisation.  Ordering between the circuits is device-side
+    and event-only (`p25_circuit_mark` / `p25_circuit_wait_mark`).
 
-    Buffers are `slots`-deep: step j uses slot j % slots.  A level's proofs of step j are overwritten by step j+slots,
-    which first waits (on the device) for the level ABOVE to have finished step j."""
+    The schedule is LAGGED: level l of step i is enqueued one step after level l-1 of step i (level 1 after the leaves
+    of step i+1 have been enqueued, level 2 after those of step i+2, ...).  HIP streams are multiplexed onto a few
+    hardware queues, and a wait that is not yet satisfied when it reaches the head of its queue holds up whatever was
+    enqueued behind it on the streams sharing that queue -- the next step's leaf kernels; issued a step late, the wait
+    is long satisfied and costs nothing, and the tree's latency-bound top (one or two proofs per level) hides under a
+    full machine.  (Round 4, measured: un-lagged with helper streams 110 leaf-equivalent proofs/s against 138
+    un-aggregated -- 12.8 ms of machine per aggregate proof for 7.4 ms of work; more hardware queues: 70.)
 
-    def __init__(self, circuit, n_leaves, arity, device, slots=2):
+    Buffers are `slots` = levels + 2 deep: step i uses slot i % slots; a buffer is rewritten only after the level above
+    has marked that it has finished reading it.  `level_streams`: proofs kept in flight by level 1, 2, ... (the last
+    entry repeats): the tree is 1/8 of the work and runs under the leaf circuit's 16 streams."""
+
+    def __init__(self, circuit, n_leaves, arity, device, leaf_batch=None, level_streams=(4, 2, 1)):
         import torch
         if n_leaves < 2 or n_leaves & (n_leaves - 1):
             raise ValueError("DeviceTree needs a power-of-two number of leaves >= 2")
-        self.torch, self.dev, self.slots, self.n_leaves, self.arity = torch, device, slots, n_leaves, arity
+        self.torch, self.dev, self.n_leaves, self.arity = torch, device, n_leaves, arity
         self.leaf, self.levels, self.build_s = circuit, [], 0.0
+        plan = level_plan(n_leaves, arity)
+        self.slots = len(plan) + 2
+        if self.slots > 6:     # mark slots 6 and 7 are bench.py's (the gather of the timed steps)
+            raise ValueError("tree too deep for the mark slots it may use (0..5)")
+        self.leaf_batch = leaf_batch or n_leaves
+        lpw = int(circuit.info.proof_words)
+        self.leaf_buf = [torch.zeros((self.leaf_batch, lpw), dtype=torch.int64, device=device) for _ in range(self.slots)]
         circ, n = circuit, n_leaves
-        for k in level_plan(n_leaves, arity):
+        for k in plan:
             t = time.perf_counter()
             nxt = circ.build_aggregator(k)
             nxt.digest()
             self.build_s += time.perf_counter() - t
             n //= k
+            if level_streams:
+                nxt.set_streams(max(1, min(level_streams[min(len(self.levels), len(level_streams) - 1)], n)))
             pw = int(nxt.info.proof_words)
             assert int(nxt.info.num_inputs) == k * int(circ.info.proof_words)
             self.levels.append({
                 "circ": nxt, "n": n, "k": k, "pw": pw,
                 "seeds": torch.arange(n, dtype=torch.int64, device=device),
-                "out": [torch.zeros((n, pw), dtype=torch.int64, device=device) for _ in range(slots)],
-                "status": [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(slots)],
-                # marker[s]: a stream that holds "this level's work up to the latest step of slot s"
-                "marker": [torch.cuda.Stream(device=device) for _ in range(slots)],
+                "out": [torch.zeros((n, pw), dtype=torch.int64, device=device) for _ in range(self.slots)],
+                "status": [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(self.slots)],
             })
             circ = nxt
         self.top = circ
-        self.hop = [torch.cuda.Stream(device=device) for _ in self.levels]   # carry "the level below is done" upwards
         self.aggregates_per_step = sum(L["n"] for L in self.levels)
-        self.steps = 0
+        self.host_steps = 0      # calls of step()
+        self.leaf_steps = 0      # steps whose leaves have been enqueued
 
-    def before_leaves(self):
-        """Call before enqueuing the leaf proofs of the next step into its slot: they overwrite the buffer level 1 read
-        `slots` steps ago."""
-        if self.steps >= self.slots:
-            self.leaf.wait_stream(self.levels[0]["marker"][self.steps % self.slots].cuda_stream)
-
-    def enqueue(self, d_leaf_proofs):
-        """Enqueue the whole tree over the leaf proofs just enqueued (`d_leaf_proofs`: [n_leaves, leaf proof words]
-        int64, contiguous, being written by the leaf circuit's streams).  Returns the slot."""
-        s = self.steps % self.slots
-        below_c, below_buf = self.leaf, d_leaf_proofs
-        for i, L in enumerate(self.levels):
-            c = L["circ"]
-            below_c.stream_join(self.hop[i].cuda_stream)       # everything the level below has been asked for ...
-            c.wait_stream(self.hop[i].cuda_stream)             # ... before this level's witness generation reads it
-            if self.steps >= self.slots and i + 1 < len(self.levels):   # the level above still reads out[s] of step - slots
-                c.wait_stream(self.levels[i + 1]["marker"][s].cuda_stream)
-            c.prove_dev(below_buf.data_ptr(), L["n"], L["seeds"].data_ptr(), L["out"][s].data_ptr(), L["pw"],
+    def step(self, prove_leaves=None):
+        """One host step: enqueue the leaf proofs of step j (`prove_leaves(buffer, j)` must enqueue them on the leaf
+        circuit into `buffer`, [leaf_batch, proof words] int64; the tree folds its first n_leaves rows), then level l of
+        step j - l for every level.  `prove_leaves=None`: no new leaves (flushing the levels still owed)."""
+        j, S = self.host_steps, self.slots
+        circs = [self.leaf] + [L["circ"] for L in self.levels]
+        if prove_leaves is not None:
+            assert j == self.leaf_steps, "leaf steps must be consecutive"
+            s = j % S
+            if j >= S:                                   # level 1 has finished reading this slot (step j - S)
+                self.leaf.wait_mark(circs[1], s)
+            prove_leaves(self.leaf_buf[s], j)
+            self.leaf.mark(s)
+            self.leaf_steps += 1
+        for l in range(1, len(circs)):
+            i = j - l
+            if i < 0 or i >= self.leaf_steps:
+                continue
+            s, L, c = i % S, self.levels[l - 1], circs[l]
+            c.wait_mark(circs[l - 1], s)                 # the level below has written step i (marked a host step ago)
+            if i >= S and l + 1 < len(circs):            # the level above has finished reading out[s] of step i - S
+                c.wait_mark(circs[l + 1], s)
+            below = self.leaf_buf[s][:self.n_leaves] if l == 1 else self.levels[l - 2]["out"][s]
+            c.prove_dev(below.data_ptr(), L["n"], L["seeds"].data_ptr(), L["out"][s].data_ptr(), L["pw"],
                         L["status"][s].data_ptr())
-            c.stream_join(L["marker"][s].cuda_stream)
-            below_c, below_buf = c, L["out"][s]
-        self.steps += 1
-        return s
+            c.mark(s)
+        self.host_steps += 1
+
+    def flush(self):
+        """Enqueue the levels still owed to the leaf steps already enqueued."""
+        for _ in self.levels:
+            self.step(None)
 
     def sync(self):
+        self.leaf.sync()
         for L in self.levels:
             L["circ"].sync()
 
-    def root(self, slot):
-        """(root proof, all statuses zero) of a finished step (host copies)."""
-        ok = all(int((L["status"][slot] != 0).sum().item()) == 0 for L in self.levels)
-        return self.levels[-1]["out"][slot][0].cpu().numpy().view(np.uint64), ok
+    def root(self, step):
+        """(root proof, every aggregate's status zero) of leaf step `step` (one of the last `slots`), after sync()."""
+        s = step % self.slots
+        ok = all(int((L["status"][s] != 0).sum().item()) == 0 for L in self.levels)
+        return self.levels[-1]["out"][s][0].cpu().numpy().view(np.uint64), ok
+
+    def leaf_proofs(self, step):
+        return self.leaf_buf[step % self.slots]
 
     def close(self):
         for L in self.levels:

@@ -154,6 +154,9 @@ EXPORTED_SYMBOLS = {
     "p25_circuit_sync": (i32, [vp]),
     "p25_circuit_stream_join": (i32, [vp, vp]),
     "p25_circuit_wait_stream": (i32, [vp, vp]),
+    "p25_circuit_mark": (i32, [vp, C.c_uint32]),
+    "p25_circuit_wait_mark": (i32, [vp, vp, C.c_uint32]),
+    "p25_circuit_stream_wait_mark": (i32, [vp, C.c_uint32, vp]),
     "p25_circuit_kernel_stats": (i32, [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "p25_witness": (i32, [vp, vp, C.c_uint64, vp, C.POINTER(i32)]),
     "p25_transcript": (i32, [vp, vp, vp, sz, vp]),
@@ -548,6 +551,18 @@ class Circuit:
     def wait_stream(self, stream):
         """Proofs requested from now on start only after what `stream` holds now."""
         _check(lib().p25_circuit_wait_stream(self._h, C.c_void_p(stream)))
+
+    def mark(self, slot):
+        """Remember the tail of every proving stream under `slot` (0..7); see wait_mark."""
+        _check(lib().p25_circuit_mark(self._h, slot))
+
+    def stream_wait_mark(self, slot, stream):
+        """`stream` (a raw hipStream_t) waits for mark(slot)'s point."""
+        _check(lib().p25_circuit_stream_wait_mark(self._h, slot, C.c_void_p(stream)))
+
+    def wait_mark(self, producer, slot):
+        """Proofs requested from now on start only after `producer.mark(slot)`'s point (device-side, events only)."""
+        _check(lib().p25_circuit_wait_mark(self._h, producer._h, slot))
 
     def set_streams(self, n):
         """Proofs kept in flight by the batch entry points (1..32, default 16)."""

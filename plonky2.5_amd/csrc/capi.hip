@@ -644,6 +644,32 @@ p25_status p25_circuit_wait_stream(p25_circuit* c, void* stream) {
     return P25_OK;
   });
 }
+p25_status p25_circuit_mark(p25_circuit* c, uint32_t slot) {
+  return guarded([&]() -> p25_status {
+    if (!c) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
+    c->device().mark((int)slot);
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_stream_wait_mark(p25_circuit* c, uint32_t slot, void* stream) {
+  return guarded([&]() -> p25_status {
+    if (!c) throw std::invalid_argument("null argument");
+    P25_LOCK(c);
+    c->device().stream_wait_mark((hipStream_t)stream, (int)slot);
+    return P25_OK;
+  });
+}
+p25_status p25_circuit_wait_mark(p25_circuit* c, p25_circuit* producer, uint32_t slot) {
+  return guarded([&]() -> p25_status {
+    if (!c || !producer) throw std::invalid_argument("null argument");
+    if (c == producer) throw std::invalid_argument("a circuit's own streams are already in order");
+    std::lock(c->mu, producer->mu);   // both, without a lock-order deadlock between two threads chaining opposite ways
+    std::lock_guard<std::recursive_mutex> l1(c->mu, std::adopt_lock), l2(producer->mu, std::adopt_lock);
+    c->device().wait_mark(producer->device(), (int)slot);
+    return P25_OK;
+  });
+}
 p25_status p25_circuit_kernel_stats(p25_circuit* c, int enable, int reset, double* ms_out, uint64_t* launches_out) {
   return guarded([&]() -> p25_status {
     if (!c) throw std::invalid_argument("null argument");

@@ -229,18 +229,9 @@ static u64* launch_levels_to_cap(u64* cur, size_t m, unsigned cap_height, hipStr
       }
       return cur;
     }
-    // A lone proof: in the range where a level runs cooperatively anyway (one permutation deep whatever its size), FIVE
-    // levels per launch -- k_tree_top_coop with every block reducing a 32-node subtree to its root, the levels in
-    // between staying in LDS -- instead of five launches that each pay a kernel boundary and the constants' staging.
-    if (single_proof && (m >> 1) <= COOP_PARENTS_SINGLE && (m >> 5) >= cap && (m >> 5) <= 65536) {
-      hipLaunchKernelGGL(k_tree_top_coop, dim3((unsigned)(m >> 5)), dim3(TOP_GROUPS * coop::GROUP), 0, st, cur,
-                         (uint32_t)TOP_MAX_NODES, (uint32_t)(m >> 5));
-      for (int k = 0; k < 5; k++) {
-        cur += 4 * m;
-        m >>= 1;
-      }
-      continue;
-    }
+    // (Measured and not adopted, round 4: five cooperative levels per launch for a lone proof -- k_tree_top_coop with every
+    // block reducing a 32-node subtree -- instead of five launches: 2048 blocks keep eight waves per SIMD resident through
+    // the later levels and the wires commit of a lone proof went 5.8 -> 5.96 ms.)
     u64* nxt = cur + 4 * m;
     m >>= 1;
     launch_level(cur, nxt, m, st, single_proof);

@@ -534,7 +534,7 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
 // The recursion instantiation (k_quotient_rec: aggregation circuits): waves per SIMD, and whether the merged pass over
 // the routed wires (below) is compiled in for it too
 #ifndef P25_QREC_WAVES
-#define P25_QREC_WAVES 2
+#define P25_QREC_WAVES 3
 #endif
 #ifndef P25_QREC_MERGED
 #define P25_QREC_MERGED 1

@@ -96,6 +96,14 @@ class DeviceCircuit {
   //   wait_stream(ext):  everything this circuit enqueues from now on waits for what `ext` holds now
   void stream_join(hipStream_t ext);
   void wait_stream(hipStream_t ext);
+  // The same between two CIRCUITS, through events only (no helper stream whose wait packets would sit in a hardware
+  // queue in front of unrelated work): mark(slot) records the tail of every proving stream of this circuit;
+  // wait_mark(producer, slot) makes everything this circuit enqueues from now on wait for the producer's mark.
+  // A level of an aggregation tree proves straight on the buffer the level below wrote (plonky25_amd.aggregate).
+  static constexpr int MAX_MARKS = 8;
+  void mark(int slot);
+  void wait_mark(DeviceCircuit& producer, int slot);
+  void stream_wait_mark(hipStream_t ext, int slot);   // a caller's stream waits for mark(slot) (stream_join, but lag-able)
   // proofs kept in flight by prove_batch* (one HIP stream + working set each), 1..16
   void set_streams(int k) { streams_ = k < 1 ? 1 : (k > 32 ? 32 : k); }
   hipStream_t stream() const { return stream_; }
@@ -131,6 +139,8 @@ class DeviceCircuit {
   std::vector<std::unique_ptr<Ctx>> ctxs_;   // proofs in flight: one working set + HIP stream each
   hipEvent_t ev_witness_[2] = {nullptr, nullptr};  // witness pass into vals_[b] finished
   hipEvent_t ev_ext_ = nullptr, ev_main_ = nullptr;  // stream_join / wait_stream
+  std::vector<hipEvent_t> marks_[MAX_MARKS];         // mark(slot): [0] the main stream, [1 + k] proving stream k
+  size_t marks_recorded_[MAX_MARKS] = {0};           // how many of them the latest mark(slot) recorded
   int streams_ = 16;
   bool single_proof_ = false;  // set per prove call: one proof in flight -> latency-oriented kernel forms
   DevMem vals_[2];             // witness values of a pass, slot-major [slot][proof of the pass]; double-buffered

@@ -320,6 +320,8 @@ DeviceCircuit::~DeviceCircuit() {
   ctxs_.clear();
   for (auto& e : ev_witness_)
     if (e) (void)hipEventDestroy(e);
+  for (auto& v : marks_)
+    for (auto& e : v) (void)hipEventDestroy(e);
   if (ev_ext_) (void)hipEventDestroy(ev_ext_);
   if (ev_main_) (void)hipEventDestroy(ev_main_);
   for (auto* v : {&kstats_pending_, &kstats_free_})
@@ -421,6 +423,28 @@ void DeviceCircuit::wait_stream(hipStream_t ext) {
   if (!ev_ext_) P25_HIP(hipEventCreateWithFlags(&ev_ext_, hipEventDisableTiming));
   P25_HIP(hipEventRecord(ev_ext_, ext));
   P25_HIP(hipStreamWaitEvent(stream_, ev_ext_, 0));
+}
+
+void DeviceCircuit::mark(int slot) {
+  if (slot < 0 || slot >= MAX_MARKS) throw std::invalid_argument("mark slot out of range");
+  auto& ev = marks_[slot];
+  while (ev.size() < 1 + ctxs_.size()) {
+    hipEvent_t e = nullptr;
+    P25_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ev.push_back(e);
+  }
+  P25_HIP(hipEventRecord(ev[0], stream_));
+  for (size_t k = 0; k < ctxs_.size(); k++) P25_HIP(hipEventRecord(ev[1 + k], ctxs_[k]->st));
+  marks_recorded_[slot] = 1 + ctxs_.size();
+}
+void DeviceCircuit::stream_wait_mark(hipStream_t ext, int slot) {
+  if (slot < 0 || slot >= MAX_MARKS) throw std::invalid_argument("mark slot out of range");
+  for (size_t k = 0; k < marks_recorded_[slot]; k++) P25_HIP(hipStreamWaitEvent(ext, marks_[slot][k], 0));
+}
+void DeviceCircuit::wait_mark(DeviceCircuit& producer, int slot) {
+  if (slot < 0 || slot >= MAX_MARKS) throw std::invalid_argument("mark slot out of range");
+  for (size_t k = 0; k < producer.marks_recorded_[slot]; k++)
+    P25_HIP(hipStreamWaitEvent(stream_, producer.marks_[slot][k], 0));
 }
 
 void DeviceCircuit::kernel_stats(double* ms, u64* launches, bool reset) {

@@ -7,7 +7,7 @@ import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(lib, batch, steps, agg, pipe=0):
+def child(lib, batch, steps, agg, pipe=0, tstreams="4,2,1"):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     import numpy as np, torch
@@ -50,22 +50,25 @@ def child(lib, batch, steps, agg, pipe=0):
         for i in range(3):
             _p, _s, tm1 = a1.prove(grp, seeds=[i], timings=True)
         out["agg"]["single"] = {k: round(v, 3) for k, v in tm1.as_dict().items()}
-    if pipe:   # the pipelined device-resident tree (bench.py's `aggregation.pipelined`): 1 warm-up step + `pipe` timed steps
+    if pipe:   # the pipelined device-resident tree (bench.py's `aggregation.pipelined`): warm-up steps + `pipe` timed steps
         from plonky25_amd import aggregate as ag
-        tree = ag.DeviceTree(c, ag.largest_pow2(batch), 8, dev)
-        d_sp = torch.zeros((pipe + 1, batch), dtype=torch.int32, device=dev)
+        ls = tuple(int(x) for x in tstreams.split(",")) if tstreams != "0" else None
+        tree = ag.DeviceTree(c, ag.largest_pow2(batch), 8, dev, leaf_batch=batch, level_streams=ls)
+        nst = len(tree.levels) + 1 + pipe
+        d_sp = torch.zeros((nst, batch), dtype=torch.int32, device=dev)
 
-        def pstep(k):
-            tree.before_leaves()
-            c.prove_dev(d_in.data_ptr(), batch, d_seeds.data_ptr(), d_p[k & 1].data_ptr(), pw, d_sp[k].data_ptr())
-            return tree.enqueue(d_p[k & 1][:tree.n_leaves])
-        pstep(0); c.sync(); tree.sync(); torch.cuda.synchronize()
+        def leaves(buf, j):
+            c.prove_dev(d_in.data_ptr(), batch, d_seeds.data_ptr(), buf.data_ptr(), pw, d_sp[j].data_ptr())
+        for _ in range(len(tree.levels) + 1):      # fill the pipeline: every level has run once
+            tree.step(leaves)
+        tree.sync(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(1, pipe + 1):
-            slot = pstep(k)
-        c.sync(); tree.sync(); torch.cuda.synchronize()
+        for _ in range(pipe):                      # steady state: every host step = one leaf batch + one instance of every level
+            tree.step(leaves)
+        tree.sync(); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        _root, rok = tree.root(slot)
+        tree.flush(); tree.sync(); torch.cuda.synchronize()
+        _root, rok = tree.root(tree.leaf_steps - 1)
         out["pipe"] = {"steps": pipe, "leaf_eq_proofs_per_s": round(batch * pipe / dt, 2), "ms_per_step": round(dt / pipe * 1e3, 1),
                        "ok": bool(rok and (d_sp.cpu().numpy() == 0).all())}
     print("AB " + json.dumps(out), flush=True)
@@ -74,8 +77,8 @@ def child(lib, batch, steps, agg, pipe=0):
 def main():
     a = sys.argv[1:]
     if a and a[0] == "--child":
-        return child(a[1], int(a[2]), int(a[3]), int(a[4]), int(a[5]))
-    batch, steps, rounds, agg, pipe, libs = 256, 3, 2, 0, 0, []
+        return child(a[1], int(a[2]), int(a[3]), int(a[4]), int(a[5]), a[6])
+    batch, steps, rounds, agg, pipe, libs, tstreams = 256, 3, 2, 0, 0, [], "0"
     i = 0
     while i < len(a):
         if a[i] == "--batch": batch = int(a[i + 1]); i += 2
@@ -83,15 +86,17 @@ def main():
         elif a[i] == "--rounds": rounds = int(a[i + 1]); i += 2
         elif a[i] == "--agg": agg = int(a[i + 1]); i += 2
         elif a[i] == "--pipe": pipe = int(a[i + 1]); i += 2
+        elif a[i] == "--tree-streams": tstreams = a[i + 1]; i += 2
+        elif a[i] == "--hwq": os.environ["GPU_MAX_HW_QUEUES"] = a[i + 1]; i += 2     # inherited by the children
         else:
             name, _, path = a[i].partition("=")
-            libs.append((name, path or "base")); i += 1
+            libs.append((name, path or "base", tstreams)); i += 1
     for r in range(rounds):
-        for name, path in libs:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path, str(batch), str(steps), str(agg), str(pipe)],
+        for name, path, ts in libs:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path, str(batch), str(steps), str(agg), str(pipe), ts],
                                capture_output=True, text=True)
             line = [l for l in p.stdout.splitlines() if l.startswith("AB ")]
-            print(f"round {r} {name:16s} {line[0][3:] if line else 'FAILED ' + p.stderr[-400:]}", flush=True)
+            print(f"round {r} {name:16s} hwq {os.environ.get('GPU_MAX_HW_QUEUES', '24'):3s} tree-streams {ts:8s} {line[0][3:] if line else 'FAILED ' + p.stderr[-400:]}", flush=True)
 
 
 if __name__ == "__main__":
