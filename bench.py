@@ -141,15 +141,16 @@ def bench_config5(p25, np, torch, dev, host_threads, verify):
     d_in = torch.from_numpy(host_in.view(np.int64)).to(dev)
     d_seeds = torch.arange(B, dtype=torch.int64, device=dev)
     d_proofs = torch.zeros((B, pw), dtype=torch.int64, device=dev)
-    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
+    steps = 3
+    d_status = torch.zeros((1 + steps, B), dtype=torch.int32, device=dev)   # a row per step: no step's statuses are erased
     torch.cuda.synchronize()
-    steps = 2
-    for it in range(1 + steps):
+    for it in range(1 + steps):     # like the main loop: the timed steps are only enqueued, one synchronisation at the end
         if it == 1:
+            circ.sync()
             torch.cuda.synchronize()
             t = time.perf_counter()
-        circ.prove_dev(d_in.data_ptr(), B, d_seeds.data_ptr(), d_proofs.data_ptr(), pw, d_status.data_ptr())
-        circ.sync()
+        circ.prove_dev(d_in.data_ptr(), B, d_seeds.data_ptr(), d_proofs.data_ptr(), pw, d_status[it].data_ptr())
+    circ.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     ok = bool((d_status.cpu().numpy() == 0).all())

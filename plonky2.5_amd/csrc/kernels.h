@@ -67,6 +67,8 @@ struct NttPass {
   int log_n_table;
   int use_twiddle;       // multiply output (t, j) by pow_table[t*j] (N = R*NT required)
   const u64* pre;        // optional [n_cosets][N]: input element at address k is multiplied by pre[coset][k]
+  const u64* pre_t;      // or, for N too large for that table to stay in L2, its two factors (in_kind 0, natural order only):
+  const u64* pre_i;      //   pre_t[coset][t] * pre_i[coset][i] for the element (t, i) at address t + i * NT
   const u64* post_t;     // optional [NT]
   const u64* post_i;     // optional [R]
   int inverse;           // pow_table holds powers of the INVERSE root (selects the 16th-root constants of kernels_ntt.hip)

@@ -112,9 +112,14 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
 
   for (int k = tid; k < (a.full_table ? R : R / 2); k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
 
-  // coset pre-scale: one table entry per input coefficient (shift_c^k at the coefficient's address k)
+  // coset pre-scale: one table entry per input coefficient (shift_c^k at the coefficient's address k) ...
   const u64* pre = a.pre ? a.pre + ((size_t)coset << (a.log_r + a.log_nt)) : nullptr;
-  auto in_slot = [&](int e, size_t& addr, int& slot) {
+  // ... or its two factors shift_c^t * (shift_c^NT)^i when N is too large for the table to live in L2 (2^19-row circuits:
+  // 8 cosets x 4 MB, re-fetched for every polynomial).  A lane's elements all have the same t (the block size is a multiple
+  // of the tile width), so the t factor is loaded once; the i factors (R entries per coset) stay cached.
+  const u64* pre_i = a.pre_t ? a.pre_i + ((size_t)coset << a.log_r) : nullptr;
+  const u64 pre_tv = a.pre_t ? a.pre_t[((size_t)coset << a.log_nt) + tg0 + (tid & (T - 1))] : 1;
+  auto in_slot = [&](int e, size_t& addr, int& slot, int& ii) {
     int t, i;
     if (a.in_kind == 0) {
       t = e & (T - 1);
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
       addr = (size_t)trow * R + off;
     }
     slot = i * TP + t;
+    ii = i;
   };
   // Eight elements per lane at a time: their loads (value + pre-scale factor) are all issued before the first is used.
   // (One element per iteration, as the loop was written first, is one exposed memory round trip per element: the
@@ -141,19 +147,22 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
 #pragma unroll
     for (int k = 0; k < LB; k++) {
       size_t addr;
-      in_slot(e + k * nth, addr, slot[k]);
+      int ii;
+      in_slot(e + k * nth, addr, slot[k], ii);
       xv[k] = in[addr];
-      pv[k] = pre ? pre[addr] : 1;
+      pv[k] = pre ? pre[addr] : (pre_i ? pre_i[ii] : 1);
     }
 #pragma unroll
-    for (int k = 0; k < LB; k++) lds[slot[k]] = pre ? gl::mul(xv[k], pv[k]) : xv[k];
+    for (int k = 0; k < LB; k++)
+      lds[slot[k]] = pre ? gl::mul(xv[k], pv[k]) : (pre_i ? gl::mul(gl::mul_nc(xv[k], pre_tv), pv[k]) : xv[k]);
   }
   for (; e < T * R; e += nth) {
     size_t addr;
-    int slot;
-    in_slot(e, addr, slot);
+    int slot, ii;
+    in_slot(e, addr, slot, ii);
     u64 x = in[addr];
     if (pre) x = gl::mul(x, pre[addr]);
+    if (pre_i) x = gl::mul(gl::mul_nc(x, pre_tv), pre_i[ii]);
     lds[slot] = x;
   }
   __syncthreads();
@@ -405,18 +414,40 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
   const u64* pw = tb.pow_table(log_n, false);
   const u64 w_big = gl::root_of_unity(log_n + rate_bits);
   // per-coset pre-scale table: coefficient k gets shift_c^k, shift_c = shift * w_{8n}^c  (n words per coset;
-  // one load + one multiply per element instead of two factor tables and two multiplies)
+  // one load + one multiply per element instead of two factor tables and two multiplies) -- while the table (8n words)
+  // fits the L2s next to the data (n <= 2^16: 4 MB, 1/8 of it per XCD).  Above that the two-pass transform takes the
+  // factors shift_c^k1 (k1 < R1) and (shift_c^R1)^k2 (k2 < R2) instead: 12 K words for n = 2^19 instead of 4 M.
   auto& cache = tb.coset_cache();
-  auto key = std::make_tuple(log_n, rate_bits, shift);
+  const bool factored = l1 != 0 && log_n > 16;
+  auto key = std::make_tuple(factored ? -log_n : log_n, rate_bits, shift);
   auto it = cache.find(key);
   if (it == cache.end()) {
-    std::vector<u64> h((size_t)nc * n);
-    for (int c = 0; c < nc; c++) {
-      u64 sc = gl::mul(shift, gl::pow(w_big, c));
-      u64 x = 1;
-      for (size_t k = 0; k < n; k++) {
-        h[(size_t)c * n + k] = x;
-        x = gl::mul(x, sc);
+    std::vector<u64> h;
+    if (!factored) {
+      h.resize((size_t)nc * n);
+      for (int c = 0; c < nc; c++) {
+        u64 sc = gl::mul(shift, gl::pow(w_big, c));
+        u64 x = 1;
+        for (size_t k = 0; k < n; k++) {
+          h[(size_t)c * n + k] = x;
+          x = gl::mul(x, sc);
+        }
+      }
+    } else {   // [nc][R1] then [nc][R2]
+      const size_t R1 = (size_t)1 << l1, R2 = (size_t)1 << l2;
+      h.resize((size_t)nc * (R1 + R2));
+      for (int c = 0; c < nc; c++) {
+        const u64 sc = gl::mul(shift, gl::pow(w_big, c)), sc_r1 = gl::pow(sc, R1);
+        u64 x = 1;
+        for (size_t k = 0; k < R1; k++) {
+          h[(size_t)c * R1 + k] = x;
+          x = gl::mul(x, sc);
+        }
+        x = 1;
+        for (size_t k = 0; k < R2; k++) {
+          h[(size_t)nc * R1 + (size_t)c * R2 + k] = x;
+          x = gl::mul(x, sc_r1);
+        }
       }
     }
     it = cache.emplace(key, tb.upload(h)).first;
@@ -427,7 +458,12 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
   p.in = d_coeffs; p.out = d_lde;
   p.in_poly_stride = coeff_stride; p.out_poly_stride = lde_stride;
   for (int c = 0; c < nc; c++) p.coset_out_off[c] = (size_t)gl::bitrev(c, rate_bits) * n;
-  p.pre = it->second;  // indexed by the input address: requires natural-order input (in_br_* = 0)
+  if (factored) {
+    p.pre_t = it->second;
+    p.pre_i = it->second + ((size_t)nc << l1);
+  } else {
+    p.pre = it->second;  // indexed by the input address: requires natural-order input (in_br_* = 0)
+  }
   if (l1 == 0) {
     p.log_r = l2; p.log_nt = 0; p.log_t = 0;
     p.in_kind = 1; p.out_kind = 1; p.out_br_i = 1;
