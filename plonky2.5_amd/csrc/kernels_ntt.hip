@@ -27,6 +27,18 @@
 #include "kernels.h"
 #include "ntt16.h"
 
+// transforms above 2^P25_NTT_FACTOR_LOG points take the coset pre-scale as two factor tables (ntt_lde_bitrev)
+// wave priority in the load and store phases of k_ntt_tile (the butterfly phases run at P25_PRIO_BULK)
+#ifndef P25_NTT_PRIO_LOAD
+#define P25_NTT_PRIO_LOAD P25_PRIO_BULK
+#endif
+#ifndef P25_NTT_PRIO_STORE
+#define P25_NTT_PRIO_STORE P25_PRIO_BULK
+#endif
+#ifndef P25_NTT_FACTOR_LOG
+#define P25_NTT_FACTOR_LOG 16
+#endif
+
 namespace p25 {
 
 // G consecutive radix-2 DIF stages on the 2^G elements col[k * step], k < 2^G, held in registers.
@@ -81,7 +93,7 @@ __device__ __forceinline__ void dif16_group(u64* col, const u64* wl, int step, i
 
 template <bool INV, int NTH>
 __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
-  P25_WAVE_PRIO(P25_PRIO_BULK);
+  P25_WAVE_PRIO(P25_NTT_PRIO_LOAD);   // the load phase: its waves' requests should leave before a sibling block's butterflies
   extern __shared__ u64 lds[];
   const int R = 1 << a.log_r, T = 1 << a.log_t;
   const int TP = T > 1 ? T + 1 : 1;  // row padding: conflict-free for both access directions
@@ -166,6 +178,7 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
     lds[slot] = x;
   }
   __syncthreads();
+  P25_WAVE_PRIO(P25_PRIO_BULK);
 
   // DIF network, natural in -> bit-reversed out, up to 4 stages (radix 16) per LDS round trip:
   // a work item holds the 2^g elements {base + k*stride} of one sub-transform in registers.
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
     slot = q * TP + t;
     tw = (u32)(tg0 + t);
   };
+  P25_WAVE_PRIO(P25_NTT_PRIO_STORE);
   // the four-step twiddles (a gather from the power table) likewise eight at a time
   int eo = tid;
   if (a.use_twiddle && !a.post_t) {
@@ -418,7 +432,7 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
   // fits the L2s next to the data (n <= 2^16: 4 MB, 1/8 of it per XCD).  Above that the two-pass transform takes the
   // factors shift_c^k1 (k1 < R1) and (shift_c^R1)^k2 (k2 < R2) instead: 12 K words for n = 2^19 instead of 4 M.
   auto& cache = tb.coset_cache();
-  const bool factored = l1 != 0 && log_n > 16;
+  const bool factored = l1 != 0 && log_n > P25_NTT_FACTOR_LOG;
   auto key = std::make_tuple(factored ? -log_n : log_n, rate_bits, shift);
   auto it = cache.find(key);
   if (it == cache.end()) {

@@ -539,6 +539,10 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
 #ifndef P25_QREC_MERGED
 #define P25_QREC_MERGED 1
 #endif
+// prefetch distance of the permutation-argument pass (1, 2, 4 or 8)
+#ifndef P25_Q_PF
+#define P25_Q_PF 1
+#endif
 #ifndef P25_QREC_PRIO
 #define P25_QREC_PRIO P25_PRIO_BULK
 #endif
@@ -710,21 +714,34 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     merged_mask = 0;
   }
   {
-    u64 wn = wrc.col(0), sn = csc.col(n_consts + 2);   // wire and sigma read one position ahead
+    // wires and sigmas read P25_Q_PF positions ahead (a ring of that many register pairs; the chunk length, 8, is a
+    // multiple of it, so the ring index is static in the unrolled loop)
+    constexpr int PF = P25_Q_PF;
+    u64 wq[PF], sq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; d++) {
+      wq[d] = d < RW ? wrc.col(d) : 0;
+      sq[d] = d < RW ? csc.col(n_consts + 2 + d) : 0;
+    }
     for (int k = 0; k < nch; k++) {
       u64 np0 = 1, dp0 = 1, np1 = 1, dp1 = 1;
       // beta * k_j * x: k_j * beta comes from a per-proof table (k_alpha_pows fills it)
-      for (int j = k * per; j < (k + 1) * per && j < RW; j++) {
-        const u64 w = wn, sg = sn;
-        if (j + 1 < RW) {
-          wn = wrc.col(j + 1);
-          sn = csc.col(n_consts + 3 + j);
+      for (int j0 = k * per; j0 < (k + 1) * per && j0 < RW; j0 += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; d++) {
+          const int j = j0 + d;
+          if (j >= RW || j >= (k + 1) * per) break;
+          const u64 w = wq[d], sg = sq[d];
+          if (j + PF < RW) {
+            wq[d] = wrc.col(j + PF);
+            sq[d] = csc.col(n_consts + 2 + j + PF);
+          }
+          const u64 wg0 = gl::add(w, gamma0), wg1 = gl::add(w, gamma1);
+          np0 = gl::mul_nc(np0, gl::mad_nc(kb[j], x, wg0));
+          dp0 = gl::mul_nc(dp0, gl::mad_nc(beta0, sg, wg0));
+          np1 = gl::mul_nc(np1, gl::mad_nc(kb[RW + j], x, wg1));
+          dp1 = gl::mul_nc(dp1, gl::mad_nc(beta1, sg, wg1));
         }
-        const u64 wg0 = gl::add(w, gamma0), wg1 = gl::add(w, gamma1);
-        np0 = gl::mul_nc(np0, gl::mad_nc(kb[j], x, wg0));
-        dp0 = gl::mul_nc(dp0, gl::mad_nc(beta0, sg, wg0));
-        np1 = gl::mul_nc(np1, gl::mad_nc(kb[RW + j], x, wg1));
-        dp1 = gl::mul_nc(dp1, gl::mad_nc(beta1, sg, wg1));
       }
 #pragma unroll
       for (int c = 0; c < NC; c++) {

@@ -7,6 +7,37 @@ import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def child_config5(lib, steps):
+    """BASELINE config 5 (2^20-row inner STARK, outer circuit 2^19 rows): 16 proofs per step, steps only enqueued."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    import numpy as np, torch
+    import __graft_entry__ as ge
+    p25 = ge.load_package()
+    if lib != "base":
+        sys.modules["plonky25_amd.binding"].lib_path = lib
+    p25.device_init(0)
+    dev = torch.device("cuda", 0)
+    inp, cfg = p25.p3_prove_fibonacci(20, 100, 16, threads=os.cpu_count())
+    c = p25.Circuit.build_p3_verifier(cfg); c.digest()
+    pw, B = int(c.info.proof_words), 16
+    d_in = torch.from_numpy(np.stack([inp] * B).view(np.int64)).to(dev)
+    d_seeds = torch.arange(B, dtype=torch.int64, device=dev)
+    d_p = torch.zeros((B, pw), dtype=torch.int64, device=dev)
+    d_s = torch.zeros((steps + 1, B), dtype=torch.int32, device=dev)
+    for k in range(steps + 1):
+        if k == 1:
+            c.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        c.prove_dev(d_in.data_ptr(), B, d_seeds.data_ptr(), d_p.data_ptr(), pw, d_s[k].data_ptr())
+    c.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"config5_proofs_per_s": round(B * steps / dt, 3), "ok": bool((d_s.cpu().numpy() == 0).all())}
+    for i in range(2):
+        _p, _s, tm = c.prove(inp, seeds=[i], timings=True)
+    out["single"] = {k: round(v, 2) for k, v in tm.as_dict().items()}
+    print("AB " + json.dumps(out), flush=True)
+
+
 def child(lib, batch, steps, agg, pipe=0, tstreams="4,2,1"):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
@@ -76,9 +107,11 @@ def child(lib, batch, steps, agg, pipe=0, tstreams="4,2,1"):
 
 def main():
     a = sys.argv[1:]
+    if a and a[0] == "--child5":
+        return child_config5(a[1], int(a[2]))
     if a and a[0] == "--child":
         return child(a[1], int(a[2]), int(a[3]), int(a[4]), int(a[5]), a[6])
-    batch, steps, rounds, agg, pipe, libs, tstreams = 256, 3, 2, 0, 0, [], "0"
+    batch, steps, rounds, agg, pipe, libs, tstreams, cfg5 = 256, 3, 2, 0, 0, [], "0", False
     i = 0
     while i < len(a):
         if a[i] == "--batch": batch = int(a[i + 1]); i += 2
@@ -86,6 +119,7 @@ def main():
         elif a[i] == "--rounds": rounds = int(a[i + 1]); i += 2
         elif a[i] == "--agg": agg = int(a[i + 1]); i += 2
         elif a[i] == "--pipe": pipe = int(a[i + 1]); i += 2
+        elif a[i] == "--config5": cfg5 = True; i += 1
         elif a[i] == "--tree-streams": tstreams = a[i + 1]; i += 2
         elif a[i] == "--hwq": os.environ["GPU_MAX_HW_QUEUES"] = a[i + 1]; i += 2     # inherited by the children
         else:
@@ -93,7 +127,8 @@ def main():
             libs.append((name, path or "base", tstreams)); i += 1
     for r in range(rounds):
         for name, path, ts in libs:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path, str(batch), str(steps), str(agg), str(pipe), ts],
+            argv = (["--child5", path, str(steps)] if cfg5 else ["--child", path, str(batch), str(steps), str(agg), str(pipe), ts])
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv,
                                capture_output=True, text=True)
             line = [l for l in p.stdout.splitlines() if l.startswith("AB ")]
             print(f"round {r} {name:16s} hwq {os.environ.get('GPU_MAX_HW_QUEUES', '24'):3s} tree-streams {ts:8s} {line[0][3:] if line else 'FAILED ' + p.stderr[-400:]}", flush=True)
