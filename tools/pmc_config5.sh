@@ -12,4 +12,4 @@ for C in "SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   python3 tools/pmc_summary.py $OUT/_pmc5 $OUT/${TAG}_config5_pmc_${C}.json 2 > $OUT/${TAG}_config5_pmc_${C}.txt
   rm -rf $OUT/_pmc5
 done
-tail -4 $OUT/${TAG}_config5_pmc_*.txt
+for f in $OUT/${TAG}_config5_pmc_*.txt; do tail -n 1 $f; done
