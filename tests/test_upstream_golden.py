@@ -110,3 +110,21 @@ def test_circuit_data_bytes_equal_upstream(gpu, fib_circuit):
     first = next((i for i, (a, b) in enumerate(zip(mine, h)) if a != b), None)
     assert first is None, f"CircuitData bytes differ from upstream's at offset {first}"
     assert len(mine) == up["len"] and hashlib.sha256(mine).hexdigest() == up["sha256"]
+
+
+need_rec = pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "upstream_recursive_circuit.json")),
+                              reason="no upstream run of builder.verify_proof available (tools/upstream_check)")
+
+
+@need_rec
+def test_recursive_verifier_shape_vs_upstream(p25, fib_circuit, fib_oracle):
+    """The day cargo exists: how far `p25_circuit_build_recursive_verifier` is from upstream's `builder.verify_proof`
+    circuit for one fib-64 proof.  The gate SET must agree (the library claims upstream's gate set); rows per gate and
+    the digest are reported, and asserted only once DESIGN.md section 6 stops disclaiming row-for-row equality."""
+    up = json.load(open(os.path.join(GOLD, "upstream_recursive_circuit.json")))
+    dg, cap = fib_oracle.digest()
+    rc = fib_circuit.build_recursive_verifier(1, dg, cap)
+    counts = rc.gate_counts()
+    assert sorted(counts.keys()) == sorted(up["gate_ids"]), (sorted(counts.keys()), sorted(up["gate_ids"]))
+    print("rows per gate (libp25 / upstream):", {k: (counts[k], dict(zip(up["gate_ids"], up["rows_per_gate"]))[k]) for k in counts})
+    print("degree bits (libp25 / upstream):", int(rc.info.degree_bits), up["degree_bits"])

@@ -111,7 +111,42 @@ fn main() -> Result<()> {
         std::fs::write("upstream_circuit_data.json", serde_json::to_string(&json!({
             "len": bytes.len(), "sha256": format!("{:x}", Sha256::digest(&bytes)), "head_len": head.len() }))?)?;
     }
-    data.verify(proof)?;                                                      // src/p3/mod.rs:266
+    data.verify(proof.clone())?;                                              // src/p3/mod.rs:266
+    // ---- the recursive verifier of that proof: upstream's own `builder.verify_proof`, so that libp25's
+    // `p25_circuit_build_recursive_verifier` -- restated from memory, NOT claimed row for row -- becomes
+    // checkable: gate table, rows per gate and circuit digest of the circuit upstream builds for one inner proof with the
+    // inner verifier data as constants (tests/test_upstream_golden.py::test_recursive_verifier_shape_vs_upstream).
+    {
+        let mut rb = CircuitBuilder::<F, D>::new(CircuitConfig::standard_recursion_config());
+        let pt = rb.add_virtual_proof_with_pis(&data.common);
+        let vd = rb.constant_verifier_data(&data.verifier_only);
+        rb.verify_proof::<C>(&pt, &vd, &data.common);
+        let rdata = rb.build::<C>();
+        let rc = &rdata.common;
+        let rn = rc.degree();
+        let rvals: Vec<Vec<F>> = rdata.prover_only.constants_sigmas_commitment.polynomials.iter()
+            .map(|p| p.clone().fft().values).collect();
+        let mut rrows = vec![0usize; rc.gates.len()];
+        for r in 0..rn {
+            for g in 0..rc.gates.len() {
+                let s = rc.selectors_info.selector_indices[g];
+                if rvals[s][r].to_canonical_u64() == g as u64 { rrows[g] += 1; }
+            }
+        }
+        let mut rpw = PartialWitness::new();
+        rpw.set_proof_with_pis_target(&pt, &proof);
+        let rproof = rdata.prove(rpw)?;
+        std::fs::write("upstream_recursive_circuit.json", serde_json::to_string_pretty(&json!({
+            "degree_bits": rc.degree_bits(),
+            "gate_ids": rc.gates.iter().map(|g| g.0.id()).collect::<Vec<_>>(),
+            "rows_per_gate": rrows,
+            "num_gate_constraints": rc.num_gate_constraints,
+            "num_generators": rdata.prover_only.generators.len(),
+            "circuit_digest": rdata.verifier_only.circuit_digest.elements.iter().map(|e| e.to_canonical_u64()).collect::<Vec<_>>(),
+        }))?)?;
+        std::fs::write("upstream_recursive_proof.json", serde_json::to_string(&rproof)?)?;
+        rdata.verify(rproof)?;
+    }
     // the circuit as libp25 takes it (p25_circuit_import): prove it on the GPU, feed the proof back to data.verify
     std::fs::write("upstream_circuit.p25blob", export_blob::export_p25_blob(&data, &proof_t.flat_targets()))?;   // flat_targets(): the add_virtual_to order, proof.rs:357-373
     println!("wrote upstream_circuit.json, upstream_proof.json, upstream_filler.json (n = 2^{})", common.degree_bits());
