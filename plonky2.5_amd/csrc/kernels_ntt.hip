@@ -23,18 +23,15 @@
 //   kind 1 ("i-contiguous"): addr = tmap(t) * R + imap(i)
 // where imap/tmap are the identity or a bit reversal.  All values are canonical field elements.
 #include <stdlib.h>
+#include <mutex>
+#include <set>
 #include <tuple>
 #include "kernels.h"
 #include "ntt16.h"
 
 // transforms above 2^P25_NTT_FACTOR_LOG points take the coset pre-scale as two factor tables (ntt_lde_bitrev)
-// wave priority in the load and store phases of k_ntt_tile (the butterfly phases run at P25_PRIO_BULK)
-#ifndef P25_NTT_PRIO_LOAD
-#define P25_NTT_PRIO_LOAD P25_PRIO_BULK
-#endif
-#ifndef P25_NTT_PRIO_STORE
-#define P25_NTT_PRIO_STORE P25_PRIO_BULK
-#endif
+// (Phase priorities -- load / store phases of k_ntt_tile above or below its butterflies -- were measured in round 4 and
+// change nothing: profiles/r04_ab_ntt_phase_priority.txt.)
 #ifndef P25_NTT_FACTOR_LOG
 #define P25_NTT_FACTOR_LOG 16
 #endif
@@ -91,9 +88,12 @@ __device__ __forceinline__ void dif16_group(u64* col, const u64* wl, int step, i
   for (int k = 0; k < 16; k++) col[k * step] = x[k];
 }
 
-template <bool INV, int NTH>
+// PRE: how the input is pre-scaled -- 0 not at all, 1 by one table entry per element (a.pre), 2 by the product of two
+// factor-table entries (a.pre_t, a.pre_i).  A template parameter: as run-time branches in the load loop the three forms
+// cost the fib-64 shapes 8 % of the kernel (iNTT + LDE of 135 columns 0.95 -> 1.03 ms, round 4).
+template <bool INV, int NTH, int PRE>
 __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
-  P25_WAVE_PRIO(P25_NTT_PRIO_LOAD);   // the load phase: its waves' requests should leave before a sibling block's butterflies
+  P25_WAVE_PRIO(P25_PRIO_BULK);
   extern __shared__ u64 lds[];
   const int R = 1 << a.log_r, T = 1 << a.log_t;
   const int TP = T > 1 ? T + 1 : 1;  // row padding: conflict-free for both access directions
@@ -125,12 +125,12 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
   for (int k = tid; k < (a.full_table ? R : R / 2); k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
 
   // coset pre-scale: one table entry per input coefficient (shift_c^k at the coefficient's address k) ...
-  const u64* pre = a.pre ? a.pre + ((size_t)coset << (a.log_r + a.log_nt)) : nullptr;
+  const u64* pre = PRE == 1 ? a.pre + ((size_t)coset << (a.log_r + a.log_nt)) : nullptr;
   // ... or its two factors shift_c^t * (shift_c^NT)^i when N is too large for the table to live in L2 (2^19-row circuits:
   // 8 cosets x 4 MB, re-fetched for every polynomial).  A lane's elements all have the same t (the block size is a multiple
   // of the tile width), so the t factor is loaded once; the i factors (R entries per coset) stay cached.
-  const u64* pre_i = a.pre_t ? a.pre_i + ((size_t)coset << a.log_r) : nullptr;
-  const u64 pre_tv = a.pre_t ? a.pre_t[((size_t)coset << a.log_nt) + tg0 + (tid & (T - 1))] : 1;
+  const u64* pre_i = PRE == 2 ? a.pre_i + ((size_t)coset << a.log_r) : nullptr;
+  const u64 pre_tv = PRE == 2 ? a.pre_t[((size_t)coset << a.log_nt) + tg0 + (tid & (T - 1))] : 1;
   auto in_slot = [&](int e, size_t& addr, int& slot, int& ii) {
     int t, i;
     if (a.in_kind == 0) {
@@ -162,23 +162,27 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
       int ii;
       in_slot(e + k * nth, addr, slot[k], ii);
       xv[k] = in[addr];
-      pv[k] = pre ? pre[addr] : (pre_i ? pre_i[ii] : 1);
+      if constexpr (PRE == 1) pv[k] = pre[addr];
+      else if constexpr (PRE == 2) pv[k] = pre_i[ii];
+      else pv[k] = 1;
     }
 #pragma unroll
-    for (int k = 0; k < LB; k++)
-      lds[slot[k]] = pre ? gl::mul(xv[k], pv[k]) : (pre_i ? gl::mul(gl::mul_nc(xv[k], pre_tv), pv[k]) : xv[k]);
+    for (int k = 0; k < LB; k++) {
+      if constexpr (PRE == 1) lds[slot[k]] = gl::mul(xv[k], pv[k]);
+      else if constexpr (PRE == 2) lds[slot[k]] = gl::mul(gl::mul_nc(xv[k], pre_tv), pv[k]);
+      else lds[slot[k]] = xv[k];
+    }
   }
   for (; e < T * R; e += nth) {
     size_t addr;
     int slot, ii;
     in_slot(e, addr, slot, ii);
     u64 x = in[addr];
-    if (pre) x = gl::mul(x, pre[addr]);
-    if (pre_i) x = gl::mul(gl::mul_nc(x, pre_tv), pre_i[ii]);
+    if constexpr (PRE == 1) x = gl::mul(x, pre[addr]);
+    if constexpr (PRE == 2) x = gl::mul(gl::mul_nc(x, pre_tv), pre_i[ii]);
     lds[slot] = x;
   }
   __syncthreads();
-  P25_WAVE_PRIO(P25_PRIO_BULK);
 
   // DIF network, natural in -> bit-reversed out, up to 4 stages (radix 16) per LDS round trip:
   // a work item holds the 2^g elements {base + k*stride} of one sub-transform in registers.
@@ -225,7 +229,6 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
     slot = q * TP + t;
     tw = (u32)(tg0 + t);
   };
-  P25_WAVE_PRIO(P25_NTT_PRIO_STORE);
   // the four-step twiddles (a gather from the power table) likewise eight at a time
   int eo = tid;
   if (a.use_twiddle && !a.post_t) {
@@ -276,26 +279,29 @@ void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st
   // 512 threads, so that a CU's two resident blocks still give every SIMD four waves; above 64 KB of dynamic LDS the
   // function attribute has to allow it (a workgroup may take up to 160 KB on gfx950)
   const bool wide = p.log_r + p.log_t >= 13;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    const int cap = 160 * 1024;
-    P25_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    P25_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    P25_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    P25_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    attr_set = true;
+  const int pre_mode = q.pre ? 1 : (q.pre_t ? 2 : 0);
+  auto launch = [&](auto kernel, int nth) {
+    if (lds > 64 * 1024) {   // above 64 KB of dynamic LDS the function attribute has to allow it (160 KB per workgroup on gfx950)
+      static std::mutex mu;
+      static std::set<const void*> allowed;
+      std::lock_guard<std::mutex> lk(mu);
+      if (allowed.insert((const void*)kernel).second)
+        P25_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(nth), lds, st, q);
+  };
+#define P25_NTT_LAUNCH(INV, NTH)                                                            \
+  switch (pre_mode) {                                                                       \
+    case 1: launch(k_ntt_tile<INV, NTH, 1>, NTH); break;                                    \
+    case 2: launch(k_ntt_tile<INV, NTH, 2>, NTH); break;                                    \
+    default: launch(k_ntt_tile<INV, NTH, 0>, NTH); break;                                   \
   }
   if (wide) {
-    if (q.inverse)
-      hipLaunchKernelGGL((k_ntt_tile<true, 512>), grid, dim3(512), lds, st, q);
-    else
-      hipLaunchKernelGGL((k_ntt_tile<false, 512>), grid, dim3(512), lds, st, q);
+    if (q.inverse) { P25_NTT_LAUNCH(true, 512) } else { P25_NTT_LAUNCH(false, 512) }
   } else {
-    if (q.inverse)
-      hipLaunchKernelGGL((k_ntt_tile<true, 256>), grid, dim3(256), lds, st, q);
-    else
-      hipLaunchKernelGGL((k_ntt_tile<false, 256>), grid, dim3(256), lds, st, q);
+    if (q.inverse) { P25_NTT_LAUNCH(true, 256) } else { P25_NTT_LAUNCH(false, 256) }
   }
+#undef P25_NTT_LAUNCH
 }
 
 // Tile width.  A pass whose tile is STRIDED in memory (kind 0: T adjacent words per row of the tile, rows NT words

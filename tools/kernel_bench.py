@@ -9,7 +9,10 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 import __graft_entry__ as ge
 from oracle_binding import splitmix_field
-p25 = ge.load_package(); p25.device_init(0)
+p25 = ge.load_package()
+if "--lib" in sys.argv:   # A/B builds only (tools/variants.sh): an explicit path, never an environment variable
+    sys.modules["plonky25_amd.binding"].lib_path = sys.argv[sys.argv.index("--lib") + 1]
+p25.device_init(0)
 lib = p25.lib()
 from plonky25_amd.binding import _check as check
 dev = torch.device("cuda", 0)
