@@ -207,3 +207,56 @@ def test_aggregation_tree_of_four_fib64_proofs(gpu, oracle, fib_circuit, fib_inp
     bad = np.concatenate([l1[0], l1[1]])
     bad[77] = (int(bad[77]) + 1) % P
     assert agg2.prove(bad, seeds=[1])[1].tolist() == [4]
+
+
+def test_device_tree_chained_on_the_device_equals_the_host_fold(gpu, oracle):
+    """plonky25_amd.aggregate.DeviceTree -- aggregation levels proving straight on the buffer the level below writes,
+    ordered by p25_circuit_mark / p25_circuit_wait_mark, level l lagged l steps, nothing synchronised in between -- gives,
+    for every step, byte for byte the root the host-side fold of the same leaves gives (same circuits, same seeds), and
+    the root commits to the leaves.  Three steps through a two-level tree: buffer slots are reused."""
+    import torch
+    from plonky25_amd import aggregate as ag
+    leaf = gpu.Circuit.build_gadget(0, 0)                      # and(x, y): 2^4 rows; its aggregators: 2^12, 2^13 rows
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    n_leaves, steps = 4, 4
+    pw = int(leaf.info.proof_words)
+    inputs = []
+    for s in range(steps):
+        xs = rng.integers(0, P, size=(n_leaves, 2), dtype=np.uint64)
+        inputs.append(np.stack([np.array([int(a), int(b), (int(a) & int(b)) % P], dtype=np.uint64) for a, b in xs]))
+    tree = ag.DeviceTree(leaf, n_leaves, 2, dev, level_streams=(2, 1))
+    assert [L["n"] for L in tree.levels] == [2, 1] and tree.slots == 4
+    d_in = [torch.from_numpy(x.view(np.int64)).to(dev) for x in inputs]
+    d_seeds = torch.arange(n_leaves, dtype=torch.int64, device=dev)
+    d_st = torch.zeros((steps, n_leaves), dtype=torch.int32, device=dev)
+
+    def leaves(buf, j):
+        leaf.prove_dev(d_in[j].data_ptr(), n_leaves, d_seeds.data_ptr(), buf.data_ptr(), pw, d_st[j].data_ptr())
+
+    roots = {}
+    for j in range(steps):
+        tree.step(leaves)
+    tree.flush()
+    tree.sync()
+    torch.cuda.synchronize()
+    assert int((d_st != 0).sum().item()) == 0
+    for j in range(steps - tree.slots, steps):
+        if j >= 0:
+            roots[j] = tree.root(j)
+    # the host-side fold of the same leaves: same aggregation circuits, same seeds -> the same bytes
+    for j, (root, ok) in roots.items():
+        assert ok, j
+        lp, st = leaf.prove(inputs[j], seeds=np.arange(n_leaves, dtype=np.uint64))
+        assert st.tolist() == [0] * n_leaves
+        assert (tree.leaf_proofs(j).cpu().numpy().view(np.uint64)[:n_leaves] == lp).all(), j
+        f = ag.fold(leaf, [lp[i] for i in range(n_leaves)], arity=2, warm=False)
+        assert (f["root"] == root).all(), f"step {j}: the device-chained root differs from the host fold's"
+        want = ag.expected_commitment([lp[i][:ag.CAP_WORDS] for i in range(n_leaves)], 2, oracle.hash_no_pad)
+        assert [int(v) for v in tree.top.public_inputs(root)] == want
+        oc = oracle.load_circuit(f["top"].to_blob())
+        dg, cap = f["top"].digest()
+        assert oc.verify(root, dg, cap)[0] == 0
+        for c in f["owned"]:
+            c.close()
+    tree.close()
