@@ -318,6 +318,10 @@ static int pick_log_t(int log_r, int log_nt, bool strided) {
         lt = w;
         break;
       }
+  // 1024-point contiguous passes (pass 2 of 2^19- and 2^20-point transforms): 2^12-element tiles take 49 KB, three blocks of
+  // four waves per CU; 8-wide tiles of 512 threads take 80 KB, two blocks of eight waves -- four waves per SIMD instead of
+  // three to overlap the load, butterfly and store phases.  Config 5: 16.3-16.7 -> 16.8 proofs/s (profiles/r04_ab_config5_ntt.txt).
+  if (!strided && log_r == 10) lt = 3;
   if (lt > 4) lt = 4;
   if (lt > log_nt) lt = log_nt;
   if (lt < 0) lt = 0;
