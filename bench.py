@@ -560,13 +560,18 @@ def main():
             if fn.endswith((".hip", ".h", ".inc")):
                 hh.update(open(os.path.join(csrc, fn), "rb").read())
         csrc_sha = hh.hexdigest()[:16]
-        try:
-            clock_hz = p25.shader_clock_hz()     # measured in this run, under a full-chip Poseidon load
-        except Exception:
-            clock_hz = 0.0
+        clock_hz, clock_err = 0.0, ""
+        for _attempt in range(3):                # measured in this run, under a full-chip Poseidon load
+            try:
+                clock_hz = p25.shader_clock_hz()
+            except Exception as e:
+                clock_hz, clock_err = 0.0, str(e)[:120]
+            if 1.0e9 < clock_hz < 3.5e9:
+                break
+            clock_err = clock_err or f"implausible reading {clock_hz:.3g} Hz"
         clock_note = "measured in this run (in-kernel cycle counter vs the constant-rate wall clock, full-chip Poseidon load)"
         if not (1.0e9 < clock_hz < 3.5e9):
-            clock_hz, clock_note = NOMINAL_CLOCK_HZ, "nominal (the in-run measurement failed)"
+            clock_hz, clock_note = NOMINAL_CLOCK_HZ, f"nominal (the in-run measurement failed three times: {clock_err})"
         # only a PMC pass collected for exactly these kernel sources counts (tools/pmc_summary.py writes _meta.csrc_sha)
         vp, per_kernel = "", None
         for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_SQ_INSTS_VALU.json")), reverse=True):
