@@ -130,3 +130,34 @@ def test_openings_vs_oracle(gpu, oracle, log_n, n_polys):
         got = gpu.eval_polys(coeffs, zeta, scale)
         want = oracle.eval_polys(coeffs, zeta, scale)
         assert (got == want).all(), (log_n, scale)
+
+
+def test_mark_and_wait_mark_argument_checks(gpu, small):
+    """The event-ordering entry points refuse what cannot be right (status codes, never UB): slots beyond 0..7, a circuit
+    waiting for its own mark (its streams are already in order), null handles."""
+    c, _oc, _wires = small
+    other = gpu.Circuit.build_gadget(0, 0)
+    for slot in (8, 1 << 20):
+        with pytest.raises(gpu.P25Error) as e:
+            c.mark(slot)
+        assert e.value.status == 1
+        with pytest.raises(gpu.P25Error):
+            other.wait_mark(c, slot)
+        with pytest.raises(gpu.P25Error):
+            c.stream_wait_mark(slot, 0)
+    with pytest.raises(gpu.P25Error) as e:
+        c.wait_mark(c, 0)
+    assert e.value.status == 1
+    lib = gpu.lib()
+    assert lib.p25_circuit_mark(None, 0) == 1 and lib.p25_circuit_wait_mark(None, None, 0) == 1
+    assert lib.p25_circuit_stream_join(None, None) == 1 and lib.p25_circuit_wait_stream(None, None) == 1
+    # a mark nobody has taken yet is nothing to wait for; marks and waits on the legacy default stream are accepted
+    other.wait_mark(c, 3)
+    c.mark(3)
+    other.wait_mark(c, 3)
+    c.stream_wait_mark(3, 0)
+    c.stream_join(0)
+    c.wait_stream(0)
+    c.sync()
+    other.sync()
+    other.close()
