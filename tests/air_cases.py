@@ -66,3 +66,56 @@ def squares_trace(log_n, seed=1):
         x = (x + 3) % P
     t[n - 1, 2] = t[n - 1, 0]
     return t
+
+
+def random_recurrence(p25, seed, width):
+    """A seeded FAMILY of AIRs of any width (docs/DEVELOPER-GUIDE.md's recipe, generated): column j of the next row is
+    b_j * local[r_j] + c_j with random r_j, b_j, c_j (a transition constraint per column), the first row is pinned to
+    random constants.  Returns (air, coefficients); random_recurrence_trace builds the trace from the coefficients."""
+    rng = np.random.default_rng(seed)
+    air = p25.Air(width)
+    coef = []
+    for j in range(width):
+        rj = int(rng.integers(0, width))
+        bj, cj, first = (int(v) for v in rng.integers(1, P, size=3, dtype=np.uint64))
+        coef.append((rj, bj, cj, first))
+        air.when_first_row(air.sub(air.local(j), air.const(first)))
+        air.when_transition(air.sub(air.next(j), air.add(air.mul(air.const(bj), air.local(rj)), air.const(cj))))
+    return air, coef
+
+
+def random_recurrence_trace(coef, log_n):
+    n, width = 1 << log_n, len(coef)
+    t = np.zeros((n, width), dtype=np.uint64)
+    row = [c[3] for c in coef]
+    for i in range(n):
+        t[i] = row
+        row = [(c[1] * row[c[0]] + c[2]) % P for c in coef]
+    return t
+
+
+def quadratic_pair(p25, seed):
+    """width 4, seeded: (x, y) evolve linearly with random coefficients, s = x * y and u = (x + y) * (x + k) hold on EVERY
+    row (degree-2 always-constraints).  Exercises two independent quadratic constraints with random constants through
+    the verifier circuit's constraint folding."""
+    rng = np.random.default_rng(seed)
+    a, b, c, d, e, f, k, x0, y0 = (int(v) for v in rng.integers(1, P, size=9, dtype=np.uint64))
+    air = p25.Air(4)
+    x, y, s, u = (air.local(i) for i in range(4))
+    air.assert_zero(air.sub(air.mul(x, y), s))
+    air.assert_zero(air.sub(air.mul(air.add(x, y), air.add(x, air.const(k))), u))
+    air.when_first_row(air.sub(x, air.const(x0)))
+    air.when_first_row(air.sub(y, air.const(y0)))
+    air.when_transition(air.sub(air.next(0), air.add(air.add(air.mul(air.const(a), x), air.mul(air.const(b), y)), air.const(c))))
+    air.when_transition(air.sub(air.next(1), air.add(air.add(air.mul(air.const(d), x), air.mul(air.const(e), y)), air.const(f))))
+    return air, (a, b, c, d, e, f, k, x0, y0)
+
+
+def quadratic_pair_trace(par, log_n):
+    a, b, c, d, e, f, k, x, y = par
+    n = 1 << log_n
+    t = np.zeros((n, 4), dtype=np.uint64)
+    for i in range(n):
+        t[i] = (x, y, x * y % P, (x + y) * (x + k) % P)
+        x, y = (a * x + b * y + c) % P, (d * x + e * y + f) % P
+    return t

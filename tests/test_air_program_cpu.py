@@ -50,6 +50,34 @@ def test_user_air_accepted_by_its_verifier_circuit(p25, oracle, name, log_n):
         assert fc.witness(inp, seed=3)[1] == 4
 
 
+@pytest.mark.parametrize("family,seed,arg", [("random_recurrence", 1, 2), ("random_recurrence", 2, 5), ("random_recurrence", 4, 12),
+                                             ("quadratic_pair", 11, None), ("quadratic_pair", 13, None)])
+def test_seeded_air_families_accepted_by_their_verifier_circuits(p25, oracle, family, seed, arg):
+    """Beyond hand-picked AIRs: seeded families (tests/air_cases.py) through the native plonky3 prover and the
+    verifier-circuit builder; the circuit's witness exists and satisfies every constraint, a violating trace cannot be
+    proved, a tampered proof has no witness."""
+    if family == "random_recurrence":
+        air, coef = air_cases.random_recurrence(p25, seed, arg)
+        trace = air_cases.random_recurrence_trace(coef, 4)
+    else:
+        air, par = air_cases.quadratic_pair(p25, seed)
+        trace = air_cases.quadratic_pair_trace(par, 4)
+    inp, cfg = p25.p3_prove_air(air, trace, num_queries=5, pow_bits=4)
+    c = p25.Circuit.build_p3_verifier_air(cfg, air)
+    oc = oracle.load_circuit(c.to_blob())
+    wires, st, msg = oc.witness(inp, seed=2)
+    assert st == 0, msg
+    bad, msg = oc.check_constraints(wires)
+    assert bad == 0, msg
+    t = inp.copy()
+    t[8] = (int(t[8]) + 1) % P
+    assert oc.witness(t, seed=2)[1] == 4
+    wrong = trace.copy()
+    wrong[3, air.width - 1] = (int(wrong[3, air.width - 1]) + 1) % P
+    with pytest.raises(p25.P25Error):
+        p25.p3_prove_air(air, wrong, num_queries=5, pow_bits=4)
+
+
 def test_violating_trace_cannot_be_proved(p25):
     air = air_cases.tribonacci(p25)
     trace = air_cases.tribonacci_trace(4)

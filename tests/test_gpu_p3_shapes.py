@@ -54,3 +54,32 @@ def test_gpu_equals_oracle_on_user_air(gpu, oracle, name, log_n):
     assert sto == 0, msg
     assert (proofs[0] == po).all()
     assert oc.verify(proofs[0], dg, capg)[0] == 0
+
+
+@pytest.mark.parametrize("family,seed,arg", [("random_recurrence", 1, 2), ("random_recurrence", 2, 5), ("random_recurrence", 3, 9),
+                                             ("quadratic_pair", 11, None), ("quadratic_pair", 12, None)])
+def test_gpu_equals_oracle_on_seeded_air_families(gpu, oracle, family, seed, arg):
+    """SURVEY.md 8f-2 beyond hand-picked AIRs: seeded families -- linear recurrences of widths 2, 5, 9 with random
+    coefficients, pairs of quadratic always-constraints with random constants -- through the native plonky3 prover, the
+    verifier-circuit builder and the GPU prover: digest and proof bytes equal the oracle's, a tampered input has no witness."""
+    import air_cases
+    if family == "random_recurrence":
+        air, coef = air_cases.random_recurrence(gpu, seed, arg)
+        trace = air_cases.random_recurrence_trace(coef, 4)
+    else:
+        air, par = air_cases.quadratic_pair(gpu, seed)
+        trace = air_cases.quadratic_pair_trace(par, 5)
+    inp, cfg = gpu.p3_prove_air(air, trace, num_queries=10, pow_bits=6)
+    c = gpu.Circuit.build_p3_verifier_air(cfg, air)
+    oc = oracle.load_circuit(c.to_blob())
+    dg, capg = c.digest()
+    do, capo = oc.digest()
+    assert (dg == do).all() and (capg == capo).all()
+    bad = inp.copy()
+    bad[inp.size // 2] = (int(bad[inp.size // 2]) + 1) % 0xFFFFFFFF00000001
+    proofs, st = c.prove(np.stack([inp, bad]), seeds=[5, 6])
+    assert st[0] == 0 and st[1] != 0
+    po, sto, _tm, msg = oc.prove(inp, seed=5)
+    assert sto == 0, msg
+    assert (proofs[0] == po).all()
+    assert oc.verify(proofs[0], dg, capg)[0] == 0
