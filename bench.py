@@ -311,7 +311,7 @@ def main():
     else:
         B, n_step_total = args.batch, args.batch * world
         g_start = rank * B
-    ni, pw = int(info.num_inputs), int(info.proof_words)
+    pw = int(info.proof_words)
     host_in = np.stack([variants[(g_start + i) % len(variants)] for i in range(max(B, 1))])[:B]
     host_seeds = np.arange(B, dtype=np.uint64) + np.uint64(g_start)                          # distinct filler seeds
     d_inputs = torch.from_numpy(host_in.view(np.int64)).to(dev)                            # [B][ni]
@@ -771,7 +771,7 @@ def main():
             oc.digest()  # constants/sigmas commitment is per-circuit, excluded like the reference's build()
             model = cpu_model()
             # (i) BASELINE config 1: the reference's prover is single-threaded (Cargo.toml:15-18 no `parallel`)
-            pr1, st1, per1, wall1 = oc.prove_many(inputs[None, :], np.array([0], dtype=np.uint64), threads=1,
+            pr1, st1, _per1, wall1 = oc.prove_many(inputs[None, :], np.array([0], dtype=np.uint64), threads=1,
                                                   want_proofs=True)
             bit_exact = bool(gpu_proof0 is not None and (pr1[0] == gpu_proof0).all())
             cb = {"value": 1.0 / wall1, "unit": "proofs/s", "cores": 1, "kind": "port", "cpu": model,
