@@ -462,8 +462,19 @@ def main():
         n_agg = int(na_t.item())
     n_agg = pagg.largest_pow2(n_agg) if n_agg >= 1 else 0
     if n_agg * world >= 2 and ok:
-        agg_state = pagg.fold_sharded(circuit, last[:n_agg].cpu().numpy().view(np.uint64), args.aggregate_arity, cdev,
-                                      distributed)
+        local_leaves = last[:n_agg].cpu().numpy().view(np.uint64)
+        agg_state = pagg.fold_sharded(circuit, local_leaves, args.aggregate_arity, cdev, distributed)
+        # ... and what a level-1 aggregate proof costs the machine with enough of them in flight (rank 0 only, no collective)
+        f0 = agg_state.get("fold")
+        if rank == 0 and f0 and f0["owned"] and n_agg >= f0["levels"][0]["arity"]:
+            try:
+                k1 = f0["levels"][0]["arity"]
+                rate1 = pagg.circuit_throughput(f0["owned"][0], np.concatenate([local_leaves[i] for i in range(k1)]), dev)
+                agg_state["level1_throughput"] = {"aggregate_proofs_per_s": round(rate1, 2), "ms_per_aggregate_proof": round(1e3 / rate1, 3),
+                                                  "batch": 64, "steps": 2,
+                                                  "note": "the level-1 aggregation circuit by itself, 16 proofs in flight, steps enqueued back to back"}
+            except Exception as e:
+                agg_state["level1_throughput"] = {"error": str(e)[:200]}
 
     # --- the same tree PIPELINED: device-resident, enqueue-only, lagged one step per level -----------------------------
     # What a production batch prover runs: every step = B leaf proofs + one instance of every level of the aggregation
@@ -708,7 +719,8 @@ def main():
                     leaf_s = leaves / (total_proofs / elapsed)   # the leaves at the measured whole-job rate
                     out["aggregation"] = {
                         "leaves": leaves, "leaves_per_rank": agg_state["leaves_per_rank"], "ranks": world,
-                        "levels": f["levels"] + fin["levels"], "root_public_inputs": root_pis,
+                        "levels": f["levels"] + fin["levels"], "level1_throughput": agg_state.get("level1_throughput"),
+                        "root_public_inputs": root_pis,
                         "root_public_inputs_commit_to_the_leaves": root_pis == want,
                         "shard_tree_prove_s_max_over_ranks": round(agg_state["tree_s_max"], 4),
                         "roots_gather_ms": round(agg_state["roots_gather_ms"], 3),

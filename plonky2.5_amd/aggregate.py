@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-__all__ = ["fold", "fold_roots", "fold_sharded", "DeviceTree", "expected_commitment", "leaf_identifier_words", "largest_pow2"]
+__all__ = ["fold", "fold_roots", "fold_sharded", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "largest_pow2"]
 
 CAP_WORDS = 64   # wires cap = the first 2^cap_height x 4 words of a flat proof (cap_height 4, include/p25.h proof layout)
 
@@ -162,6 +162,31 @@ def fold_sharded(circuit, local_leaves, arity, cdev, distributed):
             state["error"] = str(e)[:300]
     state.update({"caps": caps, "tree_s_max": tree_s_max, "roots_gather_ms": gather_ms})
     return state
+
+
+def circuit_throughput(circ, input_row, device, count=64, steps=2):
+    """Proofs/s of `circ` BY ITSELF in its throughput form: `count` proofs of the same inputs per step (distinct filler
+    seeds), `steps` steps enqueued back to back after one warm-up step, one synchronisation at the end -- what one proof
+    of this circuit costs the machine when enough of them are in flight (an aggregation level in isolation)."""
+    import torch
+    pw = int(circ.info.proof_words)
+    d_in = torch.from_numpy(np.stack([np.asarray(input_row, dtype=np.uint64)] * count).view(np.int64)).to(device)
+    d_seeds = torch.arange(count, dtype=torch.int64, device=device)
+    d_p = torch.zeros((count, pw), dtype=torch.int64, device=device)
+    d_s = torch.zeros((steps + 1, count), dtype=torch.int32, device=device)
+    t0 = 0.0
+    for k in range(steps + 1):
+        if k == 1:
+            circ.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        circ.prove_dev(d_in.data_ptr(), count, d_seeds.data_ptr(), d_p.data_ptr(), pw, d_s[k].data_ptr())
+    circ.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if int((d_s != 0).sum().item()) != 0:
+        raise RuntimeError("circuit_throughput: a proof failed")
+    return count * steps / dt
 
 
 class DeviceTree:
