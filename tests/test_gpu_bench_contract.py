@@ -42,6 +42,11 @@ def test_bench_json_contract():
     assert ag["leaves"] == 4 and [l["arity"] for l in ag["levels"]] == [2, 2] and ag["oracle_verifier_accepts_root"] is True
     assert len(ag["root_public_inputs"]) == 4 and ag["root_public_inputs_commit_to_the_leaves"] is True
     assert ag["leaf_equivalent_proofs_per_s_including_aggregation"] > 0
+    assert ag["level1_throughput"]["aggregate_proofs_per_s"] > 0          # the level-1 aggregation circuit by itself
+    # ... and the same tree resident on the device, pipelined under the leaves (16 leaves, arity 2: four levels)
+    pl = ag["pipelined"]
+    assert pl["leaf_equivalent_proofs_per_s"] > 0 and pl["all_statuses_ok"] and pl["oracle_verifier_accepts_root"]
+    assert pl["root_public_inputs_commit_to_the_leaves"] is True and [l["proofs"] for l in pl["levels"]] == [8, 4, 2, 1]
     # VALU view: priced with the clock measured in the run, and only from a PMC pass of these very kernel sources
     v = rf["valu"]
     assert 1.0e9 < v["shader_clock_hz"] < 3.5e9 and ("stale" in v or v["csrc_sha"])
