@@ -23,3 +23,20 @@ def test_c_client(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "C CLIENT OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_c_client_chains_two_circuits_on_the_device(tmp_path):
+    """tests/c_abi/chain.c: leaf proofs -> aggregation circuit through device buffers, ordered by p25_circuit_mark /
+    p25_circuit_wait_mark, from plain C (HIP runtime for the buffers only): byte-equal to the host-buffer path."""
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    libdir = os.path.join(ROOT, "plonky2.5_amd")
+    exe = str(tmp_path / "c_chain")
+    r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-D__HIP_PLATFORM_AMD__",
+                        "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "chain.c"),
+                        "-L" + libdir, "-lp25", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                        "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "C CHAIN OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
