@@ -177,6 +177,58 @@ def test_host_threads_share_one_circuit(gpu, oracle):
         c.set_streams(0)
 
 
+def test_read_only_entry_points_race_the_first_device_use(gpu, oracle):
+    """the first prove() moves the host tables into the device circuit; info(), to_blob(), gate_counts(),
+    input_target_indices() and the proof formats read those tables.  They take the circuit's lock now: hammering them
+    from three threads while a fourth makes the circuit's FIRST device call neither crashes nor reads moved-from
+    tables (every blob equals the one taken before, every info the same), and the proof equals the oracle's."""
+    import threading
+    from gadget_cases import cases
+    name, kind, param, vals = [c for c in cases(oracle) if c[0] == "compress"][0]
+    inp = np.array(vals, dtype=np.uint64)
+    for trial in range(3):
+        c = gpu.Circuit.build_gadget(kind, param)        # fresh: no device state yet
+        blob0 = c.to_blob()
+        errors, stop, out = [], threading.Event(), {}
+
+        def reader(which):
+            try:
+                while not stop.is_set():
+                    if which == 0:
+                        assert c.to_blob() == blob0
+                    elif which == 1:
+                        i = c.info
+                        assert int(i.degree_bits) >= 4 and int(i.num_wires) == 135 and int(i.witness_slots) > 0
+                        assert sum(c.gate_counts().values()) == 1 << int(i.degree_bits)
+                    else:
+                        assert len(c.input_target_indices()) == inp.size
+            except Exception as e:
+                errors.append(repr(e))
+
+        def prover():
+            try:
+                out["p"] = c.prove(inp[None, :], seeds=[trial])
+            except Exception as e:
+                errors.append(repr(e))
+
+        readers = [threading.Thread(target=reader, args=(k,)) for k in range(3)]
+        for t in readers:
+            t.start()
+        pt = threading.Thread(target=prover)
+        pt.start()
+        pt.join()
+        stop.set()
+        for t in readers:
+            t.join()
+        assert not errors, errors
+        proofs, st = out["p"]
+        assert st.tolist() == [0]
+        po, sto, _t, msg = oracle.load_circuit(blob0).prove(inp, seed=trial)
+        assert sto == 0 and (proofs[0] == po).all()
+        assert c.proof_from_bytes(c.proof_to_bytes(proofs[0])).tolist() == proofs[0].tolist()
+        c.close()
+
+
 def test_circuit_create_destroy_does_not_leak_device_memory(gpu):
     import torch
     inp, cfg = gpu.p3_prove_fibonacci(3, 3, 4)
