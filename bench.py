@@ -760,8 +760,9 @@ def main():
                         "leaf_equivalent_proofs_per_s": round(rate, 2), "fraction_of_unaggregated_rate": round(rate / (total_proofs / elapsed), 4),
                         "steps": pipe["steps"], "ms_per_step": round(pipe["elapsed"] / pipe["steps"] * 1e3, 1),
                         # what an aggregate proof costs the machine: the step's extra time over its leaves at the un-aggregated rate
-                        "machine_ms_per_aggregate_proof": round((pipe["elapsed"] / pipe["steps"] - B / (total_proofs / elapsed / world))
-                                                                * 1e3 / max(1, tree.aggregates_per_step), 2),
+                        # (None when the un-aggregated steps were slower than the pipelined ones: the gloo TEST MODE, whose gather blocks the host)
+                        "machine_ms_per_aggregate_proof": (lambda x: round(x, 2) if x > 0 else None)(
+                            (pipe["elapsed"] / pipe["steps"] - B / (total_proofs / elapsed / world)) * 1e3 / max(1, tree.aggregates_per_step)),
                         "leaf_proofs_per_rank_per_step": B, "leaves_folded_per_rank_per_step": pipe["leaves"],
                         "aggregate_proofs_per_rank_per_step": tree.aggregates_per_step, "proofs_of_any_kind_per_rank_per_step": B - pipe["leaves"] + per_step,
                         "levels": [{"arity": L["k"], "proofs": L["n"], "circuit_rows_log2": int(L["circ"].info.degree_bits)}
