@@ -260,3 +260,43 @@ def test_device_tree_chained_on_the_device_equals_the_host_fold(gpu, oracle):
         for c in f["owned"]:
             c.close()
     tree.close()
+
+
+def test_device_tree_a_failed_leaf_fails_its_branch_only(gpu):
+    """A leaf whose witness does not exist (P25_ERR_WITNESS_CONFLICT) leaves no valid proof in the buffer: the aggregate
+    above it must fail too (its status says so -- never a root that looks valid), while the other steps in flight through
+    the same buffers are untouched."""
+    import torch
+    from plonky25_amd import aggregate as ag
+    leaf = gpu.Circuit.build_gadget(0, 0)
+    dev = torch.device("cuda", 0)
+    n_leaves, steps, bad_step = 4, 3, 1
+    pw = int(leaf.info.proof_words)
+    rng = np.random.default_rng(7)
+    d_in = []
+    for s in range(steps):
+        xs = rng.integers(0, P, size=(n_leaves, 2), dtype=np.uint64)
+        rows = np.stack([np.array([int(a), int(b), (int(a) & int(b)) % P], dtype=np.uint64) for a, b in xs])
+        if s == bad_step:
+            rows[2, 2] = (int(rows[2, 2]) + 1) % P          # and(x, y) != expected: no witness for leaf 2 of this step
+        d_in.append(torch.from_numpy(rows.view(np.int64)).to(dev))
+    tree = ag.DeviceTree(leaf, n_leaves, 2, dev, level_streams=(2, 1))
+    d_seeds = torch.arange(n_leaves, dtype=torch.int64, device=dev)
+    d_st = torch.zeros((steps, n_leaves), dtype=torch.int32, device=dev)
+
+    def leaves(buf, j):
+        leaf.prove_dev(d_in[j].data_ptr(), n_leaves, d_seeds.data_ptr(), buf.data_ptr(), pw, d_st[j].data_ptr())
+
+    for _ in range(steps):
+        tree.step(leaves)
+    tree.flush()
+    tree.sync()
+    torch.cuda.synchronize()
+    st = d_st.cpu().numpy()
+    assert st[bad_step].tolist() == [0, 0, 4, 0] and (st[[0, 2]] == 0).all()
+    for j in range(steps):
+        _root, ok = tree.root(j)
+        assert ok == (j != bad_step), j
+    l1 = tree.levels[0]["status"][bad_step % tree.slots].cpu().numpy()
+    assert l1[0] == 0 and l1[1] != 0                       # only the aggregate over leaves 2, 3 failed at level 1
+    tree.close()
