@@ -213,13 +213,13 @@ def test_device_tree_chained_on_the_device_equals_the_host_fold(gpu, oracle):
     """plonky25_amd.aggregate.DeviceTree -- aggregation levels proving straight on the buffer the level below writes,
     ordered by p25_circuit_mark / p25_circuit_wait_mark, level l lagged l steps, nothing synchronised in between -- gives,
     for every step, byte for byte the root the host-side fold of the same leaves gives (same circuits, same seeds), and
-    the root commits to the leaves.  Three steps through a two-level tree: buffer slots are reused."""
+    the root commits to the leaves.  Seven steps through a two-level tree with four buffer slots: slots are reused."""
     import torch
     from plonky25_amd import aggregate as ag
     leaf = gpu.Circuit.build_gadget(0, 0)                      # and(x, y): 2^4 rows; its aggregators: 2^12, 2^13 rows
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(99)
-    n_leaves, steps = 4, 4
+    n_leaves, steps = 4, 7          # slots = 4: steps 4..6 reuse buffers, so the reader-has-finished waits execute
     pw = int(leaf.info.proof_words)
     inputs = []
     for s in range(steps):
