@@ -483,6 +483,7 @@ def main():
                                                   "note": "the level-1 aggregation circuit by itself, 16 proofs in flight, steps enqueued back to back"}
             except Exception as e:
                 agg_state["level1_throughput"] = {"error": str(e)[:200]}
+        pagg.release_fold(agg_state)     # the checker's data kept, the fold's circuits (tens of GB of working sets) closed
 
     # --- the same tree PIPELINED: device-resident, enqueue-only, lagged one step per level -----------------------------
     # What a production batch prover runs: every step = B leaf proofs + one instance of every level of the aggregation
@@ -718,23 +719,23 @@ def main():
                 out["aggregation"] = {"error": agg_state["error"]}
             else:
                 try:
-                    f, fin = agg_state["fold"], agg_state["final"]
-                    root, top = fin["root"], fin["top"]
-                    root_pis = [int(v) for v in top.public_inputs(root)]
+                    ck = agg_state["checker"]
+                    root, root_pis = ck["root"], ck["root_public_inputs"]
                     want = pagg.expected_commitment(list(agg_state["caps"]), args.aggregate_arity, ora.hash_no_pad, n_shards=world)
                     leaves = agg_state["leaves_per_rank"] * world
-                    tree_total = agg_state["tree_s_max"] + agg_state["roots_gather_ms"] * 1e-3 + fin["tree_s"]
+                    tree_total = agg_state["tree_s_max"] + agg_state["roots_gather_ms"] * 1e-3 + ck["final_tree_s"]
                     leaf_s = leaves / (total_proofs / elapsed)   # the leaves at the measured whole-job rate
+                    root_ok = ora.load_circuit(ck["top_blob"]).verify(root, ck["digest"], ck["cap"])[0] == 0
                     out["aggregation"] = {
                         "leaves": leaves, "leaves_per_rank": agg_state["leaves_per_rank"], "ranks": world,
-                        "levels": f["levels"] + fin["levels"], "level1_throughput": agg_state.get("level1_throughput"),
+                        "levels": ck["levels"], "level1_throughput": agg_state.get("level1_throughput"),
                         "root_public_inputs": root_pis,
                         "root_public_inputs_commit_to_the_leaves": root_pis == want,
                         "shard_tree_prove_s_max_over_ranks": round(agg_state["tree_s_max"], 4),
                         "roots_gather_ms": round(agg_state["roots_gather_ms"], 3),
-                        "cross_rank_prove_s": round(fin["tree_s"], 4), "tree_prove_s": round(tree_total, 4),
-                        "tree_circuit_build_s_once_per_shape": round(f["build_s"] + fin["build_s"], 2),
-                        "root_proof_words": int(root.size), "oracle_verifier_accepts_root": bool(verify_with_oracle(top, root)),
+                        "cross_rank_prove_s": round(ck["final_tree_s"], 4), "tree_prove_s": round(tree_total, 4),
+                        "tree_circuit_build_s_once_per_shape": round(ck["build_s"], 2),
+                        "root_proof_words": int(root.size), "oracle_verifier_accepts_root": bool(root_ok),
                         "leaf_prove_s_at_measured_rate": round(leaf_s, 4),
                         "leaf_equivalent_proofs_per_s_including_aggregation": round(leaves / (leaf_s + tree_total), 2),
                         "note": "every rank folds the first proofs of its last timed step to one root on its own GPU (levels "
@@ -742,8 +743,6 @@ def main():
                                 "gathered over RCCL and rank 0 proves one N-to-1 aggregate on top; every level is an aggregation "
                                 "circuit (recursive verifier of its children + 4 public inputs committing to them); circuit "
                                 "builds are once per shape and excluded like the reference's build()"}
-                    for c in f["owned"] + fin["owned"]:
-                        c.close()
                 except Exception as e:  # never lose the headline line to the optional block
                     out["aggregation"] = {"error": str(e)[:300]}
         if pipe is not None and isinstance(out.get("aggregation"), dict):

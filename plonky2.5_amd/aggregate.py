@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-__all__ = ["fold", "fold_roots", "fold_sharded", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "largest_pow2"]
+__all__ = ["fold", "fold_roots", "fold_sharded", "release_fold", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "largest_pow2"]
 
 CAP_WORDS = 64   # wires cap = the first 2^cap_height x 4 words of a flat proof (cap_height 4, include/p25.h proof layout)
 
@@ -161,6 +161,28 @@ def fold_sharded(circuit, local_leaves, arity, cdev, distributed):
         except Exception as e:
             state["error"] = str(e)[:300]
     state.update({"caps": caps, "tree_s_max": tree_s_max, "roots_gather_ms": gather_ms})
+    return state
+
+
+def release_fold(state):
+    """Keep what the checker needs of a fold_sharded state -- on rank 0 the final root, its circuit's blob, verifier data
+    and public inputs -- and close every aggregation circuit the fold built (their per-proof working sets are tens of GB
+    that the pipelined tree measured next should not have to share the device with)."""
+    fin = state.get("final")
+    if fin is not None:
+        top, root = fin["top"], fin["root"]
+        dg, cap = top.digest()
+        state["checker"] = {"root": root, "top_blob": top.to_blob(), "digest": dg, "cap": cap,
+                            "root_public_inputs": [int(v) for v in top.public_inputs(root)],
+                            "levels": state["fold"]["levels"] + fin["levels"], "final_tree_s": fin["tree_s"],
+                            "build_s": state["fold"]["build_s"] + fin["build_s"]}
+    owned = list((state.get("fold") or {}).get("owned", [])) + list((fin or {}).get("owned", []))
+    for c in owned:
+        c.close()
+    if state.get("fold"):
+        state["fold"]["owned"], state["fold"]["top"] = [], None
+    if fin is not None:
+        fin["owned"], fin["top"] = [], None
     return state
 
 
