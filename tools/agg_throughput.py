@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the 8-to-1 aggregation circuit BY ITSELF (batches of aggregate proofs, 16 in flight, steps enqueued back
 to back) next to the leaf circuit's, on one box: is an aggregate proof dearer than a leaf proof as a kernel mix, or only
-inside the pipelined tree?   usage: agg_throughput.py [aggregates per step = 64] [steps = 3]"""
+inside the pipelined tree?   usage: agg_throughput.py [aggregates per step = 64] [steps = 3] [--only leaf|agg]
+(--only: one circuit's timed loop alone, the form to put under rocprofv3 --kernel-trace --stats)"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +12,9 @@ import torch
 import __graft_entry__ as ge
 p25 = ge.load_package(); p25.device_init(0)
 dev = torch.device("cuda", 0)
+only = None
+if "--only" in sys.argv:
+    i = sys.argv.index("--only"); only = sys.argv[i + 1]; del sys.argv[i:i + 2]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 inputs, cfg = p25.p3_proof_from_json(open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")).read())
@@ -36,8 +40,11 @@ def rate(circ, rows, count):
 
 
 agg = leaf.build_aggregator(8)
-out = {"leaf_proofs_per_s": round(rate(leaf, inputs, 4 * n), 2)}
-out["aggregate_proofs_per_s"] = round(rate(agg, np.concatenate([lp[i] for i in range(8)]), n), 2)
-out["ms_per_leaf_proof"] = round(1e3 / out["leaf_proofs_per_s"], 3)
-out["ms_per_aggregate_proof"] = round(1e3 / out["aggregate_proofs_per_s"], 3)
+out = {}
+if only != "agg":
+    out["leaf_proofs_per_s"] = round(rate(leaf, inputs, n if only else 4 * n), 2)
+    out["ms_per_leaf_proof"] = round(1e3 / out["leaf_proofs_per_s"], 3)
+if only != "leaf":
+    out["aggregate_proofs_per_s"] = round(rate(agg, np.concatenate([lp[i] for i in range(8)]), n), 2)
+    out["ms_per_aggregate_proof"] = round(1e3 / out["aggregate_proofs_per_s"], 3)
 print(json.dumps(out))
