@@ -258,9 +258,11 @@ typedef struct {
       openings_ms, fri_ms, total_ms;
 } p25_timings;
 /* Threading: like upstream's `prove(&self)`, every entry point may be called from any host thread, also concurrently
- * on ONE p25_circuit (a Rust host with a rayon pool): a circuit owns its streams and per-proof contexts, so such
+ * on ONE p25_circuit (a Rust host with a rayon pool): a circuit owns its per-proof contexts, so such
  * calls are serialised inside the library (one mutex per circuit; use the batch forms, or one circuit per thread,
- * for parallelism).  Different circuits never contend.  With `timings` != NULL, or a batch of one, the proofs run one
+ * for parallelism).  Different circuits never contend for a lock; their proofs share the device through ONE pool of 16
+ * proving streams per process (a stream set per circuit oversubscribes the hardware queues as soon as two circuits are
+ * alive: DESIGN.md section 3).  With `timings` != NULL, or a batch of one, the proofs run one
  * at a time with latency-oriented kernel forms; otherwise up to 16 proofs are in flight (p25_circuit_set_streams). */
 p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* seeds,
                            uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status,
@@ -301,8 +303,8 @@ p25_status p25_circuit_wait_mark(p25_circuit* c, p25_circuit* producer, uint32_t
  * step k when it has enqueued it and lets the gather's side stream wait for that mark only after step k+1 has been
  * enqueued, so the wait never sits unsatisfied at the head of a hardware queue shared with a proving stream). */
 p25_status p25_circuit_stream_wait_mark(p25_circuit* c, uint32_t slot, void* stream);
-/* Proofs kept in flight by the batch entry points: one HIP stream and one per-proof working set (~1.6 GB for the
- * fib-64 circuit) each; 1..32, default 16 (12 .. 20 measure the same, 24 and more are slower).  A library setting, not an
+/* Proofs kept in flight by the batch entry points: one per-proof working set (~1.6 GB for the fib-64 circuit) and one
+ * stream of the process-wide pool each; 1..32, default 16 (12 .. 20 measure the same, 24 and more are slower).  A library setting, not an
  * environment variable. */
 p25_status p25_circuit_set_streams(p25_circuit* c, int32_t n_streams);
 /* Measurement hook for bench.py's roofline line: when enabled, HIP events on the proving stream

@@ -228,9 +228,12 @@ class DeviceTree:
 
     Buffers are `slots` = levels + 2 deep: step i uses slot i % slots; a buffer is rewritten only after the level above
     has marked that it has finished reading it.  `level_streams`: proofs kept in flight by level 1, 2, ... (the last
-    entry repeats): the tree is 1/8 of the work and runs under the leaf circuit's 16 streams."""
+    entry repeats); None = the library's 16 for every level.  All circuits of a process prove on ONE pool of 16 streams
+    (prover.hip: StreamPool), so a level's proofs are interleaved with the leaf proofs on those streams; spread over
+    all 16 (None) the tree measured 119.5-120.0 leaf-equivalent proofs/s, concentrated on 4 / 2 / 1 of them 117.1
+    (profiles/r04_stream_pool.txt)."""
 
-    def __init__(self, circuit, n_leaves, arity, device, leaf_batch=None, level_streams=(4, 2, 1)):
+    def __init__(self, circuit, n_leaves, arity, device, leaf_batch=None, level_streams=None):
         import torch
         if n_leaves < 2 or n_leaves & (n_leaves - 1):
             raise ValueError("DeviceTree needs a power-of-two number of leaves >= 2")

@@ -1,10 +1,53 @@
 // See prover.h.
 #include "prover.h"
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string.h>
 #include "poseidon.h"
 
 namespace p25 {
+
+// Proving streams come from ONE pool per device, shared by every circuit of the process.  HIP streams are multiplexed
+// onto GPU_MAX_HW_QUEUES hardware queues (24, capi.hip), and two streams in one hardware queue run in order: with a
+// stream set per circuit, a second circuit that is merely ALIVE (the leaf circuit's 9 idle streams beside an
+// aggregation circuit's 17) cost the active one 9 % (120.7 against 131.8 aggregate proofs/s, round 4,
+// profiles/r04_stream_pool.txt), and more hardware queues cost more than they return.  Context i of a circuit takes
+// pool stream (first + i) mod P, `first` = where the pool's cursor stood when the circuit made its first context, so the
+// few contexts of the upper levels of an aggregation tree land on different streams; P = P25_STREAM_POOL (16), or the
+// largest proofs-in-flight count any circuit has asked for.  Two circuits proving at the same time interleave whole
+// proofs on the shared streams (every ordering inside the library is by events, which stay correct -- conservatively
+// so -- when a stream carries another circuit's work too).  Pool streams live as long as the process.
+#ifndef P25_STREAM_POOL
+#define P25_STREAM_POOL 16
+#endif
+namespace {
+struct StreamPool {
+  std::mutex mu;
+  std::map<int, std::vector<hipStream_t>> per_device;
+  size_t cursor = 0;
+  size_t width = P25_STREAM_POOL;
+  // a block of `count` consecutive pool positions (the caller's contexts first .. first + count - 1)
+  size_t reserve(size_t count, size_t want_width) {
+    std::lock_guard<std::mutex> l(mu);
+    if (want_width > width) width = want_width;
+    size_t first = cursor % width;
+    cursor += count;
+    return first;
+  }
+  hipStream_t at(size_t pos) {
+    std::lock_guard<std::mutex> l(mu);
+    int dev = 0;
+    P25_HIP(hipGetDevice(&dev));
+    auto& v = per_device[dev];
+    const size_t k = pos % width;
+    if (v.size() <= k) v.resize(k + 1, nullptr);
+    if (!v[k]) P25_HIP(hipStreamCreate(&v[k]));
+    return v[k];
+  }
+};
+StreamPool g_stream_pool;
+}  // namespace
 
 DevMem::DevMem(size_t w) : words(w) {
   if (w) P25_HIP(hipMalloc(&p, w * sizeof(u64)));
@@ -173,7 +216,8 @@ struct DeviceCircuit::Ctx {
   FriWork fri;
   DevMem proof, status;
   hipEvent_t ev[12];
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr;   // a stream of the process-wide pool (P25_STREAM_POOL != 0) or the context's own
+  bool own_stream = false;
   // done[b]: recorded after the context's latest read of witness-value buffer b (DeviceCircuit::vals_[b])
   hipEvent_t done[2] = {nullptr, nullptr};
   hipEvent_t join = nullptr;   // DeviceCircuit::stream_join
@@ -184,7 +228,7 @@ struct DeviceCircuit::Ctx {
     for (auto& e : done)
       if (e) (void)hipEventDestroy(e);
     if (join) (void)hipEventDestroy(join);
-    if (st) (void)hipStreamDestroy(st);
+    if (st && own_stream) (void)hipStreamDestroy(st);
   }
 };
 
@@ -317,6 +361,10 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
 }
 
 DeviceCircuit::~DeviceCircuit() {
+  // the proving streams outlive the circuit (pool): nothing of it may still be queued when its buffers go
+  for (auto& c : ctxs_)
+    if (c->st) (void)hipStreamSynchronize(c->st);
+  if (stream_) (void)hipStreamSynchronize(stream_);
   ctxs_.clear();
   for (auto& e : ev_witness_)
     if (e) (void)hipEventDestroy(e);
@@ -348,7 +396,13 @@ void DeviceCircuit::ensure_ctx(size_t count) {
   while (ctxs_.size() < count) {
   ctxs_.emplace_back(new Ctx());
   Ctx& x = *ctxs_.back();
-  P25_HIP(hipStreamCreate(&x.st));
+  if (P25_STREAM_POOL) {
+    if (ctxs_.size() == 1) pool_first_ = g_stream_pool.reserve(count, (size_t)streams_);
+    x.st = g_stream_pool.at(pool_first_ + ctxs_.size() - 1);
+  } else {
+    P25_HIP(hipStreamCreate(&x.st));
+    x.own_stream = true;
+  }
   for (auto& e : x.done) P25_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const size_t n = c_.degree(), B = big();
   const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;

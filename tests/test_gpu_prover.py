@@ -229,6 +229,54 @@ def test_read_only_entry_points_race_the_first_device_use(gpu, oracle):
         c.close()
 
 
+def test_circuits_share_the_proving_streams_and_one_may_go_while_the_other_proves(gpu, oracle):
+    """prover.hip StreamPool: the proving streams belong to the process, not to a circuit.  Two circuits enqueue
+    device-resident batches onto the SAME streams with no host synchronisation between the calls, one of them is
+    destroyed while the other's work is still queued behind its own, and every proof still equals the oracle's."""
+    import torch
+    from gadget_cases import cases
+    dev = torch.device("cuda", 0)
+    picks = {c[0]: c for c in cases(oracle) if c[0] in ("and", "compress")}
+    circs, bufs = {}, {}
+    n = 24                                         # more than the 16 streams: every stream carries both circuits
+    for name, (_n, kind, param, vals) in picks.items():
+        c = gpu.Circuit.build_gadget(kind, param)
+        inp = np.array(vals, dtype=np.uint64)
+        pw = int(c.info.proof_words)
+        bufs[name] = dict(inp=inp, pw=pw,
+                          d_in=torch.from_numpy(np.stack([inp] * n).view(np.int64)).to(dev),
+                          d_seeds=torch.arange(n, dtype=torch.int64, device=dev),
+                          d_p=[torch.zeros((n, pw), dtype=torch.int64, device=dev) for _ in range(3)],
+                          d_s=torch.ones((3, n), dtype=torch.int32, device=dev))
+        circs[name] = c
+    for rep in range(3):                           # a, b, a, b, a, b -- enqueue only
+        for name, c in circs.items():
+            b = bufs[name]
+            c.prove_dev(b["d_in"].data_ptr(), n, b["d_seeds"].data_ptr(), b["d_p"][rep].data_ptr(), b["pw"], b["d_s"][rep].data_ptr())
+    blob_and = circs["and"].to_blob()
+    circs.pop("and").close()                       # goes with its work (and the other circuit's, behind it) still queued
+    c = circs["compress"]
+    b = bufs["compress"]
+    late, st = c.prove(np.stack([b["inp"]] * 3), seeds=[0, 1, 2])
+    c.sync(); torch.cuda.synchronize()
+    assert st.tolist() == [0, 0, 0]
+    for name, blob in (("and", blob_and), ("compress", c.to_blob())):
+        b = bufs[name]
+        assert int((b["d_s"] != 0).sum().item()) == 0, name
+        oc = oracle.load_circuit(blob)
+        want = {}
+        for seed in (0, 1, 17, n - 1):
+            po, sto, _t, _m = oc.prove(b["inp"], seed=seed)
+            assert sto == 0
+            want[seed] = po
+        for rep in range(3):
+            got = b["d_p"][rep].cpu().numpy().view(np.uint64)
+            for seed, po in want.items():
+                assert (got[seed] == po).all(), (name, rep, seed)
+    assert (late[1] == bufs["compress"]["d_p"][0].cpu().numpy().view(np.uint64)[1]).all()
+    c.close()
+
+
 def test_circuit_create_destroy_does_not_leak_device_memory(gpu):
     import torch
     inp, cfg = gpu.p3_prove_fibonacci(3, 3, 4)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the 8-to-1 aggregation circuit BY ITSELF (batches of aggregate proofs, 16 in flight, steps enqueued back
 to back) next to the leaf circuit's, on one box: is an aggregate proof dearer than a leaf proof as a kernel mix, or only
-inside the pipelined tree?   usage: agg_throughput.py [aggregates per step = 64] [steps = 3] [--only leaf|agg]
+inside the pipelined tree?   usage: agg_throughput.py [aggregates per step = 64] [steps = 3] [--only leaf|agg] [--streams S] [--close-leaf]
 (--only: one circuit's timed loop alone, the form to put under rocprofv3 --kernel-trace --stats)"""
 import json, os, sys, time
 import numpy as np
@@ -15,6 +15,9 @@ dev = torch.device("cuda", 0)
 only = None
 if "--only" in sys.argv:
     i = sys.argv.index("--only"); only = sys.argv[i + 1]; del sys.argv[i:i + 2]
+streams = None
+if "--streams" in sys.argv:
+    i = sys.argv.index("--streams"); streams = int(sys.argv[i + 1]); del sys.argv[i:i + 2]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 inputs, cfg = p25.p3_proof_from_json(open(os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")).read())
@@ -40,7 +43,12 @@ def rate(circ, rows, count):
 
 
 agg = leaf.build_aggregator(8)
-out = {}
+if streams:
+    leaf.set_streams(streams); agg.set_streams(streams)
+out = {"streams": streams or "default", "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+if "--close-leaf" in sys.argv:      # the leaf circuit's streams gone before the aggregator runs (hardware-queue sharing)
+    assert only == "agg"
+    leaf.close(); out["leaf_closed"] = True
 if only != "agg":
     out["leaf_proofs_per_s"] = round(rate(leaf, inputs, n if only else 4 * n), 2)
     out["ms_per_leaf_proof"] = round(1e3 / out["leaf_proofs_per_s"], 3)
