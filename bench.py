@@ -357,7 +357,11 @@ def main():
             fail("a rank's GPU has too little free memory for the proofs-in-flight schedule (details on stderr)")
         sys.exit(2)
     nccl = distributed and args.dist_backend == "nccl"
-    side = [torch.cuda.Stream(device=dev) for _ in range(2)] if distributed else None
+    # ONE side stream for the gathers of both buffers (side[0] is side[1]): every stream that has carried work keeps its
+    # hardware queue, the library's pool (16) + one main stream per circuit + torch's + RCCL's come close to the 24 there
+    # are, and streams sharing a queue run in order (profiles/r04_stream_pool.txt: the distributed branch lost 2.5 % of
+    # the pipelined tree with two).  Gather k-1 is issued after step k, so at step k the stream holds gather k-2 at most.
+    side = [torch.cuda.Stream(device=dev)] * 2 if distributed else None
     g_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps_all)] if nccl else None
     torch.cuda.synchronize()  # inputs are resident in HBM before anything is timed
 
@@ -477,9 +481,10 @@ def main():
         if rank == 0 and f0 and f0["owned"] and n_agg >= f0["levels"][0]["arity"]:
             try:
                 k1 = f0["levels"][0]["arity"]
-                rate1 = pagg.circuit_throughput(f0["owned"][0], np.concatenate([local_leaves[i] for i in range(k1)]), dev)
+                rate1 = pagg.circuit_throughput(f0["owned"][0], np.concatenate([local_leaves[i] for i in range(k1)]), dev,
+                                                count=128, steps=3)   # 384 timed proofs: the ramp and the drain of 16 pipelines are ~1 % of that
                 agg_state["level1_throughput"] = {"aggregate_proofs_per_s": round(rate1, 2), "ms_per_aggregate_proof": round(1e3 / rate1, 3),
-                                                  "batch": 64, "steps": 2,
+                                                  "batch": 128, "steps": 3,
                                                   "note": "the level-1 aggregation circuit by itself, 16 proofs in flight, steps enqueued back to back"}
             except Exception as e:
                 agg_state["level1_throughput"] = {"error": str(e)[:200]}

@@ -143,6 +143,7 @@ class DeviceCircuit {
   size_t marks_recorded_[MAX_MARKS] = {0};           // how many of them the latest mark(slot) recorded
   int streams_ = 16;
   size_t pool_first_ = 0;      // this circuit's first position in the process-wide stream pool (prover.hip)
+  int main_slot_ = -1;         // which of the pool's two main streams stream_ is (-1: the circuit's own)
   bool single_proof_ = false;  // set per prove call: one proof in flight -> latency-oriented kernel forms
   DevMem vals_[2];             // witness values of a pass, slot-major [slot][proof of the pass]; double-buffered
   size_t vals_batch_[2] = {0, 0};

@@ -1,6 +1,7 @@
 // See prover.h.
 #include "prover.h"
 #include <algorithm>
+#include <array>
 #include <map>
 #include <mutex>
 #include <string.h>
@@ -15,7 +16,7 @@ namespace p25 {
 // profiles/r04_stream_pool.txt), and more hardware queues cost more than they return.  Context i of a circuit takes
 // pool stream (first + i) mod P, `first` = where the pool's cursor stood when the circuit made its first context, so the
 // few contexts of the upper levels of an aggregation tree land on different streams; P = P25_STREAM_POOL (16), or the
-// largest proofs-in-flight count any circuit has asked for.  Two circuits proving at the same time interleave whole
+// largest proofs-in-flight count any circuit has asked for.  Two circuits proving at the same time interleave their
 // proofs on the shared streams (every ordering inside the library is by events, which stay correct -- conservatively
 // so -- when a stream carries another circuit's work too).  Pool streams live as long as the process.
 #ifndef P25_STREAM_POOL
@@ -34,6 +35,30 @@ struct StreamPool {
     size_t first = cursor % width;
     cursor += count;
     return first;
+  }
+  // Main streams (a circuit's witness passes): two per device.  The first circuit of the process to ask keeps one to
+  // itself for as long as it lives (the leaf circuit of a batch prover, whose passes run under its own proving all the
+  // time); every other circuit shares the second (the levels of an aggregation tree: a pass of at most 32 proofs per
+  // step each).  The library then never holds more than 16 + 2 streams, whatever number of circuits is alive -- with a
+  // main stream per circuit the pipelined tree lost 2.5 % as soon as the host added its gather stream and RCCL's
+  // (profiles/r04_stream_pool.txt).  FIFO order on a shared stream is the order of the calls, which is the order of
+  // their dependencies, and every wait is for an event recorded earlier: sharing adds no wait that could not end.
+  std::map<int, std::array<hipStream_t, 2>> mains;
+  size_t main_refs[2] = {0, 0};
+  hipStream_t main_acquire(int& which) {
+    std::lock_guard<std::mutex> l(mu);
+    int dev = 0;
+    P25_HIP(hipGetDevice(&dev));
+    auto it = mains.find(dev);
+    if (it == mains.end()) it = mains.emplace(dev, std::array<hipStream_t, 2>{nullptr, nullptr}).first;
+    which = main_refs[0] == 0 ? 0 : 1;
+    if (!it->second[which]) P25_HIP(hipStreamCreate(&it->second[which]));
+    main_refs[which]++;
+    return it->second[which];
+  }
+  void main_release(int which) {
+    std::lock_guard<std::mutex> l(mu);
+    if (which >= 0 && which < 2 && main_refs[which]) main_refs[which]--;
   }
   hipStream_t at(size_t pos) {
     std::lock_guard<std::mutex> l(mu);
@@ -240,7 +265,11 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
   if (c_.num_partial_products + 1 > MAX_CHUNKS || c_.cfg.num_routed_wires > MAX_ROUTED ||
       c_.cfg.num_challenges * (2 + c_.num_partial_products) >= ALPHA_POWS || c_.num_gate_constraints > ALPHA_POWS)
     throw std::invalid_argument("circuit exceeds the permutation-argument / quotient kernels' capacities");
-  P25_HIP(hipStreamCreate(&stream_));
+  if (P25_STREAM_POOL) {
+    stream_ = g_stream_pool.main_acquire(main_slot_);
+  } else {
+    P25_HIP(hipStreamCreate(&stream_));
+  }
   layout_ = make_proof_layout(c_);
   const size_t n = c_.degree();
   const int ncs = (int)c_.constants_sigmas.size();
@@ -377,7 +406,8 @@ DeviceCircuit::~DeviceCircuit() {
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
     }
-  if (stream_) (void)hipStreamDestroy(stream_);
+  if (main_slot_ >= 0) g_stream_pool.main_release(main_slot_);
+  else if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 void DeviceCircuit::commitment_to_host(std::vector<u64>& coeffs, std::vector<u64>& lde, std::vector<u64>& tree) {
