@@ -61,6 +61,15 @@ struct PhaseTimes {  // milliseconds, device time measured with HIP events on th
         fri = 0, total = 0;
 };
 
+// A circuit's share of the process-wide pool's two main streams (prover.hip: StreamPool); slot -1 = none held.
+struct MainStreamLease {
+  int slot = -1;
+  MainStreamLease() = default;
+  MainStreamLease(const MainStreamLease&) = delete;
+  MainStreamLease& operator=(const MainStreamLease&) = delete;
+  ~MainStreamLease();
+};
+
 class DeviceCircuit {
  public:
   explicit DeviceCircuit(Circuit c);
@@ -127,6 +136,7 @@ class DeviceCircuit {
   void ensure_ctx(size_t count);
   void ensure_vals(int buf, size_t batch);
 
+  MainStreamLease main_lease_;   // first member: given back also when the constructor throws further down
   Circuit c_;
   ProofLayout layout_;
   NttTables tables_;
@@ -143,7 +153,6 @@ class DeviceCircuit {
   size_t marks_recorded_[MAX_MARKS] = {0};           // how many of them the latest mark(slot) recorded
   int streams_ = 16;
   size_t pool_first_ = 0;      // this circuit's first position in the process-wide stream pool (prover.hip)
-  int main_slot_ = -1;         // which of the pool's two main streams stream_ is (-1: the circuit's own)
   bool single_proof_ = false;  // set per prove call: one proof in flight -> latency-oriented kernel forms
   DevMem vals_[2];             // witness values of a pass, slot-major [slot][proof of the pass]; double-buffered
   size_t vals_batch_[2] = {0, 0};

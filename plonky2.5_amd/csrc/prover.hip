@@ -71,8 +71,12 @@ struct StreamPool {
     return v[k];
   }
 };
-StreamPool g_stream_pool;
+// never destroyed: circuits of static storage duration in a host may outlive any static of this library
+StreamPool& g_stream_pool = *new StreamPool;
 }  // namespace
+MainStreamLease::~MainStreamLease() {
+  if (slot >= 0) g_stream_pool.main_release(slot);
+}
 
 DevMem::DevMem(size_t w) : words(w) {
   if (w) P25_HIP(hipMalloc(&p, w * sizeof(u64)));
@@ -266,7 +270,7 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
       c_.cfg.num_challenges * (2 + c_.num_partial_products) >= ALPHA_POWS || c_.num_gate_constraints > ALPHA_POWS)
     throw std::invalid_argument("circuit exceeds the permutation-argument / quotient kernels' capacities");
   if (P25_STREAM_POOL) {
-    stream_ = g_stream_pool.main_acquire(main_slot_);
+    stream_ = g_stream_pool.main_acquire(main_lease_.slot);
   } else {
     P25_HIP(hipStreamCreate(&stream_));
   }
@@ -406,8 +410,7 @@ DeviceCircuit::~DeviceCircuit() {
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
     }
-  if (main_slot_ >= 0) g_stream_pool.main_release(main_slot_);
-  else if (stream_) (void)hipStreamDestroy(stream_);
+  if (main_lease_.slot < 0 && stream_) (void)hipStreamDestroy(stream_);   // a pooled main stream goes back with main_lease_
 }
 
 void DeviceCircuit::commitment_to_host(std::vector<u64>& coeffs, std::vector<u64>& lde, std::vector<u64>& tree) {
