@@ -277,6 +277,32 @@ def test_circuits_share_the_proving_streams_and_one_may_go_while_the_other_prove
     c.close()
 
 
+def test_more_proofs_in_flight_than_the_pool_is_wide(gpu, oracle):
+    """p25_circuit_set_streams above the pool's 16: the pool widens for the contexts made from then on (a circuit that
+    already has contexts keeps its streams; two contexts of one circuit on one stream only run in order).  Proofs are
+    the oracle's either way."""
+    from gadget_cases import cases
+    _n, kind, param, vals = [c for c in cases(oracle) if c[0] == "and"][0]
+    inp = np.array(vals, dtype=np.uint64)
+    a = gpu.Circuit.build_gadget(kind, param)
+    pa, st = a.prove(np.stack([inp] * 4), seeds=[0, 1, 2, 3])          # four contexts under the 16-wide pool
+    assert st.tolist() == [0] * 4
+    b = gpu.Circuit.build_gadget(kind, param)
+    b.set_streams(24)
+    n = 50
+    pb, st = b.prove(np.stack([inp] * n), seeds=list(range(n)))         # 24 contexts: the pool is 24 wide now
+    assert st.tolist() == [0] * n
+    a.set_streams(24)
+    pa2, st = a.prove(np.stack([inp] * n), seeds=list(range(n)))        # grows to 24 under the new width
+    assert st.tolist() == [0] * n
+    assert (pa2 == pb).all() and (pa2[:4] == pa).all()
+    oc = oracle.load_circuit(b.to_blob())
+    for seed in (0, 15, 16, 23, 24, 49):
+        po, sto, _t, _m = oc.prove(inp, seed=seed)
+        assert sto == 0 and (pb[seed] == po).all(), seed
+    a.close(); b.close()
+
+
 def test_circuit_create_destroy_does_not_leak_device_memory(gpu):
     import torch
     inp, cfg = gpu.p3_prove_fibonacci(3, 3, 4)
