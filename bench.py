@@ -52,7 +52,10 @@ def parse_args():
                     help="leaves of the aggregation-tree measurement after the timed region (recursive 2-to-1 verifier "
                          "circuits down to ONE root proof), PER RANK: every rank folds that many proofs of its own shard to one "
                          "root, the N roots are gathered and rank 0 proves one N-to-1 aggregate on top; -1 = 64 (0 = off)")
-    ap.add_argument("--aggregate-arity", type=int, default=8, choices=(2, 4, 8, 16), help="children per aggregation circuit")
+    ap.add_argument("--aggregate-arity", type=int, default=13, choices=range(2, 17), metavar="2..16",
+                    help="children per aggregation circuit, at most (plonky25_amd.aggregate.level_plan).  13 is the most the "
+                         "2^16 rows of an aggregation circuit over fib-64 verifier proofs hold (62,753 rows; 8 use 38,687, "
+                         "14 need 2^17): the same machine time per aggregate proof, 23 instead of 37 of them per 256 leaves")
     ap.add_argument("--extra-configs", choices=("auto", "none"), default="auto",
                     help="auto: also measure BASELINE configs 2 (single proof) and 5 (2^20-row inner STARK) and report "
                          "them in the `configs` block (N = 1 only)")
@@ -472,7 +475,6 @@ def main():
         na_t = torch.tensor([n_agg], dtype=torch.int32, device=cdev)
         dist.all_reduce(na_t, op=dist.ReduceOp.MIN)     # every shard folds the same shape
         n_agg = int(na_t.item())
-    n_agg = pagg.largest_pow2(n_agg) if n_agg >= 1 else 0
     if n_agg * world >= 2 and ok:
         local_leaves = last[:n_agg].cpu().numpy().view(np.uint64)
         agg_state = pagg.fold_sharded(circuit, local_leaves, args.aggregate_arity, cdev, distributed)
@@ -495,7 +497,7 @@ def main():
     # tree (B -> B/8 -> ... -> 1 per rank, over the leaves of earlier steps), nothing synchronised until the end.
     # Measures leaf proofs/s INCLUDING their aggregation directly, in steady state.
     pipe = None
-    nl = pagg.largest_pow2(B) if B >= 1 else 0
+    nl = B
     if args.aggregate != 0 and ok and nl >= 2 and (agg_state is None or not agg_state.get("error")):
         perr, tree = None, None
         K_pipe = 3
@@ -769,7 +771,7 @@ def main():
                             (pipe["elapsed"] / pipe["steps"] - B / (total_proofs / elapsed / world)) * 1e3 / max(1, tree.aggregates_per_step)),
                         "leaf_proofs_per_rank_per_step": B, "leaves_folded_per_rank_per_step": pipe["leaves"],
                         "aggregate_proofs_per_rank_per_step": tree.aggregates_per_step, "proofs_of_any_kind_per_rank_per_step": B - pipe["leaves"] + per_step,
-                        "levels": [{"arity": L["k"], "proofs": L["n"], "circuit_rows_log2": int(L["circ"].info.degree_bits)}
+                        "levels": [{"arity": L["k"], "children": L["children"], "proofs": L["n"], "circuit_rows_log2": int(L["circ"].info.degree_bits)}
                                    for L in tree.levels],
                         "all_statuses_ok": pipe["statuses_ok"], "root_public_inputs_commit_to_the_leaves": got == want,
                         "oracle_verifier_accepts_root": bool(verify_with_oracle(tree.top, pipe["root"])),

@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-__all__ = ["fold", "fold_roots", "fold_sharded", "release_fold", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "largest_pow2"]
+__all__ = ["fold", "fold_roots", "fold_sharded", "release_fold", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "largest_pow2", "level_plan", "group_bounds"]
 
 CAP_WORDS = 64   # wires cap = the first 2^cap_height x 4 words of a flat proof (cap_height 4, include/p25.h proof layout)
 
@@ -31,22 +31,34 @@ def leaf_identifier_words(proof, n_public_inputs):
 
 
 def level_plan(n, arity):
-    """Group sizes per level for n children folded `arity` at a time down to one (n a power of two, arity too)."""
+    """Group sizes per level for n children folded at most `arity` at a time down to one: a level of n children is
+    ceil(n / arity) groups of k = ceil(n / groups) children each.  Powers of two fold exactly (256 by 8: 8, 8, 4).  When
+    groups x k > n -- 256 by 13: 20 groups of 13 = 260 -- the LAST group is the last k children, i.e. it overlaps its
+    neighbour and re-verifies up to k - 1 children that group has verified already (`group_bounds`): every level stays
+    one batch of one circuit over consecutive rows, and nothing is padded or copied."""
     plan = []
     while n > 1:
-        k = min(arity, n)
+        groups = -(-n // arity)
+        k = -(-n // groups)
         plan.append(k)
-        n //= k
+        n = groups
     return plan
 
 
+def group_bounds(n, k):
+    """[(first child, one past the last)] of the ceil(n / k) groups of a level of n children: consecutive, the last
+    one right-aligned (it overlaps the one before it when k does not divide n)."""
+    groups = -(-n // k)
+    return [(k * i, k * (i + 1)) for i in range(groups - 1)] + [(n - k, n)]
+
+
 def fold(circuit, leaves, arity=8, warm=True, in_flight=16):
-    """Folds `leaves` (flat proofs of `circuit`, a power of two of them) into one root proof.  Returns a dict with the
+    """Folds `leaves` (flat proofs of `circuit`, any number of them: `level_plan`) into one root proof.  Returns a dict with the
     root proof, the circuit it belongs to (`top`; the caller closes `owned` when done), per-level records and the time
     spent proving (`tree_s`) and building circuits (`build_s`, once per shape).  One leaf: the leaf is the root."""
     n = len(leaves)
-    if n < 1 or n & (n - 1):
-        raise ValueError("fold needs a power-of-two number of leaves")
+    if n < 1:
+        raise ValueError("fold needs at least one leaf")
     level, circ, levels, owned, tree_s, build_s = list(leaves), circuit, [], [], 0.0, 0.0
     for k in level_plan(n, arity):
         t = time.perf_counter()
@@ -55,7 +67,8 @@ def fold(circuit, leaves, arity=8, warm=True, in_flight=16):
         bs = time.perf_counter() - t
         build_s += bs
         owned.append(nxt)
-        groups = np.stack([np.concatenate(level[k * i:k * (i + 1)]) for i in range(len(level) // k)])
+        n_children = len(level)
+        groups = np.stack([np.concatenate(level[a:b]) for a, b in group_bounds(n_children, k)])
         if warm:   # this circuit's contexts and tables: once per shape, like the build
             w = min(in_flight, len(groups))
             nxt.prove(groups[:w], seeds=list(range(w)))
@@ -66,7 +79,7 @@ def fold(circuit, leaves, arity=8, warm=True, in_flight=16):
             raise RuntimeError(f"aggregation level {len(levels) + 1}: statuses {st.tolist()}")
         tree_s += dt
         level = [out[i] for i in range(out.shape[0])]
-        levels.append({"level": len(levels) + 1, "arity": k, "circuit_rows_log2": int(nxt.info.degree_bits),
+        levels.append({"level": len(levels) + 1, "arity": k, "children": n_children, "circuit_rows_log2": int(nxt.info.degree_bits),
                        "rows_used": int(nxt.info.num_rows_used), "proofs": len(level), "prove_s": round(dt, 4),
                        "ms_per_proof": round(dt / len(level) * 1e3, 3), "circuit_build_s": round(bs, 2)})
         circ = nxt
@@ -106,7 +119,7 @@ def expected_commitment(leaf_caps, arity, hash_no_pad, n_shards=1):
     for s in range(n_shards):
         ids = [hash_no_pad(np.asarray(c, dtype=np.uint64)) for c in leaf_caps[s * per:(s + 1) * per]]
         for k in level_plan(per, arity):
-            ids = [hash_no_pad(np.concatenate(ids[k * i:k * (i + 1)])) for i in range(len(ids) // k)]
+            ids = [hash_no_pad(np.concatenate(ids[a:b])) for a, b in group_bounds(len(ids), k)]
         roots.append(ids[0])
     if n_shards == 1:
         return [int(v) for v in roots[0]]
@@ -215,7 +228,8 @@ class DeviceTree:
     """The aggregation tree of one shard kept RESIDENT ON THE DEVICE and only ever enqueued: an aggregation circuit's
     inputs are its k children's flat proofs back to back, i.e. exactly k consecutive rows of the buffer the level
     below writes its proofs into (proof stride = proof words), so a level is `p25_prove_batch_dev` straight on the
-    previous level's output -- no host round trip, no synchronisation.  Ordering between the circuits is device-side
+    previous level's output -- no host round trip, no synchronisation.  Any number of leaves and any arity: when k does
+    not divide a level's children its last group is the last k rows (`group_bounds`), one more call on the same buffer.  Ordering between the circuits is device-side
     and event-only (`p25_circuit_mark` / `p25_circuit_wait_mark`).
 
     The schedule is LAGGED: level l of step i is enqueued one step after level l-1 of step i (level 1 after the leaves
@@ -235,8 +249,8 @@ class DeviceTree:
 
     def __init__(self, circuit, n_leaves, arity, device, leaf_batch=None, level_streams=None):
         import torch
-        if n_leaves < 2 or n_leaves & (n_leaves - 1):
-            raise ValueError("DeviceTree needs a power-of-two number of leaves >= 2")
+        if n_leaves < 2:
+            raise ValueError("DeviceTree needs at least two leaves")
         self.torch, self.dev, self.n_leaves, self.arity = torch, device, n_leaves, arity
         self.leaf, self.levels, self.build_s = circuit, [], 0.0
         plan = level_plan(n_leaves, arity)
@@ -252,13 +266,13 @@ class DeviceTree:
             nxt = circ.build_aggregator(k)
             nxt.digest()
             self.build_s += time.perf_counter() - t
-            n //= k
+            n_children, n = n, -(-n // k)
             if level_streams:
                 nxt.set_streams(max(1, min(level_streams[min(len(self.levels), len(level_streams) - 1)], n)))
             pw = int(nxt.info.proof_words)
             assert int(nxt.info.num_inputs) == k * int(circ.info.proof_words)
             self.levels.append({
-                "circ": nxt, "n": n, "k": k, "pw": pw,
+                "circ": nxt, "n": n, "k": k, "pw": pw, "children": n_children, "cpw": int(circ.info.proof_words),
                 "seeds": torch.arange(n, dtype=torch.int64, device=device),
                 "out": [torch.zeros((n, pw), dtype=torch.int64, device=device) for _ in range(self.slots)],
                 "status": [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(self.slots)],
@@ -292,8 +306,16 @@ class DeviceTree:
             if i >= S and l + 1 < len(circs):            # the level above has finished reading out[s] of step i - S
                 c.wait_mark(circs[l + 1], s)
             below = self.leaf_buf[s][:self.n_leaves] if l == 1 else self.levels[l - 2]["out"][s]
-            c.prove_dev(below.data_ptr(), L["n"], L["seeds"].data_ptr(), L["out"][s].data_ptr(), L["pw"],
-                        L["status"][s].data_ptr())
+            # groups 0 .. n-2 are consecutive rows of `below`; the last one is its last k rows (group_bounds): a second
+            # call when k does not divide the number of children, the same batch otherwise
+            n, k, pw = L["n"], L["k"], L["pw"]
+            exact = n * k == L["children"]
+            head = n if exact else n - 1
+            if head:
+                c.prove_dev(below.data_ptr(), head, L["seeds"].data_ptr(), L["out"][s].data_ptr(), pw, L["status"][s].data_ptr())
+            if not exact:
+                c.prove_dev(below.data_ptr() + (L["children"] - k) * L["cpw"] * 8, 1, L["seeds"].data_ptr() + head * 8,
+                            L["out"][s].data_ptr() + head * pw * 8, pw, L["status"][s].data_ptr() + head * 4)
             c.mark(s)
         self.host_steps += 1
 

@@ -29,11 +29,12 @@ def test_gather_world2_gloo(n_total):
     assert f"DIST_OK {n_total}" in out.stdout
 
 
-@pytest.mark.parametrize("n_per_rank,arity", [(8, 8), (16, 4), (1, 8)])
+@pytest.mark.parametrize("n_per_rank,arity", [(8, 8), (16, 4), (1, 8), (20, 13), (7, 3)])
 def test_sharded_aggregation_world2_gloo(n_per_rank, arity):
     """Every rank folds its own shard, ONE root per rank is gathered, rank 0 proves the cross-rank aggregate; the final
     public inputs equal the hash tree over ALL ranks' leaves (stand-in circuits: libp25 has no CPU path; the real
-    prover runs the same code in tests/test_gpu_bench_contract.py)."""
+    prover runs the same code in tests/test_gpu_bench_contract.py).  (20, 13) and (7, 3): arities that do not divide
+    the shard -- the last group of a level is right-aligned and overlaps its neighbour (aggregate.group_bounds)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(29551 + n_per_rank + arity),

@@ -262,6 +262,62 @@ def test_device_tree_chained_on_the_device_equals_the_host_fold(gpu, oracle):
     tree.close()
 
 
+def test_device_tree_and_fold_with_an_arity_that_does_not_divide_the_leaves(gpu, oracle):
+    """Five leaves, at most three children per aggregator: level 1 is two groups, rows 0..2 and -- right-aligned,
+    overlapping -- rows 2..4 (aggregate.group_bounds), level 2 the two of them.  The device-chained tree (a second
+    p25_prove_batch_dev on the last three rows of the same buffer), the host fold and the commitment recomputed from the
+    leaves agree, the oracle's verifier accepts the root, and the root commits to EVERY leaf: changing any one leaf's
+    cap changes the expected commitment."""
+    import torch
+    from plonky25_amd import aggregate as ag
+    assert ag.level_plan(5, 3) == [3, 2] and ag.group_bounds(5, 3) == [(0, 3), (2, 5)]
+    leaf = gpu.Circuit.build_gadget(0, 0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    n_leaves, steps = 5, 5
+    pw = int(leaf.info.proof_words)
+    inputs = []
+    for s in range(steps):
+        xs = rng.integers(0, P, size=(n_leaves, 2), dtype=np.uint64)
+        inputs.append(np.stack([np.array([int(a), int(b), (int(a) & int(b)) % P], dtype=np.uint64) for a, b in xs]))
+    tree = ag.DeviceTree(leaf, n_leaves, 3, dev)
+    assert [(L["k"], L["children"], L["n"]) for L in tree.levels] == [(3, 5, 2), (2, 2, 1)]
+    d_in = [torch.from_numpy(x.view(np.int64)).to(dev) for x in inputs]
+    d_seeds = torch.arange(n_leaves, dtype=torch.int64, device=dev)
+    d_st = torch.zeros((steps, n_leaves), dtype=torch.int32, device=dev)
+
+    def leaves(buf, j):
+        leaf.prove_dev(d_in[j].data_ptr(), n_leaves, d_seeds.data_ptr(), buf.data_ptr(), pw, d_st[j].data_ptr())
+
+    for j in range(steps):
+        tree.step(leaves)
+    tree.flush(); tree.sync(); torch.cuda.synchronize()
+    assert int((d_st != 0).sum().item()) == 0
+    for j in range(steps - tree.slots, steps):
+        if j < 0:
+            continue
+        root, ok = tree.root(j)
+        assert ok, j
+        lp, st = leaf.prove(inputs[j], seeds=np.arange(n_leaves, dtype=np.uint64))
+        assert st.tolist() == [0] * n_leaves
+        f = ag.fold(leaf, [lp[i] for i in range(n_leaves)], arity=3, warm=False)
+        assert [l["arity"] for l in f["levels"]] == [3, 2] and [l["proofs"] for l in f["levels"]] == [2, 1]
+        assert (f["root"] == root).all(), f"step {j}: the device-chained root differs from the host fold's"
+        caps = [lp[i][:ag.CAP_WORDS] for i in range(n_leaves)]
+        want = ag.expected_commitment(caps, 3, oracle.hash_no_pad)
+        assert [int(v) for v in tree.top.public_inputs(root)] == want
+        for i in range(n_leaves):                 # every leaf is under the root
+            other = [c.copy() for c in caps]
+            other[i][0] = (int(other[i][0]) + 1) % P
+            assert ag.expected_commitment(other, 3, oracle.hash_no_pad) != want, i
+        oc = oracle.load_circuit(f["top"].to_blob())
+        dg, cap = f["top"].digest()
+        assert oc.verify(root, dg, cap)[0] == 0
+        for c in f["owned"]:
+            c.close()
+    tree.close()
+
+
 def test_device_tree_a_failed_leaf_fails_its_branch_only(gpu):
     """A leaf whose witness does not exist (P25_ERR_WITNESS_CONFLICT) leaves no valid proof in the buffer: the aggregate
     above it must fail too (its status says so -- never a root that looks valid), while the other steps in flight through

@@ -84,7 +84,7 @@ def child(lib, batch, steps, agg, pipe=0, tstreams="4,2,1"):
     if pipe:   # the pipelined device-resident tree (bench.py's `aggregation.pipelined`): warm-up steps + `pipe` timed steps
         from plonky25_amd import aggregate as ag
         ls = tuple(int(x) for x in tstreams.split(",")) if tstreams != "0" else None
-        tree = ag.DeviceTree(c, ag.largest_pow2(batch), 8, dev, leaf_batch=batch, level_streams=ls)
+        tree = ag.DeviceTree(c, batch, int(os.environ.get("P25_AB_ARITY", "13")), dev, leaf_batch=batch, level_streams=ls)
         nst = len(tree.levels) + 1 + pipe
         d_sp = torch.zeros((nst, batch), dtype=torch.int32, device=dev)
 
