@@ -4,7 +4,7 @@ taken literally): N leaf proofs folded `arity` at a time (plonky25_amd.aggregate
 rank) down to one root proof, every level a plain batch prove on the GPU.  Prints one JSON line with the per-level
 circuit sizes and times; the root is checked by the oracle's verifier.  The profiling target for the aggregator's
 kernels: `rocprofv3 --kernel-trace --stats -- python3 tools/aggregate.py 64 8`.
-usage: aggregate.py [N = 64, a power of two] [arity = 8] [--no-leaves: read nothing, prove the leaves untimed]"""
+usage: aggregate.py [N = 64] [arity = 8; bench.py's default is 13] [--no-leaves: read nothing, prove the leaves untimed]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
