@@ -14,15 +14,9 @@ import time
 
 import numpy as np
 
-__all__ = ["fold", "fold_roots", "fold_sharded", "release_fold", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "largest_pow2", "level_plan", "group_bounds"]
+__all__ = ["fold", "fold_roots", "fold_sharded", "release_fold", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "level_plan", "group_bounds"]
 
 CAP_WORDS = 64   # wires cap = the first 2^cap_height x 4 words of a flat proof (cap_height 4, include/p25.h proof layout)
-
-
-def largest_pow2(n):
-    while n & (n - 1):
-        n &= n - 1
-    return n
 
 
 def leaf_identifier_words(proof, n_public_inputs):
