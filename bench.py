@@ -49,8 +49,8 @@ def parse_args():
                     help="strong-scaling mode (BASELINE config 4 literally: --total 2048): this many proofs per step in "
                          "all, split across the ranks; overrides --batch")
     ap.add_argument("--aggregate", type=int, default=-1,
-                    help="leaves of the aggregation-tree measurement after the timed region (recursive 2-to-1 verifier "
-                         "circuits down to ONE root proof), PER RANK: every rank folds that many proofs of its own shard to one "
+                    help="leaves of the aggregation-tree measurement after the timed region (recursive k-to-1 verifier "
+                         "circuits down to ONE root proof, k = --aggregate-arity), PER RANK: every rank folds that many proofs of its own shard to one "
                          "root, the N roots are gathered and rank 0 proves one N-to-1 aggregate on top; -1 = 64 (0 = off)")
     ap.add_argument("--aggregate-arity", type=int, default=13, choices=range(2, 17), metavar="2..16",
                     help="children per aggregation circuit, at most (plonky25_amd.aggregate.level_plan).  13 is the most the "
