@@ -52,10 +52,11 @@ def parse_args():
                     help="leaves of the aggregation-tree measurement after the timed region (recursive k-to-1 verifier "
                          "circuits down to ONE root proof, k = --aggregate-arity), PER RANK: every rank folds that many proofs of its own shard to one "
                          "root, the N roots are gathered and rank 0 proves one N-to-1 aggregate on top; -1 = 64 (0 = off)")
-    ap.add_argument("--aggregate-arity", type=int, default=13, choices=range(2, 17), metavar="2..16",
-                    help="children per aggregation circuit, at most (plonky25_amd.aggregate.level_plan).  13 is the most the "
-                         "2^16 rows of an aggregation circuit over fib-64 verifier proofs hold (62,753 rows; 8 use 38,687, "
-                         "14 need 2^17): the same machine time per aggregate proof, 23 instead of 37 of them per 256 leaves")
+    ap.add_argument("--aggregate-arity", type=int, default=0, choices=[0] + list(range(2, 17)), metavar="0 | 2..16",
+                    help="children per aggregation circuit, at most (plonky25_amd.aggregate.level_plan); 0 = the arity at which "
+                         "an aggregation circuit costs least per child (aggregate.widest_arity).  For fib-64 verifier proofs "
+                         "that is 13, the most the circuit's 2^16 rows hold (62,753 rows; 8 use 38,687, 14 need 2^17): the same "
+                         "machine time per aggregate proof, 23 instead of 37 of them per 256 leaves")
     ap.add_argument("--extra-configs", choices=("auto", "none"), default="auto",
                     help="auto: also measure BASELINE configs 2 (single proof) and 5 (2^20-row inner STARK) and report "
                          "them in the `configs` block (N = 1 only)")
@@ -470,6 +471,8 @@ def main():
     # are gathered over RCCL, rank 0 proves one N-to-1 aggregate on top.  Collectives only where every rank reaches them:
     # a local failure is agreed on first.
     agg_state = None
+    if args.aggregate != 0 and args.aggregate_arity == 0 and ok:
+        args.aggregate_arity = pagg.widest_arity(circuit)      # deterministic: the same on every rank
     n_agg = min(args.aggregate if args.aggregate >= 0 else 64, B)
     if distributed:
         na_t = torch.tensor([n_agg], dtype=torch.int32, device=cdev)
@@ -735,6 +738,7 @@ def main():
                     root_ok = ora.load_circuit(ck["top_blob"]).verify(root, ck["digest"], ck["cap"])[0] == 0
                     out["aggregation"] = {
                         "leaves": leaves, "leaves_per_rank": agg_state["leaves_per_rank"], "ranks": world,
+                        "max_children_per_aggregation_circuit": args.aggregate_arity,
                         "levels": ck["levels"], "level1_throughput": agg_state.get("level1_throughput"),
                         "root_public_inputs": root_pis,
                         "root_public_inputs_commit_to_the_leaves": root_pis == want,

@@ -14,9 +14,34 @@ import time
 
 import numpy as np
 
-__all__ = ["fold", "fold_roots", "fold_sharded", "release_fold", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "level_plan", "group_bounds"]
+__all__ = ["fold", "fold_roots", "fold_sharded", "release_fold", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "level_plan", "group_bounds", "widest_arity"]
 
 CAP_WORDS = 64   # wires cap = the first 2^cap_height x 4 words of a flat proof (cap_height 4, include/p25.h proof layout)
+
+
+def widest_arity(circuit, cap=16):
+    """The number of children (<= cap) at which an aggregation circuit over proofs of `circuit` costs least per child:
+    an aggregation circuit pays for 2^ceil(log2 rows) rows and uses rows(k) = a + b k of them (the verifier of one more
+    child is the same rows again), so the best k fills a power of two.  a and b come from two small builds (k = 2, 3),
+    the chosen k is built and checked (one smaller if the estimate was a few rows short).  fib-64 verifier proofs: 13
+    (62,753 of 2^16 rows; 8 use 38,687, 14 need 2^17) -- profiles/r04_arity.txt."""
+    c2, c3 = circuit.build_aggregator(2), circuit.build_aggregator(3)
+    r2, r3 = int(c2.info.num_rows_used), int(c3.info.num_rows_used)
+    c2.close(); c3.close()
+    b, a = r3 - r2, r2 - 2 * (r3 - r2)
+
+    def padded(k):
+        return 1 << max(1, (a + b * k - 1).bit_length())
+
+    best = min(range(2, cap + 1), key=lambda k: (padded(k) / k, -k))
+    while best > 2:
+        c = circuit.build_aggregator(best)
+        fits = (1 << int(c.info.degree_bits)) <= padded(best)
+        c.close()
+        if fits:
+            break
+        best -= 1
+    return best
 
 
 def leaf_identifier_words(proof, n_public_inputs):

@@ -75,3 +75,32 @@ def test_expected_commitment_follows_the_plan(ag):
     ids2 = [h(c) for c in caps2[5:]]
     r2 = h(np.concatenate([h(np.concatenate(ids2[0:3])), h(np.concatenate(ids2[2:5]))]))
     assert ag.expected_commitment(caps2, 3, h, n_shards=2) == [int(v) for v in h(np.concatenate([h(np.concatenate(l1)), r2]))]
+
+
+def test_widest_arity_fills_a_power_of_two(ag):
+    """rows(k) = a + b k from two small builds; the arity with the fewest padded rows per child; the chosen circuit is
+    built and checked, one child fewer when the estimate was short."""
+    class Fake:
+        built = []
+
+        def __init__(self, a, b, k=0, bump=0):
+            self.a, self.b, self.bump = a, b, bump
+            rows = a + b * k + (bump if k > 3 else 0)
+
+            class Info:
+                num_rows_used = rows
+                degree_bits = max(1, (rows - 1).bit_length())
+            self.info = Info()
+
+        def build_aggregator(self, k):
+            Fake.built.append(k)
+            return Fake(self.a, self.b, k, self.bump)
+
+        def close(self):
+            pass
+
+    assert ag.widest_arity(Fake(181, 4813)) == 13            # the fib-64 verifier circuit's figures: 62,750 of 2^16 rows
+    assert Fake.built[:2] == [2, 3] and Fake.built[-1] == 13
+    assert ag.widest_arity(Fake(181, 4813), cap=8) == 6       # 2^15 / 6 beats 2^16 / 8
+    assert ag.widest_arity(Fake(100, 1000)) == 16             # 16,100 rows in 2^14: the cap
+    assert ag.widest_arity(Fake(181, 4813, bump=3000)) == 12  # the real circuit larger than the line through k = 2, 3

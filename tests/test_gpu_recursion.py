@@ -318,6 +318,17 @@ def test_device_tree_and_fold_with_an_arity_that_does_not_divide_the_leaves(gpu,
     tree.close()
 
 
+def test_widest_arity_of_the_fib64_verifier_circuit(gpu, fib_circuit):
+    """bench.py's default (--aggregate-arity 0): thirteen fib-64 verifier proofs are what the 2^16 rows of an aggregation
+    circuit hold (profiles/r04_arity.txt); fourteen need 2^17."""
+    from plonky25_amd import aggregate as ag
+    assert ag.widest_arity(fib_circuit) == 13
+    a13, a14 = fib_circuit.build_aggregator(13), fib_circuit.build_aggregator(14)
+    assert int(a13.info.degree_bits) == 16 and int(a14.info.degree_bits) == 17
+    assert int(a13.info.num_inputs) == 13 * int(fib_circuit.info.proof_words)
+    a13.close(); a14.close()
+
+
 def test_device_tree_a_failed_leaf_fails_its_branch_only(gpu):
     """A leaf whose witness does not exist (P25_ERR_WITNESS_CONFLICT) leaves no valid proof in the buffer: the aggregate
     above it must fail too (its status says so -- never a root that looks valid), while the other steps in flight through
