@@ -182,8 +182,10 @@ p25_status p25_circuit_build_gate_eval(int32_t kind, p25_circuit** out);
 /* p25_circuit_build_recursive_verifier whose circuit also REGISTERS FOUR PUBLIC INPUTS (upstream
  * `builder.register_public_inputs`): hash_no_pad over the identifiers of the proofs it verifies, a proof's identifier
  * being its own public inputs when it has any (an aggregate further down the tree) and hash_no_pad(its wires cap)
- * otherwise (a leaf).  Stacked 2-to-1 aggregators expose the root of a Poseidon tree over the batch: the "final
- * aggregation step" of BASELINE.json leaves one proof whose public inputs commit to every leaf proof. */
+ * otherwise (a leaf).  Stacked aggregators expose the root of a Poseidon tree over the batch: the "final
+ * aggregation step" of BASELINE.json leaves one proof whose public inputs commit to every leaf proof.  n_proofs is free:
+ * the circuit's size follows it -- over fib-64 verifier proofs 13 children still fit 2^16 rows (62,753; 8 use 38,687,
+ * 14 need 2^17), which is what plonky25_amd.aggregate.widest_arity finds and bench.py uses. */
 p25_status p25_circuit_build_aggregator(p25_circuit* inner, const uint64_t* digest4, const uint64_t* cs_cap,
                                         int32_t n_proofs, p25_circuit** out);
 
