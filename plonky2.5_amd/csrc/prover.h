@@ -63,7 +63,7 @@ struct PhaseTimes {  // milliseconds, device time measured with HIP events on th
 
 // A circuit's share of the process-wide pool's two main streams (prover.hip: StreamPool); slot -1 = none held.
 struct MainStreamLease {
-  int slot = -1;
+  int slot = -1, device = 0;
   MainStreamLease() = default;
   MainStreamLease(const MainStreamLease&) = delete;
   MainStreamLease& operator=(const MainStreamLease&) = delete;

@@ -1,7 +1,6 @@
 // See prover.h.
 #include "prover.h"
 #include <algorithm>
-#include <array>
 #include <map>
 #include <mutex>
 #include <string.h>
@@ -43,22 +42,27 @@ struct StreamPool {
   // main stream per circuit the pipelined tree lost 2.5 % as soon as the host added its gather stream and RCCL's
   // (profiles/r04_stream_pool.txt).  FIFO order on a shared stream is the order of the calls, which is the order of
   // their dependencies, and every wait is for an event recorded earlier: sharing adds no wait that could not end.
-  std::map<int, std::array<hipStream_t, 2>> mains;
-  size_t main_refs[2] = {0, 0};
-  hipStream_t main_acquire(int& which) {
+  struct Mains {
+    hipStream_t st[2] = {nullptr, nullptr};
+    size_t refs[2] = {0, 0};
+  };
+  std::map<int, Mains> mains;
+  hipStream_t main_acquire(MainStreamLease& lease) {
     std::lock_guard<std::mutex> l(mu);
     int dev = 0;
     P25_HIP(hipGetDevice(&dev));
-    auto it = mains.find(dev);
-    if (it == mains.end()) it = mains.emplace(dev, std::array<hipStream_t, 2>{nullptr, nullptr}).first;
-    which = main_refs[0] == 0 ? 0 : 1;
-    if (!it->second[which]) P25_HIP(hipStreamCreate(&it->second[which]));
-    main_refs[which]++;
-    return it->second[which];
+    Mains& m = mains[dev];
+    const int which = m.refs[0] == 0 ? 0 : 1;
+    if (!m.st[which]) P25_HIP(hipStreamCreate(&m.st[which]));
+    m.refs[which]++;
+    lease.slot = which;      // only now: a lease that failed to form gives nothing back
+    lease.device = dev;
+    return m.st[which];
   }
-  void main_release(int which) {
+  void main_release(const MainStreamLease& lease) {
     std::lock_guard<std::mutex> l(mu);
-    if (which >= 0 && which < 2 && main_refs[which]) main_refs[which]--;
+    auto it = mains.find(lease.device);
+    if (it != mains.end() && lease.slot >= 0 && lease.slot < 2 && it->second.refs[lease.slot]) it->second.refs[lease.slot]--;
   }
   hipStream_t at(size_t pos) {
     std::lock_guard<std::mutex> l(mu);
@@ -75,7 +79,7 @@ struct StreamPool {
 StreamPool& g_stream_pool = *new StreamPool;
 }  // namespace
 MainStreamLease::~MainStreamLease() {
-  if (slot >= 0) g_stream_pool.main_release(slot);
+  if (slot >= 0) g_stream_pool.main_release(*this);
 }
 
 DevMem::DevMem(size_t w) : words(w) {
@@ -270,7 +274,7 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
       c_.cfg.num_challenges * (2 + c_.num_partial_products) >= ALPHA_POWS || c_.num_gate_constraints > ALPHA_POWS)
     throw std::invalid_argument("circuit exceeds the permutation-argument / quotient kernels' capacities");
   if (P25_STREAM_POOL) {
-    stream_ = g_stream_pool.main_acquire(main_lease_.slot);
+    stream_ = g_stream_pool.main_acquire(main_lease_);
   } else {
     P25_HIP(hipStreamCreate(&stream_));
   }
