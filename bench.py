@@ -30,6 +30,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+COLLECTIVE_TIMEOUT_S = 1800   # torch.distributed process-group timeout (RCCL watchdog included)
 N_SIMD, NOMINAL_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; the clock is measured in the run (p25_shader_clock_hz)
 
 
@@ -267,10 +268,15 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # The collective timeout bounds what ranks != 0 may wait in the final barrier while rank 0 checks the run with the
+        # oracle and assembles the JSON line (`rank0_post_region_s` in the record: tens of seconds): set explicitly, well
+        # above that, instead of inheriting the backend's default watchdog.
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S)
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=pg_timeout)
 
     p25 = ge.load_package()
     p25.device_init(local_rank)
@@ -444,6 +450,7 @@ def main():
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    t_region_end = time.perf_counter()
     per_rank = None
     if distributed:
         gather_s = (sum(e0.elapsed_time(e1) for e0, e1 in g_ev[args.warmup:]) * 1e-3) if nccl else gather_host_s[0]
@@ -501,7 +508,12 @@ def main():
     # Measures leaf proofs/s INCLUDING their aggregation directly, in steady state.
     pipe = None
     nl = B
-    if args.aggregate != 0 and ok and nl >= 2 and (agg_state is None or not agg_state.get("error")):
+    pipe_go = args.aggregate != 0 and ok and nl >= 2 and (agg_state is None or not agg_state.get("error"))
+    if distributed:      # the block holds collectives: every rank enters it or none does (shards may differ in size)
+        pg_t = torch.tensor([1 if pipe_go else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(pg_t, op=dist.ReduceOp.MIN)
+        pipe_go = bool(pg_t.item())
+    if pipe_go:
         perr, tree = None, None
         K_pipe = 3
         try:
@@ -832,6 +844,10 @@ def main():
                                              f"{G * T} physical cores: wall {walln:.1f} s, per-proof "
                                              f"{float(pern.min()):.1f}-{float(pern.max()):.1f} s, all ok: {bool((stn == 0).all())}"}
             out["cpu_baseline"] = cb
+        # what the other ranks sit out in the final barrier (everything rank 0 did alone since the timed region ended,
+        # the collectives of the aggregation blocks included) against the process group's timeout
+        out["rank0_post_region_s"] = round(time.perf_counter() - t_region_end, 2)
+        out["collective_timeout_s"] = COLLECTIVE_TIMEOUT_S
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -25,9 +25,14 @@ def widest_arity(circuit, cap=16):
     child is the same rows again), so the best k fills a power of two.  a and b come from two small builds (k = 2, 3),
     the chosen k is built and checked (one smaller if the estimate was a few rows short).  fib-64 verifier proofs: 13
     (62,753 of 2^16 rows; 8 use 38,687, 14 need 2^17) -- profiles/r04_arity.txt."""
-    c2, c3 = circuit.build_aggregator(2), circuit.build_aggregator(3)
-    r2, r3 = int(c2.info.num_rows_used), int(c3.info.num_rows_used)
-    c2.close(); c3.close()
+    rows = {}
+    for k in (2, 3):
+        c = circuit.build_aggregator(k)
+        try:
+            rows[k] = int(c.info.num_rows_used)
+        finally:
+            c.close()
+    r2, r3 = rows[2], rows[3]
     b, a = r3 - r2, r2 - 2 * (r3 - r2)
 
     def padded(k):
@@ -36,8 +41,10 @@ def widest_arity(circuit, cap=16):
     best = min(range(2, cap + 1), key=lambda k: (padded(k) / k, -k))
     while best > 2:
         c = circuit.build_aggregator(best)
-        fits = (1 << int(c.info.degree_bits)) <= padded(best)
-        c.close()
+        try:
+            fits = (1 << int(c.info.degree_bits)) <= padded(best)
+        finally:
+            c.close()
         if fits:
             break
         best -= 1
@@ -192,6 +199,13 @@ def fold_sharded(circuit, local_leaves, arity, cdev, distributed):
             state["final"] = fold_roots(f["top"], roots)
         except Exception as e:
             state["error"] = str(e)[:300]
+    if distributed:
+        # rank 0 alone proves the cross-rank aggregate: its outcome is agreed on, so that every rank takes the same
+        # path around whatever collectives the caller issues next (a rank-0-only error used to leave the others in them)
+        fl = torch.tensor([0 if state["error"] else 1], dtype=torch.int32, device=cdev)
+        dist.all_reduce(fl, op=dist.ReduceOp.MIN)
+        if not bool(fl.item()) and not state["error"]:
+            state["error"] = "rank 0's cross-rank aggregate failed"
     state.update({"caps": caps, "tree_s_max": tree_s_max, "roots_gather_ms": gather_ms})
     return state
 

@@ -141,8 +141,12 @@ class StandInCircuit:
     def public_inputs(self, proof):
         return proof[-4:].copy()
 
+    fail_k = 0     # an aggregator of exactly this many children fails to prove (the rank-0-only failure test)
+
     def prove(self, groups, seeds=None):
         from plonky25_amd import aggregate as ag
+        if self.k and self.k == StandInCircuit.fail_k:
+            raise RuntimeError("stand-in: this aggregate cannot be proved")
         groups = np.asarray(groups, dtype=np.uint64).reshape(-1, self.k * self.WORDS)
         out = np.zeros((groups.shape[0], self.WORDS), dtype=np.uint64)
         for g in range(groups.shape[0]):
@@ -164,6 +168,24 @@ def main_aggregate(n_per_rank, arity):
     rng = np.random.default_rng(1234)                 # the same global batch on every rank
     all_leaves = rng.integers(0, 1 << 62, size=(world * n_per_rank, StandInCircuit.WORDS), dtype=np.uint64)
     mine = all_leaves[rank * n_per_rank:(rank + 1) * n_per_rank]
+    if "--fail-cross" in sys.argv:
+        # rank 0's cross-rank aggregate fails (the only aggregator with `world` children: the shard trees' arities are
+        # all different from it in this case): EVERY rank must see the error, and every rank must still be able to enter
+        # the next collective together (a rank-0-only error used to leave the other ranks in bench.py's
+        # all_reduce while rank 0 skipped it)
+        assert world not in ag.level_plan(n_per_rank, arity)
+        StandInCircuit.fail_k = world
+        st = ag.fold_sharded(StandInCircuit(), mine, arity, torch.device("cpu"), True)
+        assert st["error"], st
+        assert ("cannot be proved" in st["error"]) == (rank == 0)
+        t = torch.tensor([rank + 1], dtype=torch.int32)
+        dist.all_reduce(t)                                # all ranks arrive here: no hang, no mismatch
+        assert int(t.item()) == world * (world + 1) // 2
+        if rank == 0:
+            print("DIST_AGG_FAIL_AGREED", n_per_rank, arity)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     st = ag.fold_sharded(StandInCircuit(), mine, arity, torch.device("cpu"), True)
     assert st["error"] is None and st["ranks"] == world and st["leaves_per_rank"] == n_per_rank
     assert [l["arity"] for l in st["fold"]["levels"]] == ag.level_plan(n_per_rank, arity)

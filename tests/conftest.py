@@ -13,6 +13,14 @@ P = 0xFFFFFFFF00000001
 ARTIFACT = os.path.join(ROOT, "tests", "golden", "proof_fibonacci.json")
 
 
+def free_port():
+    """A rendezvous port the OS hands out (as bench.py does): a fixed number can collide with another job on the box."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -82,7 +82,7 @@ def test_config4_sharding_real_prover_two_ranks():
     shard of one batch; rank 0 checks the gathered proofs against the oracle."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29577",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "tests", "_dist_worker.py"), "7", "--real"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])

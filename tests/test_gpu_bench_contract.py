@@ -90,3 +90,31 @@ def test_bench_strong_scaling_mode_two_ranks():
     assert d["config"]["all_statuses_ok"] and d["config"]["gathered_complete_and_ok"] and d["config"]["oracle_verifier_accepts"]
     assert d["config"]["oracle_verified_indices"] == list(range(9))      # every gathered proof, both ranks' blocks
     assert abs(d["value"] - 9 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_four_ranks_uneven_shards_and_the_four_to_one_cross_rank_aggregate():
+    """The 4-GPU shape on the one-GPU box (test mode: four ranks on GPU 0, gloo for the collectives): --total 11 splits
+    3 + 3 + 3 + 2, every rank folds two of its proofs to a shard root, the FOUR roots are gathered and rank 0 proves the
+    4-to-1 cross-rank aggregate (a circuit no two-rank run ever builds); the pipelined trees differ per rank (3 leaves
+    against 2) around the same collectives.  Also: what rank 0 does alone after the timed region is reported and far
+    below the process group's timeout (the other ranks wait in the final barrier for that long)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--total", "11", "--steps", "2",
+                        "--warmup", "1", "--dist-backend", "gloo", "--verify", "11", "--aggregate", "2",
+                        "--aggregate-arity", "2"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["proofs_per_step_total"] == 11
+    assert [p["proofs_per_step"] for p in d["per_rank"]] == [3, 3, 3, 2]
+    assert d["config"]["all_statuses_ok"] and d["config"]["gathered_complete_and_ok"] and d["config"]["oracle_verifier_accepts"]
+    assert d["config"]["oracle_verified_indices"] == list(range(11))
+    ag = d["aggregation"]
+    assert ag["leaves"] == 8 and ag["ranks"] == 4 and [l["arity"] for l in ag["levels"]] == [2, 4]
+    assert ag["levels"][-1]["level"] == "cross-rank"
+    assert ag["root_public_inputs_commit_to_the_leaves"] is True and ag["oracle_verifier_accepts_root"] is True
+    pl = ag["pipelined"]
+    assert "error" not in pl, pl
+    assert pl["all_statuses_ok"] and pl["oracle_verifier_accepts_root"] and pl["root_public_inputs_commit_to_the_leaves"] is True
+    assert 0 < d["rank0_post_region_s"] < 0.25 * d["collective_timeout_s"]
