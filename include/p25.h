@@ -153,6 +153,11 @@ p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t l
  *   bit)` on a PoseidonGate; inputs = leaf words, sibling[4], bit, expected parent[4].
  * 11 public inputs (upstream `register_public_input(s)`): `param` inputs x_i; the circuit registers every x_i and the
  *   running products x_0 x_1, x_0 x_1 x_2, ... as public inputs (2 * param - 1 in all).
+ * 12 interleave_u32 (the reference's test_interleave_u32, src/common/u32/gadgets/interleaved_u32.rs:354-382): param 1 =
+ *   that test's circuit as written (x = constant_u32(0xFFFFFFFC), no witness inputs), param 0 = x is the one input; the
+ *   interleaved value is the circuit's public input (the test expects 0x5555555555555550).
+ * 13 uninterleave_to_u32 (test_uninterleave_to_u32, :388-417): param 1 = x = constant(0xF555555555555555), param 0 = x is
+ *   the input; public inputs = (evens, odds) (the test expects 0xC0000000, 0xFFFFFFFF).
  * Inputs = operands followed by the expected result(s); a wrong expectation fails the proof with
  * P25_ERR_WITNESS_CONFLICT, as the failing `connect` panics upstream. */
 p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** out);

@@ -850,6 +850,21 @@ Circuit build_gadget_circuit(int kind, int param) {
       }
       break;
     }
+    case GADGET_INTERLEAVE_U32: {  // the reference's test_interleave_u32 (gadgets/interleaved_u32.rs:354-382)
+      // param 1: the test's circuit as written -- x = constant_u32(0xFFFFFFFC), no witness inputs; param 0: x is an input
+      if (param != 0 && param != 1) throw std::invalid_argument("interleave gadget: param 0 (input) or 1 (the reference's constant)");
+      Target x = param ? cb.constant_u32(0xFFFFFFFCu) : in();
+      cb.register_public_input(cb.interleave_u32(x));
+      break;
+    }
+    case GADGET_UNINTERLEAVE_TO_U32: {  // test_uninterleave_to_u32 (gadgets/interleaved_u32.rs:388-417)
+      if (param != 0 && param != 1) throw std::invalid_argument("uninterleave gadget: param 0 (input) or 1 (the reference's constant)");
+      Target x = param ? cb.constant(0xF555555555555555ull) : in();
+      auto [evens, odds] = cb.uninterleave_to_u32(x);
+      cb.register_public_input(evens);
+      cb.register_public_input(odds);
+      break;
+    }
     default:
       throw std::invalid_argument("unknown gadget kind");
   }
