@@ -172,10 +172,27 @@ class Oracle:
         L.p25o_fri_prove.argtypes = [vp, ui, ui, ui, vp, sz, ui, ui, vp, sz, vp, sz]
         L.p25o_fri_prove.restype = sz
         L.p25o_prove_many.restype = C.c_double
+        L.p25o_set_tuned.argtypes = [C.c_int]
+        L.p25o_set_tuned.restype = C.c_int
+        L.p25o_x8_available.restype = C.c_int
+        L.p25o_poseidon_permute_x8.argtypes = [vp]
         L.p25o_set_threads(min(64, os.cpu_count() or 1))
 
     def set_threads(self, n):
         self.lib.p25o_set_threads(n)
+
+    def set_tuned(self, on):
+        """The tuned cpu_baseline leg: Merkle trees hashed eight at a time on AVX-512 (ref_hash_x8.cpp).  Process-wide;
+        returns whether it is now in effect (False: switched off, or the CPU has no AVX-512).  The checker leaves it off."""
+        return bool(self.lib.p25o_set_tuned(1 if on else 0))
+
+    def x8_available(self):
+        return bool(self.lib.p25o_x8_available())
+
+    def poseidon_permute_x8(self, states):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(8, 12).copy()
+        self.lib.p25o_poseidon_permute_x8(_p(s))
+        return s
 
     def load_circuit(self, blob):
         return OracleCircuit(self.lib, blob)

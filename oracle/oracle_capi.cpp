@@ -5,6 +5,7 @@
 #include "ref_hash.h"
 #include "ref_gates.h"
 #include "ref_prover.h"
+#include "ref_hash_x8.h"
 #include <atomic>
 #include <chrono>
 #include <memory>
@@ -85,6 +86,10 @@ static void put_msg(char* dst, size_t cap, const std::string& m) {
 }
 
 void p25o_set_threads(int n) { ref_set_threads(n); }
+// tuned cpu_baseline leg: AVX-512 Merkle hashing (ref_hash_x8.cpp); returns 1 if in effect (0: asked off, or no AVX-512)
+int p25o_set_tuned(int on) { return ref_set_tuned(on); }
+int p25o_x8_available() { return ref_x8_available() ? 1 : 0; }
+void p25o_poseidon_permute_x8(u64* states) { ref_poseidon_x8((u64(*)[12])states); }
 
 void* p25o_circuit_load(const unsigned char* blob, size_t len) {
   try {

@@ -1,5 +1,6 @@
 // ORACLE -- test infrastructure only (see ref_prover.h).
 #include "ref_prover.h"
+#include "ref_hash_x8.h"
 #include <string.h>
 #include <chrono>
 #include <functional>
@@ -17,6 +18,13 @@ static int g_threads = 1;
 static thread_local int tl_threads = 0;       // 0 = use the process-wide setting
 static thread_local bool tl_in_worker = false;
 void ref_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+// The tuned cpu_baseline leg (bench.py): Merkle trees hashed eight leaves / eight parents at a time on AVX-512
+// (ref_hash_x8.cpp).  Off by default: the checker runs the scalar code.  Same digests either way.
+static bool g_tuned = false;
+int ref_set_tuned(int on) {
+  g_tuned = on && ref_x8_available();
+  return g_tuned ? 1 : 0;
+}
 void ref_set_thread_local_threads(int n) { tl_threads = n < 0 ? 0 : n; }
 
 namespace {
@@ -138,9 +146,15 @@ static RMerkleTree merkle_levels(std::vector<RHash> cur, unsigned cap_height) {
   t.levels.push_back(cur);
   while (cur.size() > ((size_t)1 << cap_height)) {
     std::vector<RHash> nxt(cur.size() / 2);
-    parallel_for(nxt.size(), [&](size_t b, size_t e) {
-      for (size_t i = b; i < e; i++) nxt[i] = ref_two_to_one(cur[2 * i], cur[2 * i + 1]);
-    });
+    if (g_tuned && nxt.size() % 8 == 0) {
+      parallel_for(nxt.size() / 8, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) ref_two_to_one_x8(&cur[16 * i], &nxt[8 * i]);
+      });
+    } else {
+      parallel_for(nxt.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) nxt[i] = ref_two_to_one(cur[2 * i], cur[2 * i + 1]);
+      });
+    }
     t.levels.push_back(nxt);
     cur.swap(nxt);
   }
@@ -155,9 +169,15 @@ static RMerkleTree merkle_parallel(const std::vector<std::vector<u64>>& leaves, 
 }
 static RMerkleTree merkle_parallel_flat(const u64* leaves, size_t n_leaves, size_t width, unsigned cap_height) {
   std::vector<RHash> cur(n_leaves);
-  parallel_for(n_leaves, [&](size_t b, size_t e) {
-    for (size_t i = b; i < e; i++) cur[i] = ref_hash_or_noop(leaves + i * width, width);
-  });
+  if (g_tuned && width > 4 && n_leaves % 8 == 0) {
+    parallel_for(n_leaves / 8, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i++) ref_hash_rows_x8(leaves, width, 8 * i, &cur[8 * i]);
+    });
+  } else {
+    parallel_for(n_leaves, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i++) cur[i] = ref_hash_or_noop(leaves + i * width, width);
+    });
+  }
   return merkle_levels(std::move(cur), cap_height);
 }
 

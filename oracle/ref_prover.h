@@ -13,6 +13,7 @@
 #include "ref_circuit.h"
 #include "ref_hash.h"
 
+int ref_set_tuned(int on);                 // AVX-512 Merkle hashing for the timed baseline leg; returns what is now in effect
 void ref_set_threads(int n);               // process-wide width of parallel loops
 void ref_set_thread_local_threads(int n);  // override for the calling thread (0 = none)
 

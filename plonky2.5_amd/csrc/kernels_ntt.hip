@@ -270,7 +270,15 @@ void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st
   // the radix-16 groups index a full table of R twiddles; a 2^11-point sub-transform (2^22-point transforms) would
   // not fit the LDS a block may take with it and keeps the half table and the radix-2 network
   q.full_table = p.log_r <= 10;
-  const size_t lds = tile_lds_bytes(p.log_r, p.log_t);
+  size_t lds = tile_lds_bytes(p.log_r, p.log_t);
+#ifdef P25_EXPERIMENT_KNOBS
+  // tools/knobs_build.sh only (never the shipped library): extra dynamic LDS per block, to hold the kernel to fewer blocks per CU
+  static const size_t pad = [] {
+    const char* e = getenv("P25_X_NTT_LDS_PAD");
+    return e ? (size_t)strtoul(e, nullptr, 0) : 0;
+  }();
+  if (lds + pad <= 160 * 1024) lds += pad;
+#endif
   q.n_tiles = 1u << (p.log_nt - p.log_t);
   q.n_cosets = (uint32_t)n_cosets;
   q.xcd_map = n_cosets > 1 && (q.n_tiles & 7u) == 0;

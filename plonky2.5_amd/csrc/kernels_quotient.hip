@@ -863,10 +863,20 @@ void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   const size_t big = (size_t)1 << (a.degree_bits + a.rate_bits);
   bool rec = false;
   for (uint32_t gi = 0; gi < a.n_gates; gi++) rec |= a.gates[gi].kind >= G_ARITH_EXT;   // the recursion gate set
+  size_t lds_pad = 0;
+#ifdef P25_EXPERIMENT_KNOBS
+  // tools/knobs_build.sh only (never the shipped library): dynamic LDS the launch reserves and never touches, to hold the
+  // kernel to fewer workgroups per CU than its registers allow (round 5: does a capped quotient leave the hash kernels room?)
+  static const size_t pad = [] {
+    const char* e = getenv("P25_X_Q_LDS_PAD");
+    return e ? (size_t)strtoul(e, nullptr, 0) : 0;
+  }();
+  lds_pad = pad;
+#endif
   if (rec)
-    hipLaunchKernelGGL(k_quotient_rec, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_quotient_rec, dim3((unsigned)((big + 127) / 128)), dim3(128), lds_pad, st, a);
   else
-    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), lds_pad, st, a);
 }
 
 }  // namespace p25

@@ -18,6 +18,41 @@ def test_poseidon_v1_kats(oracle):
         assert [int(x) for x in out] == kat["output"]
 
 
+def test_tuned_avx512_poseidon_equals_the_scalar_oracle(oracle):
+    """oracle/ref_hash_x8.cpp (the tuned cpu_baseline leg of bench.py): eight permutations per call, bit-identical to the
+    scalar oracle on the reference's four known-answer vectors (poseidon2_goldilocks.rs:190-211), on edge words and on
+    random states; Merkle commitments of an LDE are the same with the switch on and off."""
+    import pytest
+    from conftest import splitmix_field
+    if not oracle.x8_available():
+        pytest.skip("no AVX-512 on this host")
+    g = json.load(open(os.path.join(GOLD, "poseidon_v1_constants.json")))
+    st = np.zeros((8, 12), dtype=np.uint64)
+    for k, kat in enumerate(g["kats"]):
+        st[k] = st[k + 4] = np.array(kat["input"], dtype=np.uint64)
+    out = oracle.poseidon_permute_x8(st)
+    for k, kat in enumerate(g["kats"]):
+        assert [int(x) for x in out[k]] == kat["output"] and [int(x) for x in out[k + 4]] == kat["output"]
+    edge = np.zeros((8, 12), dtype=np.uint64)
+    edge[1, :], edge[2, :], edge[3, :], edge[4, :] = P - 1, 0xFFFFFFFF, 1 << 32, 0xFFFFFFFF00000000
+    edge[5], edge[6], edge[7] = np.arange(12), P - 1 - np.arange(12, dtype=np.uint64), splitmix_field(12, seed=1)
+    assert (oracle.poseidon_permute_x8(edge) == oracle.poseidon_permute(edge)).all()
+    for seed in range(20):
+        s = splitmix_field(96, seed=100 + seed).reshape(8, 12)
+        assert (oracle.poseidon_permute_x8(s) == oracle.poseidon_permute(s)).all()
+    # widths on both sides of the rate: 5 (one permutation), 8, 9, 20, 135 words per leaf
+    try:
+        for width in (5, 8, 9, 20, 135):
+            vals = splitmix_field(width * 64, seed=width).reshape(width, 64)
+            assert not oracle.set_tuned(False)
+            plain = oracle.lde_commit(vals, 3, 4)
+            assert oracle.set_tuned(True)
+            tuned = oracle.lde_commit(vals, 3, 4)
+            assert all((a == b).all() for a, b in zip(plain, tuned)), width
+    finally:
+        oracle.set_tuned(False)
+
+
 def test_poseidon2_probe_vectors(oracle):
     # SURVEY.md App. C.1: Poseidon2 outputs that reproduce the artifact's Merkle roots
     z = oracle.poseidon2_permute(np.zeros(12, dtype=np.uint64))[0]

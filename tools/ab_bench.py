@@ -123,13 +123,16 @@ def main():
         elif a[i] == "--tree-streams": tstreams = a[i + 1]; i += 2
         elif a[i] == "--hwq": os.environ["GPU_MAX_HW_QUEUES"] = a[i + 1]; i += 2     # inherited by the children
         else:
-            name, _, path = a[i].partition("=")
-            libs.append((name, path or "base", tstreams)); i += 1
+            # name=path[@ENV=VAL[,ENV=VAL...]]: the environment of that variant's child processes (experiment knobs of a
+            # tools/knobs_build.sh library, e.g. q2=tools/build/variants/libp25_knobs.so@P25_X_Q_LDS_PAD=40960)
+            name, _, rest = a[i].partition("=")
+            path, _, envs = rest.partition("@")
+            libs.append((name, path or "base", tstreams, dict(kv.split("=", 1) for kv in envs.split(",") if kv))); i += 1
     for r in range(rounds):
-        for name, path, ts in libs:
+        for name, path, ts, env in libs:
             argv = (["--child5", path, str(steps)] if cfg5 else ["--child", path, str(batch), str(steps), str(agg), str(pipe), ts])
             p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv,
-                               capture_output=True, text=True)
+                               capture_output=True, text=True, env=dict(os.environ, **env))
             line = [l for l in p.stdout.splitlines() if l.startswith("AB ")]
             print(f"round {r} {name:16s} hwq {os.environ.get('GPU_MAX_HW_QUEUES', '24'):3s} tree-streams {ts:8s} {line[0][3:] if line else 'FAILED ' + p.stderr[-400:]}", flush=True)
 
