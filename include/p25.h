@@ -44,7 +44,16 @@ const char* p25_version(void);
  * The index is recorded and re-applied (hipSetDevice is per host thread) at every entry point, so calls from
  * any host thread run on this device.  Without it the first call adopts the thread's current device.
  * P25_ERR_NO_DEVICE if none. */
-p25_status p25_device_init(int device_index);
+p25_status p25_device_init(int device_index);     /* = p25_device_init_ex(device_index, P25_DEFAULT_HW_QUEUES) */
+/* Same with the number of hardware queues the HIP runtime may spread its streams over made explicit.  The library keeps
+ * 16 proofs in flight on 16 + 2 streams; ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+ * streams sharing a queue run in order (4 -> 16 queues: 78.8 -> 91.7 proofs/s).  hw_queues > 0: the variable is set for this
+ * process -- here, in this call, before the library's first HIP call, and only if the host has not exported it already; it
+ * has an effect only if HIP has not been initialised yet (a host that touches HIP first exports it itself).  hw_queues = 0:
+ * the environment is left alone.  Loading the library changes nothing in the process (rounds 1-4 set the variable from a
+ * load-time constructor). */
+#define P25_DEFAULT_HW_QUEUES 24
+p25_status p25_device_init_ex(int device_index, int hw_queues);
 
 /* ------------------------------------------------------------------------------------------
  * Primitives (host buffers; used by the parity tests).
@@ -267,7 +276,9 @@ typedef struct {
 /* Threading: like upstream's `prove(&self)`, every entry point may be called from any host thread, also concurrently
  * on ONE p25_circuit (a Rust host with a rayon pool): a circuit owns its per-proof contexts, so such
  * calls are serialised inside the library (one mutex per circuit; use the batch forms, or one circuit per thread,
- * for parallelism).  Different circuits never contend for a lock; their proofs share the device through ONE pool of 16
+ * for parallelism).  Different circuits do not contend for a lock while proving (two exceptions: building a recursive
+ * verifier / aggregator holds the INNER circuit's lock for the duration of the build, and p25_circuit_wait_mark takes both
+ * circuits' locks); their proofs share the device through ONE pool of 16
  * proving streams + 2 main streams per process (a stream set per circuit oversubscribes the hardware queues as soon as
  * two circuits are alive: DESIGN.md section 3).  With `timings` != NULL, or a batch of one, the proofs run one
  * at a time with latency-oriented kernel forms; otherwise up to 16 proofs are in flight (p25_circuit_set_streams). */
@@ -284,6 +295,22 @@ p25_status p25_prove_batch_filler(p25_circuit* c, const uint64_t* inputs, size_t
 p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t n_proofs, const uint64_t* d_seeds,
                                uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status,
                                p25_timings* timings);
+/* The same over WINDOWS of one device buffer: proof i reads its num_inputs words at
+ *   d_buffer + min(i * window_stride_words, last_window_offset_words),
+ * i.e. equally spaced windows with the LAST one right-aligned.  This is how a level of an aggregation tree proves straight on
+ * the buffer the level below wrote its proofs into, in ONE batch: an aggregator of k children takes k consecutive flat proofs
+ * (window stride = k * child proof words = its num_inputs); when k does not divide the number of children n, the last of
+ * the ceil(n / k) groups is the last k children -- offset (n - k) * child proof words -- and overlaps its neighbour.
+ * THE COMMITMENT RULE a consumer of the root's public inputs must reproduce (plonky25_amd.aggregate.level_plan /
+ * group_bounds / expected_commitment are its executable form): a level of n children folded at most `arity` at a time has
+ * G = ceil(n / arity) groups of k = ceil(n / G) children; group g < G - 1 covers children [g k, (g + 1) k), group G - 1
+ * covers [n - k, n); an aggregate's four public inputs are hash_no_pad over its children's identifiers in that order (a
+ * child's identifier = its own public inputs if it has any, hash_no_pad(its wires cap) otherwise); levels repeat until one
+ * proof is left; with N ranks every rank folds its own shard this way and one N-to-1 aggregate over the shard roots (rank
+ * order) is the final proof.  Children in an overlap are verified twice and appear twice under the root. */
+p25_status p25_prove_batch_dev_windows(p25_circuit* c, const uint64_t* d_buffer, size_t window_stride_words,
+                                       size_t last_window_offset_words, size_t n_proofs, const uint64_t* d_seeds,
+                                       uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status);
 p25_status p25_circuit_sync(p25_circuit* c);
 /* Device-side ordering between the circuit's proving streams and a stream of the caller's (a hipStream_t; NULL = the
  * legacy default stream), with NO host synchronisation -- what a host needs to consume step k's proofs (copy them out,
@@ -298,12 +325,13 @@ p25_status p25_circuit_wait_stream(p25_circuit* c, void* stream);
 /* The same between two circuits, through events only -- chaining provers on the device, e.g. an aggregation circuit
  * (p25_circuit_build_aggregator) proving straight on the buffer its children's proofs are being written to: its inputs
  * are those flat proofs back to back, so `d_inputs` of its p25_prove_batch_dev is the producer's `d_proofs`.
- *   p25_circuit_mark(c, slot):            remember the tail of every proving stream of c under `slot` (0..7)
+ *   p25_circuit_mark(c, slot):            remember the tail of every proving stream of c under `slot` (0..P25_MAX_MARKS-1)
  *   p25_circuit_wait_mark(c, producer, slot):  what c is asked for from now on starts only after the producer's mark
  * Marks are events: recording one never blocks, and a wait issued long after the mark (plonky25_amd.aggregate.DeviceTree
  * issues a level's wait one step late) finds it already satisfied, so no hardware queue stalls on it.  Upstream's
  * counterpart is host code: `builder.verify_proof` circuits proved one after the other by `data.prove(pw)`
  * (src/p3/mod.rs:260) with the proofs passed through `PartialWitness`. */
+#define P25_MAX_MARKS 16
 p25_status p25_circuit_mark(p25_circuit* c, uint32_t slot);
 p25_status p25_circuit_wait_mark(p25_circuit* c, p25_circuit* producer, uint32_t slot);
 /* ... and a stream of the caller's waiting for a mark: p25_circuit_stream_join that can be issued late (bench.py marks

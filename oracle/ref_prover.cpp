@@ -460,6 +460,23 @@ std::vector<std::vector<u64>> ref_quotient_chunks(const RCircuit& c, const RPoly
     }
     const u64 n_field = (u64)n;
     const size_t next_step = (size_t)1 << c.rate_bits;
+    if (g_tuned && big % 8 == 0 && NC <= 8) {   // the tuned leg: eight points per pass (ref_quotient_x8.cpp), same values
+      parallel_for(big / 8, [&](size_t gb, size_t ge) {
+        u64 xs[8], l0s[8], outv[8][8];
+        u64 x = rf_mul(7, rf_pow(w_big, gb * 8));
+        for (size_t g = gb; g < ge; g++) {
+          const size_t i0 = g * 8;
+          for (int j = 0; j < 8; j++, x = rf_mul(x, w_big)) {
+            xs[j] = x;
+            l0s[j] = rf_mul(zh[(i0 + j) % (1 << c.rate_bits)], rf_inv(rf_mul(n_field, rf_sub(x, 1))));
+          }
+          ref_vanishing_points_x8(c, pre.constants_sigmas, wires, zs_batch, betas.data(), gammas.data(), alphas.data(), pih, i0,
+                                  xs, l0s, outv);
+          for (int k = 0; k < NC; k++)
+            for (int j = 0; j < 8; j++) qvals[k][i0 + j] = rf_mul(outv[k][j], zh_inv[(i0 + j) % (1 << c.rate_bits)]);
+        }
+      });
+    } else
     parallel_for(big, [&](size_t ib, size_t ie) {
       std::vector<FB> consts(n_consts), sig(RW), wv(c.num_wires), z(NC), zn(NC), pp(NC * NP);
       FB outv[8];

@@ -16,6 +16,8 @@ import numpy as np
 
 __all__ = ["fold", "fold_roots", "fold_sharded", "release_fold", "DeviceTree", "circuit_throughput", "expected_commitment", "leaf_identifier_words", "level_plan", "group_bounds", "widest_arity"]
 
+MAX_MARKS = 16                    # include/p25.h P25_MAX_MARKS
+TREE_MARK_SLOTS = MAX_MARKS - 2   # DeviceTree uses slots 0 .. 13 (levels + 2 of them): 256 leaves two at a time (8 levels) fit
 CAP_WORDS = 64   # wires cap = the first 2^cap_height x 4 words of a flat proof (cap_height 4, include/p25.h proof layout)
 
 
@@ -260,9 +262,9 @@ def circuit_throughput(circ, input_row, device, count=64, steps=2):
 class DeviceTree:
     """The aggregation tree of one shard kept RESIDENT ON THE DEVICE and only ever enqueued: an aggregation circuit's
     inputs are its k children's flat proofs back to back, i.e. exactly k consecutive rows of the buffer the level
-    below writes its proofs into (proof stride = proof words), so a level is `p25_prove_batch_dev` straight on the
+    below writes its proofs into (proof stride = proof words), so a level is ONE `p25_prove_batch_dev_windows` straight on the
     previous level's output -- no host round trip, no synchronisation.  Any number of leaves and any arity: when k does
-    not divide a level's children its last group is the last k rows (`group_bounds`), one more call on the same buffer.  Ordering between the circuits is device-side
+    not divide a level's children its last group is the last k rows (`group_bounds`), the right-aligned last window of the same batch.  Ordering between the circuits is device-side
     and event-only (`p25_circuit_mark` / `p25_circuit_wait_mark`).
 
     The schedule is LAGGED: level l of step i is enqueued one step after level l-1 of step i (level 1 after the leaves
@@ -288,8 +290,8 @@ class DeviceTree:
         self.leaf, self.levels, self.build_s = circuit, [], 0.0
         plan = level_plan(n_leaves, arity)
         self.slots = len(plan) + 2
-        if self.slots > 6:     # mark slots 6 and 7 are bench.py's (the gather of the timed steps)
-            raise ValueError("tree too deep for the mark slots it may use (0..5)")
+        if self.slots > TREE_MARK_SLOTS:     # the top two mark slots are the caller's (bench.py: the gather of the timed steps)
+            raise ValueError(f"tree too deep for the mark slots it may use (0..{TREE_MARK_SLOTS - 1}): {len(plan)} levels")
         self.leaf_batch = leaf_batch or n_leaves
         lpw = int(circuit.info.proof_words)
         self.leaf_buf = [torch.zeros((self.leaf_batch, lpw), dtype=torch.int64, device=device) for _ in range(self.slots)]
@@ -339,16 +341,12 @@ class DeviceTree:
             if i >= S and l + 1 < len(circs):            # the level above has finished reading out[s] of step i - S
                 c.wait_mark(circs[l + 1], s)
             below = self.leaf_buf[s][:self.n_leaves] if l == 1 else self.levels[l - 2]["out"][s]
-            # groups 0 .. n-2 are consecutive rows of `below`; the last one is its last k rows (group_bounds): a second
-            # call when k does not divide the number of children, the same batch otherwise
+            # groups 0 .. n-2 are consecutive windows of k rows of `below`, the last one its last k rows (group_bounds): ONE
+            # batch either way (p25_prove_batch_dev_windows; a separate batch-of-one call for the overlapping group, as rounds
+            # 3-4 issued it, runs that proof alone with the latency-oriented kernel forms)
             n, k, pw = L["n"], L["k"], L["pw"]
-            exact = n * k == L["children"]
-            head = n if exact else n - 1
-            if head:
-                c.prove_dev(below.data_ptr(), head, L["seeds"].data_ptr(), L["out"][s].data_ptr(), pw, L["status"][s].data_ptr())
-            if not exact:
-                c.prove_dev(below.data_ptr() + (L["children"] - k) * L["cpw"] * 8, 1, L["seeds"].data_ptr() + head * 8,
-                            L["out"][s].data_ptr() + head * pw * 8, pw, L["status"][s].data_ptr() + head * 4)
+            c.prove_dev_windows(below.data_ptr(), k * L["cpw"], (L["children"] - k) * L["cpw"], n, L["seeds"].data_ptr(),
+                                L["out"][s].data_ptr(), pw, L["status"][s].data_ptr())
             c.mark(s)
         self.host_steps += 1
 

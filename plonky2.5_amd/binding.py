@@ -151,6 +151,8 @@ EXPORTED_SYMBOLS = {
     "p25_prove_batch": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
     "p25_prove_batch_filler": (i32, [vp, vp, sz, vp, vp, sz, vp]),
     "p25_prove_batch_dev": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(Timings)]),
+    "p25_prove_batch_dev_windows": (i32, [vp, vp, sz, sz, sz, vp, vp, sz, vp]),
+    "p25_device_init_ex": (i32, [C.c_int, C.c_int]),
     "p25_circuit_sync": (i32, [vp]),
     "p25_circuit_stream_join": (i32, [vp, vp]),
     "p25_circuit_wait_stream": (i32, [vp, vp]),
@@ -205,8 +207,12 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def device_init(index=0):
-    _check(lib().p25_device_init(index))
+def device_init(index=0, hw_queues=None):
+    """p25_device_init / p25_device_init_ex: hw_queues None = the library's default (24), 0 = leave GPU_MAX_HW_QUEUES alone."""
+    if hw_queues is None:
+        _check(lib().p25_device_init(index))
+    else:
+        _check(lib().p25_device_init_ex(index, hw_queues))
 
 
 def shader_clock_hz():
@@ -541,6 +547,11 @@ class Circuit:
         _check(lib().p25_prove_batch_dev(self._h, d_inputs, n_proofs, d_seeds, d_proofs, proof_stride, d_status,
                                          C.byref(timings) if timings is not None else None))
 
+    def prove_dev_windows(self, d_buffer, window_stride, last_window_offset, n_proofs, d_seeds, d_proofs, proof_stride, d_status):
+        """p25_prove_batch_dev_windows: proof i reads its inputs at d_buffer + min(i * window_stride, last_window_offset) words."""
+        _check(lib().p25_prove_batch_dev_windows(self._h, d_buffer, window_stride, last_window_offset, n_proofs, d_seeds,
+                                                 d_proofs, proof_stride, d_status))
+
     def sync(self):
         _check(lib().p25_circuit_sync(self._h))
 
@@ -553,7 +564,7 @@ class Circuit:
         _check(lib().p25_circuit_wait_stream(self._h, C.c_void_p(stream)))
 
     def mark(self, slot):
-        """Remember the tail of every proving stream under `slot` (0..7); see wait_mark."""
+        """Remember the tail of every proving stream under `slot` (0..15, P25_MAX_MARKS); see wait_mark."""
         _check(lib().p25_circuit_mark(self._h, slot))
 
     def stream_wait_mark(self, slot, stream):

@@ -102,12 +102,19 @@ const char* p25_version(void) { return "libp25 0.1 (gfx950)"; }
 // The prover keeps up to 16 proofs in flight on separate HIP streams so that the latency-bound stretches of
 // one proof overlap the VALU-bound kernels of others.  ROCclr multiplexes streams onto
 // GPU_MAX_HW_QUEUES hardware queues (default 4), and streams sharing a queue serialise: 16 queues
-// measured 78.8 -> 91.7 proofs/s on one MI355X (12 streams); 24 queues with 16 streams a further 1.5%.  The variable is read when the HIP runtime
-// initialises, so it is set when this library is loaded (never overriding the caller's choice); a host
-// that initialises HIP before loading libp25 should export it itself.
-__attribute__((constructor)) static void p25_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// measured 78.8 -> 91.7 proofs/s on one MI355X (12 streams); 24 queues with 16 streams a further 1.5%.  The variable is read
+// when the HIP runtime initialises, so the library asks for it in p25_device_init_ex -- an explicit call with an explicit
+// argument, before its first HIP call, never overriding a value the host has exported -- and NOT when it is loaded (rounds
+// 1-4 did that from a constructor: a process-wide side effect a host had no say in).  A host that initialises HIP before
+// that call exports the variable itself.
+p25_status p25_device_init(int device_index) { return p25_device_init_ex(device_index, P25_DEFAULT_HW_QUEUES); }
 
-p25_status p25_device_init(int device_index) {
+p25_status p25_device_init_ex(int device_index, int hw_queues) {
+  if (hw_queues < 0 || hw_queues > 128) {
+    g_last_error = "hw_queues out of range (0 = leave the runtime's setting alone)";
+    return P25_ERR_INVALID_ARG;
+  }
+  if (hw_queues > 0) setenv("GPU_MAX_HW_QUEUES", std::to_string(hw_queues).c_str(), 0);   // before the first HIP call below
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     g_last_error = "no HIP device available (libp25 has no CPU fallback)";
@@ -607,6 +614,22 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
     p25::PhaseTimes pt;
     d.prove_batch_dev(d_inputs, n_proofs, d_seeds, d_proofs, proof_stride_words, d_status, timings ? &pt : nullptr);
     fill_timings(timings, pt);
+    return P25_OK;
+  });
+}
+p25_status p25_prove_batch_dev_windows(p25_circuit* c, const uint64_t* d_buffer, size_t window_stride_words,
+                                       size_t last_window_offset_words, size_t n_proofs, const uint64_t* d_seeds,
+                                       uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status) {
+  return guarded([&]() -> p25_status {
+    if (!c || !d_buffer || !d_seeds || !d_proofs || !d_status) throw std::invalid_argument("null argument");
+    if (window_stride_words == 0) throw std::invalid_argument("window stride is zero");
+    if (n_proofs && last_window_offset_words > (n_proofs - 1) * window_stride_words)
+      throw std::invalid_argument("last window lies beyond the windows before it");
+    P25_LOCK(c);
+    p25::DeviceCircuit& d = c->device();
+    if (proof_stride_words < d.layout().total) throw std::invalid_argument("proof_stride smaller than the proof");
+    d.prove_batch_dev(d_buffer, n_proofs, d_seeds, d_proofs, proof_stride_words, d_status, nullptr, nullptr,
+                      window_stride_words, last_window_offset_words);
     return P25_OK;
   });
 }

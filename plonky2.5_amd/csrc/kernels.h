@@ -73,6 +73,7 @@ struct NttPass {
   const u64* post_i;     // optional [R]
   int inverse;           // pow_table holds powers of the INVERSE root (selects the 16th-root constants of kernels_ntt.hip)
   uint32_t n_tiles, n_cosets, xcd_map, full_table;  // set by launch_ntt_pass
+  uint32_t n_polys, n_blocks_total;                  // set by launch_ntt_pass
 };
 void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st);
 // Shader clock (Hz) under a full-chip Poseidon load, from in-kernel cycle and wall-clock counters (kernels_hash.hip).

@@ -13,12 +13,12 @@
 #include <stdlib.h>
 #include "kernels.h"
 #include "poseidon.h"
-#include "poseidon_mfma.h"
 #include "poseidon2.h"
 #include "coop.h"
 #include "coop_lat.h"
 // Build switches (tools/hash_variants.sh builds the variants): which kernels take the wave-wide permutation of
-// poseidon_mfma.h (full-round MDS layers on the matrix cores) and the occupancy they are compiled for.
+// tools/poseidon_mfma.h (full-round MDS layers on the matrix cores; an experiment kept under tools/, not product code)
+// and the occupancy they are compiled for.
 // Measured on MI355X (profiles/r03_mfma_*.txt): the MFMA form executes 10 % fewer VALU instructions per permutation and
 // is 5 % faster standalone (2726 vs 2593 Mperm/s), but needs 128 VGPRs (4 waves per SIMD instead of 6) and each of its
 // 168 MFMAs holds the SIMD's VALU issue for ~13 cycles; in the 16-stream proving pipeline that is +0.4 % (leaf + tree)
@@ -28,6 +28,9 @@
 #endif
 #ifndef P25_TREE_MX
 #define P25_TREE_MX 0
+#endif
+#if P25_LEAF_MX || P25_TREE_MX
+#include "poseidon_mfma.h"   // tools/poseidon_mfma.h: experiment builds only (tools/hash_variants.sh adds -I tools); never in libp25.so
 #endif
 #ifndef P25_LEAF_MINW
 #define P25_LEAF_MINW (P25_LEAF_MX ? 4 : 6)

@@ -32,6 +32,9 @@
 // transforms above 2^P25_NTT_FACTOR_LOG points take the coset pre-scale as two factor tables (ntt_lde_bitrev)
 // (Phase priorities -- load / store phases of k_ntt_tile above or below its butterflies -- were measured in round 4 and
 // change nothing: profiles/r04_ab_ntt_phase_priority.txt.)
+#ifndef P25_NTT_PERSIST
+#define P25_NTT_PERSIST 0
+#endif
 #ifndef P25_NTT_FACTOR_LOG
 #define P25_NTT_FACTOR_LOG 16
 #endif
@@ -103,14 +106,30 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
   // With xcd_map the 1-D grid is decoded so that the n_cosets blocks reading the SAME coefficient tile run on the
   // same XCD back to back (the tile is fetched from HBM once, not once per coset) and an XCD only ever touches
   // tiles = xcd (mod 8), i.e. 1/8 of the per-coset pre-scale table, which then stays L2-resident across polynomials.
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int wstride_log = a.log_n_table - a.log_r;  // w_R^k = w_N^(k * N/R)
+  for (int k = tid; k < (a.full_table ? R : R / 2); k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
+  // P25_NTT_PERSIST (experiment, tools/knobs_build.sh): a 1-D grid that may hold fewer blocks than there are tiles; a block
+  // then walks the tiles grid-stride (a multiple of 8 apart, so it stays on its XCD's share), twiddles staged once.
+#if P25_NTT_PERSIST
+  for (u32 L = blockIdx.x; L < a.n_blocks_total; L += gridDim.x) {
+  if (L != blockIdx.x) __syncthreads();   // the previous tile's stores have read the LDS this tile's loads overwrite
+#else
+  {
+  const u32 L = blockIdx.x;
+#endif
   u32 tile, poly, coset;
   if (a.xcd_map) {
-    const u32 L = blockIdx.x, xcd = L & 7u, m = L >> 3;
+    const u32 xcd = L & 7u, m = L >> 3;
     const u32 tiles8 = a.n_tiles >> 3;
     coset = m % a.n_cosets;
     const u32 r = m / a.n_cosets;
     tile = (r % tiles8) * 8 + xcd;
     poly = r / tiles8;
+  } else if (P25_NTT_PERSIST) {   // 1-D grid: tile fastest, then polynomial, then coset (the 3-D grid's order)
+    tile = L % a.n_tiles;
+    poly = (L / a.n_tiles) % a.n_polys;
+    coset = L / (a.n_tiles * a.n_polys);
   } else {
     tile = blockIdx.x;
     poly = blockIdx.y;
@@ -119,11 +138,6 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
   const u32 tg0 = tile * T;
   const u64* in = a.in + (size_t)poly * a.in_poly_stride;
   u64* out = a.out + (size_t)poly * a.out_poly_stride + a.coset_out_off[coset];
-  const int tid = threadIdx.x, nth = blockDim.x;
-  const int wstride_log = a.log_n_table - a.log_r;  // w_R^k = w_N^(k * N/R)
-
-  for (int k = tid; k < (a.full_table ? R : R / 2); k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
-
   // coset pre-scale: one table entry per input coefficient (shift_c^k at the coefficient's address k) ...
   const u64* pre = PRE == 1 ? a.pre + ((size_t)coset << (a.log_r + a.log_nt)) : nullptr;
   // ... or its two factors shift_c^t * (shift_c^NT)^i when N is too large for the table to live in L2 (2^19-row circuits:
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
     if (a.post_t) x = gl::mul(x, gl::mul(a.post_t[tw], a.post_i[j]));
     out[addr] = x;
   }
+  }
 }
 
 // LDS bytes of a tile: R rows of T (+1 padding) words + the sub-transform's twiddle table
@@ -283,6 +298,18 @@ void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st
   q.n_cosets = (uint32_t)n_cosets;
   q.xcd_map = n_cosets > 1 && (q.n_tiles & 7u) == 0;
   dim3 grid = q.xcd_map ? dim3(q.n_tiles * (uint32_t)n_polys * (uint32_t)n_cosets) : dim3(q.n_tiles, n_polys, n_cosets);
+  q.n_polys = (uint32_t)n_polys;
+  q.n_blocks_total = q.n_tiles * (uint32_t)n_polys * (uint32_t)n_cosets;
+#if P25_NTT_PERSIST
+  grid = dim3(q.n_blocks_total);
+#if defined(P25_EXPERIMENT_KNOBS)
+  static const unsigned cap = [] {
+    const char* e = getenv("P25_X_NTT_GRID");
+    return e ? (unsigned)strtoul(e, nullptr, 0) & ~7u : 0u;
+  }();
+  if (cap && grid.x > cap) grid = dim3(cap);
+#endif
+#endif
   // tiles of 2^13 elements (16-wide tiles of 512-point sub-transforms: 2^19-point transforms, BASELINE config 5) take
   // 512 threads, so that a CU's two resident blocks still give every SIMD four waves; above 64 KB of dynamic LDS the
   // function attribute has to allow it (a workgroup may take up to 160 KB on gfx950)
@@ -290,10 +317,13 @@ void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st
   const int pre_mode = q.pre ? 1 : (q.pre_t ? 2 : 0);
   auto launch = [&](auto kernel, int nth) {
     if (lds > 64 * 1024) {   // above 64 KB of dynamic LDS the function attribute has to allow it (160 KB per workgroup on gfx950)
+      // the attribute belongs to the CURRENT device's function object (the stream pool serves several devices per process)
       static std::mutex mu;
-      static std::set<const void*> allowed;
+      static std::set<std::pair<int, const void*>> allowed;
+      int dev = 0;
+      P25_HIP(hipGetDevice(&dev));
       std::lock_guard<std::mutex> lk(mu);
-      if (allowed.insert((const void*)kernel).second)
+      if (allowed.insert({dev, (const void*)kernel}).second)
         P25_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     hipLaunchKernelGGL(kernel, grid, dim3(nth), lds, st, q);

@@ -543,6 +543,9 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
 #ifndef P25_Q_PF
 #define P25_Q_PF 1
 #endif
+#ifndef P25_Q_PERSIST
+#define P25_Q_PERSIST 0
+#endif
 #ifndef P25_QREC_PRIO
 #define P25_QREC_PRIO P25_PRIO_BULK
 #endif
@@ -569,8 +572,18 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   __syncthreads();
   const uint32_t lde_bits = a.degree_bits + a.rate_bits;
   const size_t big = (size_t)1 << lde_bits;
+  // P25_Q_PERSIST (experiment, tools/knobs_build.sh): the grid may hold fewer blocks than there are 128-point blocks; a
+  // block then walks them grid-stride, its alpha-power tables staged once.  A launch that fits the chip is dispatched at
+  // once (its hardware queue's pipe is free for the next queue) and holds at most grid / 256 blocks per CU.
+#if P25_Q_PERSIST
+  for (size_t pblk = blockIdx.x; pblk * blockDim.x < big; pblk += gridDim.x) {
+  const size_t p = pblk * blockDim.x + threadIdx.x;  // bit-reversed position
+  if (p >= big) break;
+#else
+  {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // bit-reversed position
   if (p >= big) return;
+#endif
   const uint32_t i_nat = gl::bitrev((u32)p, lde_bits);
   const u64 x = gl::mul(gl::GENERATOR, a.pow_big[i_nat]);
   const uint32_t rate_mask = (1u << a.rate_bits) - 1;
@@ -822,6 +835,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   }
   a.out[p] = gl::mul(res[0], zhi);
   a.out[big + p] = gl::mul(res[1], zhi);
+  }
 }
 
 __global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
@@ -873,10 +887,18 @@ void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   }();
   lds_pad = pad;
 #endif
+  unsigned grid = (unsigned)((big + 127) / 128);
+#if defined(P25_EXPERIMENT_KNOBS) && P25_Q_PERSIST
+  static const unsigned cap = [] {
+    const char* e = getenv("P25_X_Q_GRID");
+    return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
+  }();
+  if (cap && grid > cap) grid = cap;
+#endif
   if (rec)
-    hipLaunchKernelGGL(k_quotient_rec, dim3((unsigned)((big + 127) / 128)), dim3(128), lds_pad, st, a);
+    hipLaunchKernelGGL(k_quotient_rec, dim3(grid), dim3(128), lds_pad, st, a);
   else
-    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((big + 127) / 128)), dim3(128), lds_pad, st, a);
+    hipLaunchKernelGGL(k_quotient, dim3(grid), dim3(128), lds_pad, st, a);
 }
 
 }  // namespace p25

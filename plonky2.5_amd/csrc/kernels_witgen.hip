@@ -373,7 +373,11 @@ __global__ __launch_bounds__(256) void k_witgen_level_fused(const WitGen* __rest
 // connected to an earlier input is compared with it (P25_ERR_WITNESS_CONFLICT on mismatch; upstream panics
 // "was set twice with different values") instead of racing it for the slot.  This is the first kernel of a
 // proof, so when both happen the smaller code is reported (deterministic within the launch).
-__global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, const uint32_t* __restrict__ input_slots,
+// Proof p of the pass (the call's proof p0 + p) reads its n_inputs words at inputs + min((p0 + p) * in_stride, in_max_off):
+// in_stride = n_inputs and no bound for a plain [n_proofs][n_inputs] array; windows over a buffer with the last one
+// right-aligned for p25_prove_batch_dev_windows (an aggregation level proving on its children's proofs).
+__global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, size_t in_stride, size_t in_max_off, size_t p0,
+                                    const uint32_t* __restrict__ input_slots,
                                     const uint32_t* __restrict__ input_first, uint32_t n_inputs,
                                     u64* __restrict__ vals, size_t B, uint32_t n_proofs,
                                     uint32_t* __restrict__ status) {
@@ -387,14 +391,16 @@ __global__ void k_witgen_set_inputs(const u64* __restrict__ inputs, const uint32
   if (i == n_inputs) {
     vals[p] = 0;
   } else {
-    u64 v = inputs[(size_t)p * n_inputs + i];
+    size_t off = (p0 + p) * in_stride;
+    if (off > in_max_off) off = in_max_off;
+    u64 v = inputs[off + i];
     if (v >= gl::P) {
       v -= gl::P;
       flag(1);  // P25_ERR_INVALID_ARG
     }
     const uint32_t a = input_slots[i];
     if (a & WIT_CHECK_FLAG) {
-      u64 w = inputs[(size_t)p * n_inputs + input_first[i]];
+      u64 w = inputs[off + input_first[i]];
       if (w >= gl::P) w -= gl::P;
       if (w != v) flag(4);  // P25_ERR_WITNESS_CONFLICT
     } else {
@@ -414,10 +420,12 @@ __global__ void k_witgen_fill_wires(const u64* __restrict__ vals, size_t B, uint
 }
 
 void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u64* d_seeds, u64* d_vals,
-                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st, const u64* d_filler) {
+                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st, const u64* d_filler,
+                   size_t in_stride, size_t in_max_off, size_t p0) {
   size_t tot = (size_t)(wp.n_inputs + 1) * n_proofs;
-  hipLaunchKernelGGL(k_witgen_set_inputs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_inputs,
-                     wp.d_input_slots, wp.d_input_first, wp.n_inputs, d_vals, B, n_proofs, d_status);
+  if (in_stride == 0) in_stride = wp.n_inputs;
+  hipLaunchKernelGGL(k_witgen_set_inputs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_inputs, in_stride,
+                     in_max_off, p0, wp.d_input_slots, wp.d_input_first, wp.n_inputs, d_vals, B, n_proofs, d_status);
   for (size_t l = 0; l + 1 < wp.level_start.size(); l++) {
     uint32_t b = wp.level_start[l], cnt = wp.level_start[l + 1] - b;
     if (!cnt) continue;

@@ -96,8 +96,10 @@ class DeviceCircuit {
 
   // Device-resident API used by bench.py: inputs already in HBM ([n_proofs][num_inputs]), proofs
   // written to a device buffer; asynchronous on the internal stream until sync().
+  // in_stride / in_max_off: proof p reads its inputs at d_inputs + min(p * in_stride, in_max_off) words (0 / -1: the plain array)
   void prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs, size_t proof_stride,
-                       uint32_t* d_status, PhaseTimes* times, const u64* d_filler = nullptr);
+                       uint32_t* d_status, PhaseTimes* times, const u64* d_filler = nullptr, size_t in_stride = 0,
+                       size_t in_max_off = (size_t)-1);
   void sync();
   // Device-side ordering against a caller's stream, no host synchronisation (the multi-GPU gather runs on a side
   // stream underneath the next step's proofs):
@@ -109,7 +111,7 @@ class DeviceCircuit {
   // queue in front of unrelated work): mark(slot) records the tail of every proving stream of this circuit;
   // wait_mark(producer, slot) makes everything this circuit enqueues from now on wait for the producer's mark.
   // A level of an aggregation tree proves straight on the buffer the level below wrote (plonky25_amd.aggregate).
-  static constexpr int MAX_MARKS = 8;
+  static constexpr int MAX_MARKS = 16;   // include/p25.h: P25_MAX_MARKS
   void mark(int slot);
   void wait_mark(DeviceCircuit& producer, int slot);
   void stream_wait_mark(hipStream_t ext, int slot);   // a caller's stream waits for mark(slot) (stream_join, but lag-able)

@@ -35,6 +35,12 @@ struct StreamPool {
     cursor += count;
     return first;
   }
+  // A circuit asked for more proofs in flight after its first context existed (p25_circuit_set_streams(32) on a live
+  // circuit): the pool grows with it, so that contexts i and i + 16 do not silently share a stream.
+  void widen(size_t want_width) {
+    std::lock_guard<std::mutex> l(mu);
+    if (want_width > width) width = want_width;
+  }
   // Main streams (a circuit's witness passes): two per device.  The first circuit of the process to ask keeps one to
   // itself for as long as it lives (the leaf circuit of a batch prover, whose passes run under its own proving all the
   // time); every other circuit shares the second (the levels of an aggregation tree: a pass of at most 32 proofs per
@@ -435,6 +441,7 @@ void DeviceCircuit::ensure_ctx(size_t count) {
   Ctx& x = *ctxs_.back();
   if (P25_STREAM_POOL) {
     if (ctxs_.size() == 1) pool_first_ = g_stream_pool.reserve(count, (size_t)streams_);
+    else g_stream_pool.widen((size_t)streams_);
     x.st = g_stream_pool.at(pool_first_ + ctxs_.size() - 1);
   } else {
     P25_HIP(hipStreamCreate(&x.st));
@@ -910,7 +917,8 @@ size_t DeviceCircuit::ctx_bytes() const {
 }
 
 void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const u64* d_seeds, u64* d_proofs,
-                                    size_t proof_stride, uint32_t* d_status, PhaseTimes* times, const u64* d_filler) {
+                                    size_t proof_stride, uint32_t* d_status, PhaseTimes* times, const u64* d_filler,
+                                    size_t in_stride, size_t in_max_off) {
   size_t K = times ? 1 : (size_t)streams_;
   if (K > n_proofs) K = n_proofs ? n_proofs : 1;
   if (K > ctxs_.size()) {
@@ -950,8 +958,8 @@ void DeviceCircuit::prove_batch_dev(const u64* d_inputs, size_t n_proofs, const 
       P25_HIP(hipEventCreate(&e1));
       P25_HIP(hipEventRecord(e0, stream_));
     }
-    launch_witgen(wp_, d_inputs + base * wp_.n_inputs, d_seeds + base, vals_[buf].p, bsz, (uint32_t)bsz, d_status + base,
-                  stream_, d_filler ? d_filler + base * wp_.num_random_fill : nullptr);
+    launch_witgen(wp_, d_inputs, d_seeds + base, vals_[buf].p, bsz, (uint32_t)bsz, d_status + base,
+                  stream_, d_filler ? d_filler + base * wp_.num_random_fill : nullptr, in_stride, in_max_off, base);
     P25_HIP(hipEventRecord(ev_witness_[buf], stream_));
     if (times) {
       P25_HIP(hipEventRecord(e1, stream_));

@@ -28,8 +28,10 @@ struct DeviceWitnessProgram {
 __device__ __forceinline__ void set_status(uint32_t* status, uint32_t code) { atomicCAS(status, 0u, code); }
 #endif
 // d_filler (nullable): explicit RandomValueGenerator values [n_proofs][num_random_fill] used instead of the seeds
+// Proof p of the pass reads its inputs at d_inputs + min((p0 + p) * in_stride, in_max_off)  (in_stride 0 = n_inputs).
 void launch_witgen(const DeviceWitnessProgram& wp, const u64* d_inputs, const u64* d_seeds, u64* d_vals,
-                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st, const u64* d_filler = nullptr);
+                   size_t B, uint32_t n_proofs, uint32_t* d_status, hipStream_t st, const u64* d_filler = nullptr,
+                   size_t in_stride = 0, size_t in_max_off = (size_t)-1, size_t p0 = 0);
 void launch_fill_wires(const DeviceWitnessProgram& wp, const u64* d_vals, size_t B, uint32_t p, u64* d_wires,
                        hipStream_t st);
 

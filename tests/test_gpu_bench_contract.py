@@ -32,7 +32,11 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
-    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] == 1
+    assert cb["kind"] in ("port", "port-tuned", "reference") and cb["value"] > 0 and cb["cores"] == 1
+    if cb["kind"] == "port-tuned":      # the AVX-512 leg: validated against the scalar oracle's proof, which stays beside it
+        assert cb["bytes_equal_to_the_scalar_oracle_proof"] is True
+        assert cb["untuned"]["kind"] == "port" and 0 < cb["untuned"]["value"] < cb["value"]
+        assert cb["untuned"]["gpu_proof_bit_exact_vs_this_cpu_proof"] is True
     assert cb["all_cores"]["cores"] == 4 and cb["all_cores"]["value"] > 0
     # the roofline line is the kernel with the GPU to itself; the in-flight figure is reported beside it
     assert rf["launches"] == 8 and rf["avg_launch_ms"] > 0 and rf["avg_launch_ms_timed_region"] >= 0.9 * rf["avg_launch_ms"]
