@@ -344,7 +344,9 @@ p25_status p25_circuit_stream_wait_mark(p25_circuit* c, uint32_t slot, void* str
 p25_status p25_circuit_set_streams(p25_circuit* c, int32_t n_streams);
 /* Measurement hook for bench.py's roofline line: when enabled, HIP events on the proving stream
  * bracket every launch of the dominant kernel (the Poseidon leaf sponge over the 135-column wires
- * LDE).  Returns accumulated device milliseconds and launch count; reset != 0 clears them. */
+ * LDE).  Returns accumulated device milliseconds and launch count; reset != 0 clears them.  The proving streams belong to
+ * a process-wide pool: with more than one circuit proving at the same time the bracket also spans the other circuits'
+ * kernels on that stream, so enable it while exactly one circuit is active (bench.py does). */
 p25_status p25_circuit_kernel_stats(p25_circuit* c, int enable, int reset, double* ms_out, uint64_t* launches_out);
 /* Measurement hook: the shader clock (Hz) under a full-chip Poseidon load, from the in-kernel cycle counter against
  * the constant-rate wall-clock counter; bench.py prices its VALU-instruction view with it instead of a nominal clock. */

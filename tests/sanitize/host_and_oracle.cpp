@@ -24,6 +24,7 @@ size_t p25o_proof_words(void* h);
 int p25o_prove(void* h, const u64* inputs, u64 seed, u64* proof_out, double* timings_out, char* msg, size_t msglen);
 int p25o_verify(void* h, const u64* digest4, const u64* cs_cap, const u64* proof_words, char* msg, size_t msglen);
 void p25o_set_threads(int n);
+int p25o_set_tuned(int on);
 }
 using namespace p25;
 #define CHECK(c) do { if (!(c)) { printf("CHECK FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
@@ -157,6 +158,12 @@ int main() {
   double tm[16];
   CHECK(p25o_prove(h, inp.data(), 1, proof.data(), tm, msg, sizeof msg) == 0);
   CHECK(p25o_verify(h, dg, cap.data(), proof.data(), msg, sizeof msg) == 0);
+  if (p25o_set_tuned(1)) {   // the AVX-512 leg of the cpu_baseline (ref_hash_x8.cpp, ref_quotient_x8.cpp): same bytes
+    std::vector<u64> tuned(proof.size());
+    CHECK(p25o_prove(h, inp.data(), 1, tuned.data(), tm, msg, sizeof msg) == 0);
+    CHECK(tuned == proof);
+    p25o_set_tuned(0);
+  }
   proof[100] ^= 1;
   CHECK(p25o_verify(h, dg, cap.data(), proof.data(), msg, sizeof msg) != 0);
   std::vector<u64> bad(inp);
