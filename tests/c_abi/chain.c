@@ -92,7 +92,7 @@ int main(void) {
     return 1;
   }
   /* argument checks of the ordering entry points */
-  if (p25_circuit_mark(leaf, 8) != P25_ERR_INVALID_ARG || p25_circuit_wait_mark(agg, agg, 0) != P25_ERR_INVALID_ARG ||
+  if (p25_circuit_mark(leaf, P25_MAX_MARKS) != P25_ERR_INVALID_ARG || p25_circuit_wait_mark(agg, agg, 0) != P25_ERR_INVALID_ARG ||
       p25_circuit_wait_mark(NULL, leaf, 0) != P25_ERR_INVALID_ARG) {
     fprintf(stderr, "ordering entry points accepted bad arguments\n");
     return 1;

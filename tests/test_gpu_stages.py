@@ -133,11 +133,12 @@ def test_openings_vs_oracle(gpu, oracle, log_n, n_polys):
 
 
 def test_mark_and_wait_mark_argument_checks(gpu, small):
-    """The event-ordering entry points refuse what cannot be right (status codes, never UB): slots beyond 0..7, a circuit
+    """The event-ordering entry points refuse what cannot be right (status codes, never UB): slots beyond 0..15 (P25_MAX_MARKS), a circuit
     waiting for its own mark (its streams are already in order), null handles."""
     c, _oc, _wires = small
     other = gpu.Circuit.build_gadget(0, 0)
-    for slot in (8, 1 << 20):
+    c.mark(15)                                  # the last valid slot
+    for slot in (16, 1 << 20):
         with pytest.raises(gpu.P25Error) as e:
             c.mark(slot)
         assert e.value.status == 1
