@@ -91,6 +91,56 @@ int main(void) {
     fprintf(stderr, "the device-chained aggregate differs from the host-path aggregate\n");
     return 1;
   }
+  /* ---- windows of one buffer (p25_prove_batch_dev_windows): three leaves under a 2-ary aggregator -> groups (0, 1) and,
+   * right-aligned and overlapping, (1, 2), in ONE batch straight on the leaves' device buffer; the host path proves the two
+   * groups from explicit copies and must give the same bytes */
+  {
+    const uint64_t x2 = 0x5555AAAA5555AAAAull, y2 = 0x0F0F0F0FF0F0F0F0ull;
+    uint64_t in3[9] = {x0, y0, x0 & y0, x1, y1, x1 & y1, x2, y2, x2 & y2};
+    uint64_t seeds3[3] = {7, 8, 11}, seeds_w[2] = {9, 10};
+    uint64_t* h3 = (uint64_t*)calloc(3 * lw, 8);
+    uint64_t* groups = (uint64_t*)calloc(4 * lw, 8);
+    uint64_t* h_w = (uint64_t*)calloc(2 * aw, 8);
+    p25_status st3[3], stw[2];
+    CHECK(p25_prove_batch(leaf, in3, 3, seeds3, h3, lw, st3, NULL));
+    memcpy(groups, h3, 2 * lw * 8);                      /* leaves 0, 1 */
+    memcpy(groups + 2 * lw, h3 + lw, 2 * lw * 8);        /* leaves 1, 2 */
+    CHECK(p25_prove_batch(agg, groups, 2, seeds_w, h_w, aw, stw, NULL));
+    if (st3[0] || st3[1] || st3[2] || stw[0] || stw[1]) { fprintf(stderr, "windows: host path statuses\n"); return 1; }
+    uint64_t *d_in3, *d_s3, *d_l3, *d_sw, *d_w;
+    uint32_t* d_stw;
+    HIP(hipMalloc((void**)&d_in3, sizeof in3));
+    HIP(hipMalloc((void**)&d_s3, sizeof seeds3));
+    HIP(hipMalloc((void**)&d_l3, 3 * lw * 8));
+    HIP(hipMalloc((void**)&d_sw, sizeof seeds_w));
+    HIP(hipMalloc((void**)&d_w, 2 * aw * 8));
+    HIP(hipMalloc((void**)&d_stw, 32));
+    HIP(hipMemcpy(d_in3, in3, sizeof in3, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(d_s3, seeds3, sizeof seeds3, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(d_sw, seeds_w, sizeof seeds_w, hipMemcpyHostToDevice));
+    CHECK(p25_prove_batch_dev(leaf, d_in3, 3, d_s3, d_l3, lw, d_stw + 2, NULL));
+    CHECK(p25_circuit_mark(leaf, 2));
+    CHECK(p25_circuit_wait_mark(agg, leaf, 2));
+    CHECK(p25_prove_batch_dev_windows(agg, d_l3, 2 * lw, 1 * lw, 2, d_sw, d_w, aw, d_stw));
+    CHECK(p25_circuit_sync(agg));
+    CHECK(p25_circuit_sync(leaf));
+    uint64_t* back_w = (uint64_t*)calloc(2 * aw, 8);
+    uint32_t dstw[2] = {1, 1};
+    HIP(hipMemcpy(back_w, d_w, 2 * aw * 8, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(dstw, d_stw, 8, hipMemcpyDeviceToHost));
+    if (dstw[0] || dstw[1] || memcmp(back_w, h_w, 2 * aw * 8) != 0) {
+      fprintf(stderr, "windows: the batch over windows differs from the host path (statuses %u %u)\n", dstw[0], dstw[1]);
+      return 1;
+    }
+    /* a last window beyond the ones before it, a zero stride: refused */
+    if (p25_prove_batch_dev_windows(agg, d_l3, 2 * lw, 3 * lw, 2, d_sw, d_w, aw, d_stw) != P25_ERR_INVALID_ARG ||
+        p25_prove_batch_dev_windows(agg, d_l3, 0, 0, 2, d_sw, d_w, aw, d_stw) != P25_ERR_INVALID_ARG) {
+      fprintf(stderr, "windows: bad arguments accepted\n");
+      return 1;
+    }
+    hipFree(d_in3); hipFree(d_s3); hipFree(d_l3); hipFree(d_sw); hipFree(d_w); hipFree(d_stw);
+    free(h3); free(groups); free(h_w); free(back_w);
+  }
   /* argument checks of the ordering entry points */
   if (p25_circuit_mark(leaf, P25_MAX_MARKS) != P25_ERR_INVALID_ARG || p25_circuit_wait_mark(agg, agg, 0) != P25_ERR_INVALID_ARG ||
       p25_circuit_wait_mark(NULL, leaf, 0) != P25_ERR_INVALID_ARG) {
