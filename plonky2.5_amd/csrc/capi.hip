@@ -304,7 +304,10 @@ static p25_status host_guarded(F&& f) {
 extern "C" {
 
 static p25::P3Config checked_p3_config(const p25_p3_config* cfg) {
-  if (cfg->log_quotient_degree != 0) throw std::invalid_argument("only one quotient chunk is supported (proof.rs:41-48)");
+  // one quotient chunk is the reference's proof model (proof.rs:41-48); two (constraint degree 3) is the round-5 extension
+  if (cfg->log_quotient_degree != 0 && cfg->log_quotient_degree != 1)
+    throw std::invalid_argument("one or two quotient chunks are supported (log_quotient_degree 0 or 1)");
+  if (cfg->log_quotient_degree > cfg->log_blowup) throw std::invalid_argument("log_quotient_degree above log_blowup");
   if (cfg->trace_width < 1 || cfg->trace_width > 64 || cfg->log_trace_height < 1 || cfg->log_trace_height > 24 ||
       cfg->num_queries < 1 || cfg->num_queries > 1000 || cfg->degree_bits < 1 || cfg->degree_bits > cfg->log_trace_height ||
       cfg->opening_matrix_log_max_height < 1 || cfg->opening_matrix_log_max_height > 30 || cfg->quotient_opened_len < 1 ||
@@ -356,7 +359,15 @@ p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, 
 p25_status p25_circuit_build_p3_verifier_air(const p25_p3_config* cfg, const p25_air* air, p25_circuit** out) {
   return host_guarded([&]() -> p25_status {
     if (!cfg || !air || !out) throw std::invalid_argument("null argument");
-    p25::ProgramAir pa(air_from_c(air));
+    p25::AirProgram prog = air_from_c(air);
+    // the chunk count follows from the AIR (uni-stark get_log_quotient_degree): the shape must say the same
+    int max_deg = 1;
+    for (const auto& c : prog.constraints)
+      max_deg = std::max(max_deg, prog.node_degree(c.node) + (c.when == p25::AirProgram::ALWAYS ? 0 : 1));
+    if ((max_deg <= 2 ? 0 : 1) != cfg->log_quotient_degree)
+      throw std::invalid_argument(max_deg <= 2 ? "AIR of degree <= 2 has ONE quotient chunk (log_quotient_degree 0)"
+                                               : "AIR of constraint degree 3 needs TWO quotient chunks (log_quotient_degree 1)");
+    p25::ProgramAir pa(std::move(prog));
     return build_verifier(cfg, pa, out);
   });
 }
@@ -911,6 +922,12 @@ p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t l
     pc.trace_width = prog.width;
     pc.opening_matrix_log_max_height = log_n + 1;
     pc.degree_bits = log_n;
+    {   // the number of quotient chunks follows from the AIR's degree (p3_prove_air)
+      int max_deg = 1;
+      for (const auto& c : prog.constraints)
+        max_deg = std::max(max_deg, prog.node_degree(c.node) + (c.when == p25::AirProgram::ALWAYS ? 0 : 1));
+      pc.log_quotient_degree = max_deg <= 2 ? 0 : 1;
+    }
     if (!inputs_out) {  // size query only
       if (log_n < 1 || log_n > 22 || num_queries < 1) throw std::invalid_argument("bad parameters");
       *n_out = pc.num_inputs();

@@ -178,8 +178,8 @@ void p3_proof_from_json(const char* json, size_t len, std::vector<u64>& inputs, 
   cfg.opening_proof_query_openings_opened_values_length = (int)qo.arr[0].arr[1].at("opened_values").arr.at(0).arr.size();
   cfg.degree_bits = (int)root.at("degree_bits").num;
   cfg.fri_config.num_queries = (int)fp.at("query_proofs").arr.size();
-  if (ov.at("quotient_chunks").arr.size() != 1)
-    throw std::invalid_argument("p3 proof JSON: exactly one quotient chunk is supported (proof.rs:41-48)");
+  if (ov.at("quotient_chunks").arr.size() != 1 && ov.at("quotient_chunks").arr.size() != 2)
+    throw std::invalid_argument("p3 proof JSON: one quotient chunk (proof.rs:41-48) or two (degree-3 AIRs) are supported");
   if (inputs.size() != cfg.num_inputs()) throw std::invalid_argument("p3 proof JSON: shape is not rectangular");
 }
 

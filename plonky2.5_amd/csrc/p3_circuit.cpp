@@ -403,8 +403,11 @@ void AirProgram::validate() const {
   }
   for (const Constraint& c : constraints) {
     if (c.node >= nodes.size() || c.when > TRANSITION) throw std::invalid_argument("AIR: bad constraint");
-    if (node_degree(c.node) + (c.when == ALWAYS ? 0 : 1) > 2)
-      throw std::invalid_argument("AIR: constraint degree > 2 needs more than one quotient chunk (serde/proof.rs:41-48 has one)");
+    // degree <= 2: one quotient chunk, the reference's proof model (serde/proof.rs:41-48).  Degree 3: two chunks -- the
+    // reference's verifier (verifier.rs:115-221) and its P3Config (mod.rs:76) already handle any power of two, only
+    // `OpenedValues::add_virtual_to` fixes the count; round 5 lifts that.  More needs log_blowup > 1.
+    if (node_degree(c.node) + (c.when == ALWAYS ? 0 : 1) > 3)
+      throw std::invalid_argument("AIR: constraint degree > 3 needs more than two quotient chunks (log_blowup 1 holds two)");
   }
 }
 AirProgram AirProgram::fibonacci() {
@@ -441,14 +444,15 @@ void ProgramAir::eval(VerifierConstraintFolder& folder, CircuitBuilder& cb) cons
 
 // ---------------------------------------------------------------- src/p3/serde/proof.rs:357-373
 size_t P3Config::num_inputs() const {
-  size_t n = 8 + (size_t)trace_width * 4 + 4;
+  const size_t chunks = (size_t)1 << log_quotient_degree;   // 1 for the reference's proofs (proof.rs:41-48)
+  size_t n = 8 + (size_t)trace_width * 4 + 4 * chunks;
   n += (size_t)log_trace_height * 4;
   size_t per_query = 0;
   for (int i = 0; i < log_trace_height; i++) per_query += 2 + 4 * (size_t)(log_trace_height - i);
   n += per_query * fri_config.num_queries + 3;
   n += (size_t)fri_config.num_queries *
        ((trace_width + 4 * opening_matrix_log_max_height) +
-        (opening_proof_query_openings_opened_values_length + 4 * opening_matrix_log_max_height));
+        (chunks * opening_proof_query_openings_opened_values_length + 4 * opening_matrix_log_max_height));
   return n;
 }
 static P3ProofTarget add_virtual_proof(CircuitBuilder& cb, const P3Config& cfg) {
@@ -465,10 +469,10 @@ static P3ProofTarget add_virtual_proof(CircuitBuilder& cb, const P3Config& cfg) 
   p.quotient_commit = v4();
   for (int i = 0; i < cfg.trace_width; i++) p.trace_local.push_back(vext());
   for (int i = 0; i < cfg.trace_width; i++) p.trace_next.push_back(vext());
-  {
+  for (int ch = 0; ch < (1 << cfg.log_quotient_degree); ch++) {   // proof.rs:41-48 has `(0..1)`: one chunk; see AirProgram::validate
     Ext a = vext();
     Ext b = vext();
-    p.quotient_chunks.push_back({a, b});  // proof.rs:41-48: exactly one chunk
+    p.quotient_chunks.push_back({a, b});
   }
   for (int i = 0; i < cfg.log_trace_height; i++) p.commit_phase_commits.push_back(v4());
   for (int q = 0; q < cfg.fri_config.num_queries; q++) {
@@ -487,9 +491,12 @@ static P3ProofTarget add_virtual_proof(CircuitBuilder& cb, const P3Config& cfg) 
     std::array<P3BatchOpening, 2> bo;
     int widths[2] = {cfg.trace_width, cfg.opening_proof_query_openings_opened_values_length};
     for (int b = 0; b < 2; b++) {
-      std::vector<Target> row;
-      for (int i = 0; i < widths[b]; i++) row.push_back(vt());
-      bo[b].opened_values.push_back(row);
+      const int mats = b == 0 ? 1 : (1 << cfg.log_quotient_degree);   // batch 1: one matrix per quotient chunk
+      for (int m = 0; m < mats; m++) {
+        std::vector<Target> row;
+        for (int i = 0; i < widths[b]; i++) row.push_back(vt());
+        bo[b].opened_values.push_back(row);
+      }
       for (int k = 0; k < cfg.opening_matrix_log_max_height; k++) bo[b].opening_proof.push_back(v4());
     }
     p.query_openings.push_back(std::move(bo));

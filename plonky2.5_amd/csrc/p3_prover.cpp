@@ -217,46 +217,72 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
   ch.observe_digest(trace_tree.root());
   const E2 alpha = ch.sample_ext();
 
-  // quotient on the disjoint coset 7*H_n (points x_j = 7 w_n^j = LDE natural index 2j)
-  std::vector<u64> q0(n), q1(n);
+  // Quotient chunks: 2^lqd of them, lqd = log2_ceil(max constraint degree - 1) with the selector's degree counted (uni-stark's
+  // get_log_quotient_degree).  Degree <= 2 (every AIR the reference can verify: serde/proof.rs:41-48 holds one chunk): lqd = 0;
+  // degree 3: lqd = 1.  The quotient domain is the disjoint coset 7*H_{n 2^lqd} (verifier.rs:120-124): points
+  // x_j = 7 w^j = LDE natural index j * (2 >> lqd), so with log_blowup = 1 the trace's LDE already holds the trace there.
+  int max_deg = 1;
+  for (const auto& c : air.constraints) max_deg = std::max(max_deg, air.node_degree(c.node) + (c.when == AirProgram::ALWAYS ? 0 : 1));
+  const int lqd = max_deg <= 2 ? 0 : 1;
+  const size_t Q = (size_t)1 << lqd, nq = n << lqd;          // chunks, quotient-domain size
+  const size_t lde_step = 2 >> lqd;                            // LDE index step between quotient-domain points
+  std::vector<u64> q0(nq), q1(nq);
   {
     const u64 g_inv = gl::inv(w_n);
-    const u64 zh = gl::sub(gl::pow(gl::GENERATOR, n), 1);  // x^n - 1 is constant on the coset
-    const u64 zh_inv = gl::inv(zh);
+    const u64 w_q = gl::root_of_unity(k + lqd);
+    const u64 gn = gl::pow(gl::GENERATOR, n);
+    // x^n - 1 on the coset: 7^n (w_q^j)^n - 1 takes 2^lqd values (constant for one chunk)
+    std::vector<u64> zh(Q), zh_inv(Q);
+    for (size_t r = 0; r < Q; r++) {
+      zh[r] = gl::sub(gl::mul(gn, gl::pow(w_q, r * n)), 1);
+      zh_inv[r] = gl::inv(zh[r]);
+    }
     u64 x = gl::GENERATOR;
     BaseOps ops;
     std::vector<u64> loc(W), nxt(W);
-    for (size_t j = 0; j < n; j++, x = gl::mul(x, w_n)) {
-      const size_t i0 = 2 * j, i1 = (2 * j + 2) % N2;
+    for (size_t j = 0; j < nq; j++, x = gl::mul(x, w_q)) {
+      const size_t i0 = lde_step * j, i1 = (lde_step * j + 2) % N2;   // the next ROW is x w_n = two LDE points on
       for (int c = 0; c < W; c++) {
         loc[c] = lde_nat[c][i0];
         nxt[c] = lde_nat[c][i1];
       }
       // two_adic.rs:100-147: selectors at a point of the quotient coset
+      const u64 zhx = zh[j & (Q - 1)];
       const u64 is_trans = gl::sub(x, g_inv);
-      const u64 sel[4] = {0, gl::mul(zh, gl::inv(gl::sub(x, 1))), gl::mul(zh, gl::inv(is_trans)), is_trans};
+      const u64 sel[4] = {0, gl::mul(zhx, gl::inv(gl::sub(x, 1))), gl::mul(zhx, gl::inv(is_trans)), is_trans};
       E2 acc = gl::e2(0);
       air.fold<u64>(loc, nxt, sel, ops, [&](u64 c) {  // VerifierConstraintFolder::assert_zero: acc = acc * alpha + c
         acc = gl::mul(acc, alpha);
         acc.a = gl::add(acc.a, c);
       });
-      E2 q = gl::mul(acc, zh_inv);
+      E2 q = gl::mul(acc, zh_inv[j & (Q - 1)]);
       q0[j] = q.a;
       q1[j] = q.b;
     }
   }
-  // quotient chunk matrix (one chunk, 2 base columns): P'(h) = q(7h); LDE on H_{2n} = q on 7*H_{2n}
-  std::vector<u64> qc0(q0), qc1(q1);
-  intt(qc0);
-  intt(qc1);
-  std::vector<u64> ql0 = lde2(qc0, 1), ql1 = lde2(qc1, 1);
-  std::vector<u64> quot_rows(N2 * 2);
-  for (size_t i = 0; i < N2; i++) {
-    size_t r = gl::bitrev((u32)i, L);
-    quot_rows[2 * i] = ql0[r];
-    quot_rows[2 * i + 1] = ql1[r];
+  // Chunk c = every Q-th value starting at c (TwoAdicMultiplicativeCoset::split_evals): the quotient on the coset
+  // s_c H_n, s_c = 7 w_q^c (split_domains; p3_circuit.cpp quotient_chunks_domains).  Its two base columns are committed as
+  // TwoAdicFriPcs::commit does: read as values on H_n -- the polynomial P_c(X) = q_c(s_c X) -- and extended to the coset
+  // (7 / s_c) H_{2n}, i.e. q_c on 7*H_{2n}; all chunks are matrices of ONE Merkle tree (same height: rows concatenated).
+  std::vector<std::vector<u64>> qcoef(2 * Q);     // P_c's coefficients, [2 c + component]
+  std::vector<u64> s_c(Q);
+  std::vector<u64> quot_rows(N2 * 2 * Q);
+  {
+    const u64 w_q = gl::root_of_unity(k + lqd);
+    for (size_t c = 0; c < Q; c++) {
+      s_c[c] = gl::mul(gl::GENERATOR, gl::pow(w_q, c));
+      for (int comp = 0; comp < 2; comp++) {
+        std::vector<u64> v(n);
+        const std::vector<u64>& src = comp ? q1 : q0;
+        for (size_t j = 0; j < n; j++) v[j] = src[j * Q + c];
+        intt(v);
+        std::vector<u64> l = lde2(v, gl::mul(gl::GENERATOR, gl::inv(s_c[c])));
+        for (size_t i = 0; i < N2; i++) quot_rows[i * 2 * Q + 2 * c + comp] = l[gl::bitrev((u32)i, L)];
+        qcoef[2 * c + comp] = std::move(v);
+      }
+    }
   }
-  Tree quot_tree = commit(quot_rows, 2, T);
+  Tree quot_tree = commit(quot_rows, (int)(2 * Q), T);
   ch.observe_digest(quot_tree.root());
   const E2 zeta = ch.sample_ext();
   const E2 zeta_next = gl::mul(zeta, w_n);
@@ -267,9 +293,12 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
     t_local[c] = eval_ext(coef[c], zeta);
     t_next[c] = eval_ext(coef[c], zeta_next);
   }
-  const E2 zeta_over_shift = gl::mul(zeta, gl::inv(gl::GENERATOR));
-  const E2 qz[2] = {eval_ext(qc0, zeta_over_shift), eval_ext(qc1, zeta_over_shift)};
-  {  // self-check of the identity the verifier enforces (verifier.rs:199-239)
+  std::vector<E2> qz(2 * Q);                      // q_c's components at zeta = P_c at zeta / s_c
+  for (size_t c = 0; c < Q; c++) {
+    const E2 z_over_s = gl::mul(zeta, gl::inv(s_c[c]));
+    for (int comp = 0; comp < 2; comp++) qz[2 * c + comp] = eval_ext(qcoef[2 * c + comp], z_over_s);
+  }
+  {  // self-check of the identity the verifier enforces (verifier.rs:169-239)
     E2 un = zeta;
     E2 z_h = gl::sub(gl::exp_pow2(un, k), gl::e2(1));
     E2 is_trans = gl::sub(un, gl::e2(gl::inv(w_n)));
@@ -278,7 +307,19 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
     E2 acc = gl::e2(0);
     air.fold<E2>(t_local, t_next, sel, ops, [&](E2 c) { acc = gl::add(gl::mul(acc, alpha), c); });
     E2 lhs = gl::mul(acc, gl::inv(z_h));
-    E2 rhs = gl::add(qz[0], gl::mul(qz[1], E2{0, 1}));
+    // quotient(zeta) = sum_c zps_c (q_c.a + X q_c.b),  zps_c = prod_{j != c} Z_{D_j}(zeta) / Z_{D_j}(s_c),  Z_{D_j}(x) = (x / s_j)^n - 1
+    E2 rhs = gl::e2(0);
+    for (size_t c = 0; c < Q; c++) {
+      E2 zp = gl::e2(1);
+      for (size_t j = 0; j < Q; j++) {
+        if (j == c) continue;
+        const u64 sj_inv = gl::inv(s_c[j]);
+        E2 at_zeta = gl::sub(gl::exp_pow2(gl::mul(zeta, sj_inv), k), gl::e2(1));
+        u64 at_first = gl::sub(gl::pow(gl::mul(s_c[c], sj_inv), n), 1);
+        zp = gl::mul(zp, gl::mul(at_zeta, gl::inv(at_first)));
+      }
+      rhs = gl::add(rhs, gl::mul(zp, gl::add(qz[2 * c], gl::mul(qz[2 * c + 1], E2{0, 1}))));
+    }
     if (!gl::eq(lhs, rhs)) throw std::logic_error("p3 prover: quotient identity does not hold");
   }
 
@@ -286,7 +327,7 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
   const E2 fri_alpha = ch.sample_ext();
   std::vector<E2> folded(N2);
   {
-    std::vector<E2> apow(2 * W + 2);
+    std::vector<E2> apow(2 * W + 2 * Q);
     apow[0] = gl::e2(1);
     for (size_t i = 1; i < apow.size(); i++) apow[i] = gl::mul(apow[i - 1], fri_alpha);
     parallel_for(T, N2, [&](size_t b, size_t e) {
@@ -301,8 +342,8 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
           acc = gl::add(acc, gl::mul(apow[t], gl::mul(gl::sub(gl::e2(trace_rows[i * W + c]), t_local[c]), inv_z)));
         for (int c = 0; c < W; c++, t++)
           acc = gl::add(acc, gl::mul(apow[t], gl::mul(gl::sub(gl::e2(trace_rows[i * W + c]), t_next[c]), inv_zn)));
-        for (int c = 0; c < 2; c++, t++)
-          acc = gl::add(acc, gl::mul(apow[t], gl::mul(gl::sub(gl::e2(quot_rows[2 * i + c]), qz[c]), inv_z)));
+        for (size_t c = 0; c < 2 * Q; c++, t++)     // the chunk matrices in order, two columns each, all opened at zeta
+          acc = gl::add(acc, gl::mul(apow[t], gl::mul(gl::sub(gl::e2(quot_rows[2 * Q * i + c]), qz[c]), inv_z)));
         folded[i] = acc;
       }
     });
@@ -360,7 +401,7 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
   cfg.fri_config.log_blowup = prm.log_blowup;
   cfg.fri_config.num_queries = prm.num_queries;
   cfg.fri_config.proof_of_work_bits = prm.pow_bits;
-  cfg.log_quotient_degree = 0;
+  cfg.log_quotient_degree = lqd;
   cfg.log_trace_height = k;
   cfg.trace_width = W;
   cfg.opening_matrix_log_max_height = L;
@@ -376,8 +417,7 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
   push_d(quot_tree.root());
   for (auto& e : t_local) push_e(e);
   for (auto& e : t_next) push_e(e);
-  push_e(qz[0]);
-  push_e(qz[1]);
+  for (auto& e : qz) push_e(e);
   for (auto& t : fri_trees) push_d(t.root());
   for (size_t ix : indices) {
     size_t idx = ix;
@@ -393,8 +433,7 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
   for (size_t ix : indices) {
     for (int c = 0; c < W; c++) out.push_back(trace_rows[ix * W + c]);
     for (auto& d : trace_tree.prove(ix)) push_d(d);
-    out.push_back(quot_rows[2 * ix]);
-    out.push_back(quot_rows[2 * ix + 1]);
+    for (size_t c = 0; c < 2 * Q; c++) out.push_back(quot_rows[2 * Q * ix + c]);
     for (auto& d : quot_tree.prove(ix)) push_d(d);
   }
   if (out.size() != cfg.num_inputs()) throw std::logic_error("p3 prover: flattened size mismatch");
@@ -436,9 +475,9 @@ std::string p3_inputs_to_json(const std::vector<u64>& in, const P3Config& cfg) {
   list(cfg.trace_width, [&] { val(2); });
   s += ",\"trace_next\":";
   list(cfg.trace_width, [&] { val(2); });
-  s += ",\"quotient_chunks\":[";
-  list(2, [&] { val(2); });
-  s += "]},\"opening_proof\":{\"fri_proof\":{\"commit_phase_commits\":";
+  s += ",\"quotient_chunks\":";
+  list((size_t)1 << cfg.log_quotient_degree, [&] { list(2, [&] { val(2); }); });
+  s += "},\"opening_proof\":{\"fri_proof\":{\"commit_phase_commits\":";
   list(k, [&] { val(4); });
   s += ",\"query_proofs\":";
   list(cfg.fri_config.num_queries, [&] {
@@ -463,9 +502,9 @@ std::string p3_inputs_to_json(const std::vector<u64>& in, const P3Config& cfg) {
     int widths[2] = {cfg.trace_width, cfg.opening_proof_query_openings_opened_values_length};
     int b = 0;
     list(2, [&] {
-      s += "{\"opened_values\":[";
-      arr(widths[b]);
-      s += "],\"opening_proof\":";
+      s += "{\"opened_values\":";
+      list(b == 0 ? 1 : (size_t)1 << cfg.log_quotient_degree, [&] { arr(widths[b]); });
+      s += ",\"opening_proof\":";
       list(cfg.opening_matrix_log_max_height, [&] { arr(4); });
       s += '}';
       b++;

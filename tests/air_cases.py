@@ -1,5 +1,6 @@
 """User AIRs for the 8f-2 tests (data form of the reference's `Air` trait, src/p3/air.rs:10-18) with
-trace generators.  Constraint degree (selector included) stays <= 2: one quotient chunk."""
+trace generators.  Constraint degree (selector included) <= 2: one quotient chunk, what the reference's proof model holds
+(serde/proof.rs:41-48); the `cubic*` AIRs at the end have degree 3: two chunks (round 5)."""
 import numpy as np
 
 P = 0xFFFFFFFF00000001
@@ -118,4 +119,50 @@ def quadratic_pair_trace(par, log_n):
     for i in range(n):
         t[i] = (x, y, x * y % P, (x + y) * (x + k) % P)
         x, y = (a * x + b * y + c) % P, (d * x + e * y + f) % P
+    return t
+
+
+def cubic(p25):
+    """width 2, degree 3 in an ALWAYS constraint: y = x^3 on every row; x <- y + 1; first row x = 2.  Two quotient chunks."""
+    air = p25.Air(2)
+    x, y = air.local(0), air.local(1)
+    air.assert_zero(air.sub(air.mul(air.mul(x, x), x), y))
+    air.when_first_row(air.sub(x, air.const(2)))
+    air.when_transition(air.sub(air.next(0), air.add(y, air.const(1))))
+    return air
+
+
+def cubic_trace(log_n):
+    n = 1 << log_n
+    t = np.zeros((n, 2), dtype=np.uint64)
+    x = 2
+    for i in range(n):
+        y = pow(x, 3, P)
+        t[i] = (x, y)
+        x = (y + 1) % P
+    return t
+
+
+def cubic_transition(p25):
+    """width 3, degree 3 through the SELECTOR: the transition constraint next x = x * y + 5 is quadratic, times
+    is_transition; y <- y + x (linear), z = x * y on every row (degree 2), last row: z pinned to x * y through a second
+    route (z - x y is already zero: the constraint z - x*y under when_last_row has degree 3 as well)."""
+    air = p25.Air(3)
+    x, y, z = air.local(0), air.local(1), air.local(2)
+    air.assert_zero(air.sub(air.mul(x, y), z))
+    air.when_first_row(air.sub(x, air.const(3)))
+    air.when_first_row(air.sub(y, air.const(7)))
+    air.when_transition(air.sub(air.next(0), air.add(air.mul(x, y), air.const(5))))
+    air.when_transition(air.sub(air.next(1), air.add(y, x)))
+    air.when_last_row(air.sub(air.mul(x, y), z))
+    return air
+
+
+def cubic_transition_trace(log_n):
+    n = 1 << log_n
+    t = np.zeros((n, 3), dtype=np.uint64)
+    x, y = 3, 7
+    for i in range(n):
+        t[i] = (x, y, x * y % P)
+        x, y = (x * y + 5) % P, (y + x) % P
     return t

@@ -78,6 +78,58 @@ def test_seeded_air_families_accepted_by_their_verifier_circuits(p25, oracle, fa
         p25.p3_prove_air(air, wrong, num_queries=5, pow_bits=4)
 
 
+@pytest.mark.parametrize("name,log_n", [("cubic", 4), ("cubic", 6), ("cubic_transition", 3), ("cubic_transition", 5)])
+def test_degree_three_air_two_quotient_chunks(p25, oracle, name, log_n):
+    """Constraint degree 3 (in the constraint itself, or a quadratic one under a selector): TWO quotient chunks.  The
+    reference's verifier handles any power of two (verifier.rs:115-221: split domains, zps, recomposition; mod.rs:76 derives
+    log_quotient_degree from the proof) and only its proof model fixes one (serde/proof.rs:41-48 `(0..1)`); with that lifted
+    -- one more chunk's openings after the first, one more matrix in the quotient batch -- the native prover's proof is
+    accepted by the verifier circuit built for the AIR (witness exists, every constraint zero, the plonky2 proof of it
+    verifies), any flipped input word is rejected, the JSON form round-trips, and the shapes cannot be mixed up."""
+    import p3json, json
+    air = getattr(air_cases, name)(p25)
+    trace = getattr(air_cases, name + "_trace")(log_n)
+    inp, cfg = p25.p3_prove_air(air, trace, num_queries=6, pow_bits=6)
+    assert cfg.log_quotient_degree == 1 and cfg.trace_width == air.width
+    c = p25.Circuit.build_p3_verifier_air(cfg, air)
+    assert int(c.info.num_inputs) == inp.size
+    oc = oracle.load_circuit(c.to_blob())
+    wires, st, msg = oc.witness(inp, seed=3)
+    assert st == 0, msg
+    bad, msg = oc.check_constraints(wires)
+    assert bad == 0, msg
+    proof, st, _tm, msg = oc.prove(inp, seed=3)
+    assert st == 0, msg
+    assert oc.verify(proof)[0] == 0
+    # both chunks' openings (4 + 4 words behind the trace openings), commitments, FRI and query words: no flip survives
+    q0 = 8 + 4 * air.width
+    for pos in list(range(q0, q0 + 8)) + [0, 4, 8, q0 + 8, len(inp) // 2, len(inp) - 5, len(inp) - 1]:
+        t = inp.copy()
+        t[pos] = (int(t[pos]) + 1) % P
+        assert oc.witness(t, seed=3)[1] == 4, pos
+    # the JSON form carries two chunks; the independent Python reader flattens it to the same vector and derives the shape
+    js = p25.p3_inputs_to_json(inp, cfg)
+    obj = json.loads(js)
+    assert len(obj["opened_values"]["quotient_chunks"]) == 2
+    assert len(obj["opening_proof"]["query_openings"][0][1]["opened_values"]) == 2
+    assert (p3json.flatten_p3_proof(obj) == inp).all() and p3json.p3_shape(obj)["log_quotient_degree"] == 1
+    back, cfg2 = p25.p3_proof_from_json(js)
+    assert (back == inp).all() and cfg2.log_quotient_degree == 1
+    # shapes cannot be mixed up: this AIR with a one-chunk shape, a degree-2 AIR with a two-chunk shape
+    one = p25.P3Config(cfg.log_blowup, cfg.num_queries, cfg.proof_of_work_bits, 0, cfg.log_trace_height, cfg.trace_width,
+                       cfg.opening_matrix_log_max_height, cfg.quotient_opened_len, cfg.degree_bits)
+    with pytest.raises(p25.P25Error):
+        p25.Circuit.build_p3_verifier_air(one, air)
+    if air.width == 3:
+        with pytest.raises(p25.P25Error):
+            p25.Circuit.build_p3_verifier_air(cfg, p25.Air.fibonacci())
+    # a trace that breaks the cubic relation cannot be proved
+    wrong = trace.copy()
+    wrong[2, air.width - 1] = (int(wrong[2, air.width - 1]) + 1) % P
+    with pytest.raises(p25.P25Error):
+        p25.p3_prove_air(air, wrong, num_queries=6, pow_bits=6)
+
+
 def test_violating_trace_cannot_be_proved(p25):
     air = air_cases.tribonacci(p25)
     trace = air_cases.tribonacci_trace(4)
@@ -90,7 +142,12 @@ def test_malformed_programs_rejected(p25):
     cfg = p25.P3Config.fib64()
     air = p25.Air(3)
     x = air.local(0)
-    air.when_transition(air.sub(air.mul(x, x), air.local(1)))      # degree 3 with the selector
+    air.when_transition(air.sub(air.mul(x, x), air.local(1)))      # degree 3 with the selector: needs a two-chunk shape
+    with pytest.raises(p25.P25Error):
+        p25.Circuit.build_p3_verifier_air(cfg, air)
+    air = p25.Air(3)
+    x = air.local(0)
+    air.assert_zero(air.sub(air.mul(air.mul(x, x), air.mul(x, x)), air.local(1)))   # degree 4: more than two chunks
     with pytest.raises(p25.P25Error):
         p25.Circuit.build_p3_verifier_air(cfg, air)
     air = p25.Air(3)
