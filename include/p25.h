@@ -126,8 +126,11 @@ p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, 
  * an expression DAG.  node.op: 0 LOCAL(column a of the current row)  1 NEXT(column a of the next row)
  * 2 CONST(value)  3 ADD(a,b)  4 SUB(a,b)  5 MUL(a,b), a/b = indices of EARLIER nodes.  A constraint is a
  * node that must vanish on the rows `when` selects (0 always, 1 first row, 2 last row, 3 transition),
- * folded in order like VerifierConstraintFolder (air.rs:69-118).  Degree (selector included) <= 2: the
- * reference's proof model has one quotient chunk (serde/proof.rs:41-48).  The FibonacciAir of
+ * folded in order like VerifierConstraintFolder (air.rs:69-118).  Degree (selector included) <= 2: ONE quotient chunk,
+ * the reference's proof model (serde/proof.rs:41-48 `(0..1)`), p25_p3_config.log_quotient_degree = 0.  Degree 3: TWO chunks
+ * (log_quotient_degree = 1; round 5): the reference's verifier (verifier.rs:115-221) and its shape derivation (mod.rs:76)
+ * handle any power of two, only that `(0..1)` fixes the count -- the flat input then carries the second chunk's two
+ * openings right behind the first's, and every query's quotient batch holds one row per chunk.  The FibonacciAir of
  * src/p3/mod.rs:176-221 in this form builds the very same circuit (same digest) as P25_AIR_FIBONACCI. */
 typedef struct {
   uint32_t op, a, b, reserved;
