@@ -543,6 +543,11 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
 #ifndef P25_Q_PF
 #define P25_Q_PF 1
 #endif
+// P25_Q_MERGE_PERM (round 5 experiment): the permutation argument evaluated INSIDE the merged pass over the routed wires -- each
+// routed wire column is then read once by the kernel's first two stages instead of twice (80 of ~620 column reads per point).
+#ifndef P25_Q_MERGE_PERM
+#define P25_Q_MERGE_PERM 0
+#endif
 #ifndef P25_Q_PERSIST
 #define P25_Q_PERSIST 0
 #endif
@@ -631,6 +636,20 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   u64 mg0 = 0, mg1 = 0;       // their filtered, alpha-folded sums
   const u64 beta0 = a.chal[CH_BETAS], beta1 = a.chal[CH_BETAS + 1];
   const u64 gamma0 = a.chal[CH_GAMMAS], gamma1 = a.chal[CH_GAMMAS + 1];
+  // chunk k of the partial-product check, both challenges: prev * numerator - next * denominator, folded with alpha
+  auto perm_chunk = [&](int k, u64 n0, u64 d0, u64 n1, u64 d1) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const u64 np = gl::canon(c ? n1 : n0), dp = gl::canon(c ? d1 : d0);
+      u64 prev = k == 0 ? zsc.col(c) : zsc.col(NC + c * NP + k - 1);
+      u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zsc.col(NC + c * NP + k);
+      u64 t = gl::sub(gl::mul(prev, np), gl::mul(next, dp));
+      int ti = NC + c * nch + k;
+      res[0] = gl::add(res[0], gl::mul(t, ap[ti]));
+      res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + ti]));
+    }
+  };
+  bool perm_done = false;
   if (fast) {
     for (uint32_t gi = 0; gi < a.n_gates; gi++) {
       const uint32_t kind = a.gates[gi].kind;
@@ -661,6 +680,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     mc.reset();
     u64 bs_sum = 0, bs_w0 = 0;
     u64 wnext = wrc.col(0);   // the wire read one position ahead
+    u64 snext = P25_Q_MERGE_PERM ? csc.col(n_consts + 2) : 0;   // ... and its sigma (merged permutation argument)
+    u64 pn0 = 1, pd0 = 1, pn1 = 1, pd1 = 1;
     SmallLin bs_acc;
     u64 ar0 = 0, ar1 = 0, ar2 = 0;                    // arithmetic: multiplicand 0, multiplicand 1, addend of the current op
     u64 mx0 = 0, mx1 = 0, mx2 = 0, mx3 = 0, mx4 = 0;  // mul-extension: a, b and output.a of the current op
@@ -670,6 +691,23 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const int j = base + (JJ);                                                                                  \
     const u64 w = wnext;                                                                                        \
     if (j + 1 < 80) wnext = wrc.col(j + 1);                                                                      \
+    if (P25_Q_MERGE_PERM) {   /* the permutation argument on the same read of the wire (both challenges) */        \
+      const u64 sg = snext;                                                                                     \
+      if (j + 1 < 80) snext = csc.col(n_consts + 2 + j + 1);                                                     \
+      const u64 wg0 = gl::add(w, gamma0), wg1 = gl::add(w, gamma1);                                             \
+      if ((JJ) % 8 == 0) {                                                                                      \
+        pn0 = gl::mad_nc(kb[j], x, wg0);                                                                        \
+        pd0 = gl::mad_nc(beta0, sg, wg0);                                                                       \
+        pn1 = gl::mad_nc(kb[80 + j], x, wg1);                                                                   \
+        pd1 = gl::mad_nc(beta1, sg, wg1);                                                                       \
+      } else {                                                                                                  \
+        pn0 = gl::mul_nc(pn0, gl::mad_nc(kb[j], x, wg0));                                                       \
+        pd0 = gl::mul_nc(pd0, gl::mad_nc(beta0, sg, wg0));                                                      \
+        pn1 = gl::mul_nc(pn1, gl::mad_nc(kb[80 + j], x, wg1));                                                  \
+        pd1 = gl::mul_nc(pd1, gl::mad_nc(beta1, sg, wg1));                                                      \
+      }                                                                                                         \
+      if ((JJ) % 8 == 7) perm_chunk(j >> 3, pn0, pd0, pn1, pd1);                                                \
+    }                                                                                                           \
     if ((JJ) < 4 && base == 0) {                                                                                \
       if (h_const && (JJ) < 2) mc.at((JJ), gl::mul_nc(gl::sub((JJ) == 0 ? k0 : k1, w), f_const));              \
       if (h_pi) mc.at((JJ), gl::mul_nc(gl::sub(w, a.pi_hash[(JJ)]), f_pi));                                     \
@@ -723,10 +761,11 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     if (h_bsum) mc.at(0, gl::mul_nc(gl::sub(bs_sum, bs_w0), f_bsum));
     mg0 = mc.acc0();
     mg1 = mc.acc1();
+    perm_done = P25_Q_MERGE_PERM;
   } else {
     merged_mask = 0;
   }
-  {
+  if (!perm_done) {
     // wires and sigmas read P25_Q_PF positions ahead (a ring of that many register pairs; the chunk length, 8, is a
     // multiple of it, so the ring index is static in the unrolled loop)
     constexpr int PF = P25_Q_PF;
