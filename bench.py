@@ -827,7 +827,7 @@ def main():
             # (i') the TUNED leg: the same prover with its Merkle hashing and its quotient evaluation eight
             # at a time on AVX-512 (oracle/ref_hash_x8.cpp, ref_quotient_x8.cpp), same thread count, validated against the scalar
             # proof byte for byte.  This is the number reported as cpu_baseline.value; the scalar one stays beside it.
-            cb = None
+            cb, tuned_note = None, "no AVX-512 on this host"
             if ora.set_tuned(True):
                 try:
                     prt, stt, _pert, wallt = oc.prove_many(inputs[None, :], np.array([0], dtype=np.uint64), threads=1,
@@ -839,13 +839,13 @@ def main():
                           "bytes_equal_to_the_scalar_oracle_proof": same,
                           "gpu_proof_bit_exact_vs_this_cpu_proof": bool(gpu_proof0 is not None and (prt[0] == gpu_proof0).all()),
                           "untuned": untuned}
-                    if not same or int(stt[0]) != 0:     # a tuned leg that disagrees with the checker is not a baseline
-                        cb = None
-                except Exception:
-                    cb = None
+                    if not same or int(stt[0]) != 0:     # a tuned leg that disagrees with the checker is not a baseline -- and is said so
+                        cb, tuned_note = None, f"REJECTED: status {int(stt[0])}, bytes equal to the scalar proof: {same}"
+                except Exception as e:
+                    cb, tuned_note = None, f"failed: {str(e)[:200]}"
             if cb is None:
                 ora.set_tuned(False)
-                cb = dict(untuned, cpu=model)
+                cb = dict(untuned, cpu=model, tuned_leg=tuned_note)
             if "configs" in out:
                 out["configs"]["config2_single_proof"]["bit_exact_vs_cpu_port"] = bit_exact
             if args.cpu_baseline == "full":
