@@ -634,6 +634,7 @@ p25_status p25_prove_batch_dev_windows(p25_circuit* c, const uint64_t* d_buffer,
   return guarded([&]() -> p25_status {
     if (!c || !d_buffer || !d_seeds || !d_proofs || !d_status) throw std::invalid_argument("null argument");
     if (window_stride_words == 0) throw std::invalid_argument("window stride is zero");
+    if (n_proofs > ((size_t)1 << 32) || window_stride_words > ((size_t)1 << 40)) throw std::invalid_argument("windows out of range");
     if (n_proofs && last_window_offset_words > (n_proofs - 1) * window_stride_words)
       throw std::invalid_argument("last window lies beyond the windows before it");
     P25_LOCK(c);
