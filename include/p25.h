@@ -170,6 +170,10 @@ p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t l
  *   interleaved value is the circuit's public input (the test expects 0x5555555555555550).
  * 13 uninterleave_to_u32 (test_uninterleave_to_u32, :388-417): param 1 = x = constant(0xF555555555555555), param 0 = x is
  *   the input; public inputs = (evens, odds) (the test expects 0xC0000000, 0xFFFFFFFF).
+ * 14 the reference's four gates in one circuit: inputs x, y, z (u32 values) and the expected x*y, interleave(x),
+ *   interleave(y), the (evens, odds) of uninterleave_to_u32(interleave(x)), the (low, high) of x*y+z, and the first four
+ *   words of Poseidon2 over those eleven values + 0 -- the circuit tests/blob_writer.py builds independently (8 gate
+ *   types in two selector groups).
  * Inputs = operands followed by the expected result(s); a wrong expectation fails the proof with
  * P25_ERR_WITNESS_CONFLICT, as the failing `connect` panics upstream. */
 p25_status p25_circuit_build_gadget(int32_t kind, int32_t param, p25_circuit** out);

@@ -872,6 +872,20 @@ Circuit build_gadget_circuit(int kind, int param) {
       cb.register_public_input(odds);
       break;
     }
+    case GADGET_REFERENCE_GATES: {  // all four gates the reference defines on this path + ArithmeticGate, in one small circuit:
+      // the circuit tests/blob_writer.py builds INDEPENDENTLY from the blob specification (two selector groups, 8 gate types)
+      Target x = in(), y = in(), z = in();
+      Target m = cb.mul(x, y);                           // ArithmeticGate
+      Target xi = cb.interleave_u32(x);                  // U32InterleaveGate, ops 0 and 1 of one row
+      Target yi = cb.interleave_u32(y);
+      auto [ev, od] = cb.uninterleave_to_u32(xi);        // UninterleaveToU32Gate
+      auto [lo, hi] = cb.mul_add_u32(x, y, z);           // U32ArithmeticGate
+      std::array<Target, 12> st = {m, xi, yi, ev, od, lo, hi, x, cb.zero(), cb.zero(), cb.zero(), cb.zero()};
+      auto out = cb.poseidon2_permute_targets(st);       // Poseidon2Gate
+      for (Target t : {m, xi, yi, ev, od, lo, hi}) cb.connect(t, in());
+      for (int i = 0; i < 4; i++) cb.connect(out[i], in());
+      break;
+    }
     default:
       throw std::invalid_argument("unknown gadget kind");
   }

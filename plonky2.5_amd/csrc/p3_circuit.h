@@ -165,7 +165,7 @@ Target reverse_p3_bits_len(CircuitBuilder& cb, Target x, int bit_len);
 // surfaces as a witness conflict exactly like a failing `connect` upstream.
 enum GadgetKind { GADGET_AND = 0, GADGET_XOR, GADGET_LSH, GADGET_RSH, GADGET_REVERSE, GADGET_COMPRESS, GADGET_EXP, GADGET_HASH_SLICES,
                   GADGET_CONNECTED_INPUTS, GADGET_EXT_ARITH, GADGET_POSEIDON_MERKLE, GADGET_PUBLIC_INPUTS,
-                  GADGET_INTERLEAVE_U32, GADGET_UNINTERLEAVE_TO_U32 };
+                  GADGET_INTERLEAVE_U32, GADGET_UNINTERLEAVE_TO_U32, GADGET_REFERENCE_GATES };
 Circuit build_gadget_circuit(int kind, int param);
 
 }  // namespace p25

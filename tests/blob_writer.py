@@ -13,15 +13,29 @@ MAGIC = b"P25CIRC1"
 
 # gate kinds / generator kinds of the blob (INTEGRATION.md section 5, tables "gate kind" and "generator kind")
 G_NOOP, G_CONSTANT, G_PUBLIC_INPUT, G_ARITHMETIC = 0, 1, 2, 6
+G_U32_INTERLEAVE, G_U32_UNINTERLEAVE, G_U32_ARITHMETIC, G_POSEIDON2 = 4, 5, 9, 10     # the reference's own four gates
 GEN_CONSTANT, GEN_RANDOM, GEN_ARITHMETIC = 0, 1, 2
-# (degree, upstream Gate::id()) -- orders the gate set
+GEN_POSEIDON2, GEN_U32_ARITHMETIC, GEN_U32_INTERLEAVE, GEN_U32_UNINTERLEAVE = 10, 11, 12, 13
+_PHANTOM = "PhantomData<plonky2_field::goldilocks_field::GoldilocksField>"
+# (degree, Gate::id()) -- orders the gate set; the reference's ids are `format!("{self:?}")` of its structs
+# (interleave_u32.rs:98-100, uninterleave_to_u32.rs:110-112, arithmetic_u32.rs:102-104, poseidon2_gate.rs:146-148)
 GATE_ORDER = {
     G_NOOP: (0, "NoopGate"),
     G_CONSTANT: (1, "ConstantGate { num_consts: 2 }"),
     G_PUBLIC_INPUT: (1, "PublicInputGate"),
+    G_U32_INTERLEAVE: (2, "U32InterleaveGate { num_ops: 3 }"),
+    G_U32_UNINTERLEAVE: (2, "UninterleaveToU32Gate { num_ops: 2 }"),
     G_ARITHMETIC: (3, "ArithmeticGate { num_ops: 20 }"),
+    G_U32_ARITHMETIC: (4, "U32ArithmeticGate { num_ops: 3, _phantom: " + _PHANTOM + " }"),
+    G_POSEIDON2: (7, "Poseidon2Gate { _phantom: " + _PHANTOM + " }<WIDTH=12>"),
 }
-GATE_CONSTRAINTS = {G_NOOP: 0, G_CONSTANT: 2, G_PUBLIC_INPUT: 4, G_ARITHMETIC: 20}
+# num_constraints of the reference's gates: interleave_u32.rs:229-231 (num_ops * (2 + 32)), uninterleave_to_u32.rs:264-266
+# (num_ops * (3 + 64)), arithmetic_u32.rs:167-169 (num_ops * (4 + 32)), poseidon2_gate.rs:425-427 (1 + 4 + 12 * 3 + 22 + 12 * 4 + 12)
+GATE_CONSTRAINTS = {G_NOOP: 0, G_CONSTANT: 2, G_PUBLIC_INPUT: 4, G_ARITHMETIC: 20, G_U32_INTERLEAVE: 3 * 34,
+                    G_U32_UNINTERLEAVE: 2 * 67, G_U32_ARITHMETIC: 3 * 36, G_POSEIDON2: 123}
+MULTI_OPS = {G_U32_INTERLEAVE: 3, G_U32_UNINTERLEAVE: 2, G_U32_ARITHMETIC: 3}    # ops per row (num_ops at 135 wires / 80 routed)
+MAX_DEGREE = 9                                       # max_quotient_degree_factor + 1 (upstream selectors.rs)
+UNUSED_SELECTOR = 0xFFFFFFFF
 NUM_WIRES, NUM_ROUTED, NUM_CONSTANTS, ARITH_OPS = 135, 80, 2, 20   # CircuitConfig::standard_recursion_config()
 
 
@@ -42,6 +56,7 @@ class MiniCircuit:
         self.inputs = []
         self.constants = {}            # value -> target
         self.open_arith = {}           # (c0, c1) -> (row, next op)
+        self.open_ops = {}             # multi-op gate kind -> (row, next op)   (CircuitBuilder::find_slot)
         self.generators = []           # (kind, c0, c1, aux, deps, outs)
 
     def virtual(self):
@@ -84,6 +99,47 @@ class MiniCircuit:
     def add(self, a, b):
         return self.arithmetic(1, 1, a, self.constant(1), b)
 
+    # ---- the reference's gates (wire layouts from their `wire_*` accessors)
+    def _slot(self, kind):
+        if kind in self.open_ops:
+            row, op = self.open_ops[kind]
+        else:
+            row, op = len(self.rows), 0
+            self.rows.append([kind, 0, 0])
+        if op == MULTI_OPS[kind] - 1:
+            self.open_ops.pop(kind, None)
+        else:
+            self.open_ops[kind] = (row, op + 1)
+        return row, op
+
+    def interleave_u32(self, x):
+        """gadgets/interleaved_u32.rs:89-111 on a U32InterleaveGate op: wires 2i (x) and 2i + 1 (interleaved) (interleave_u32.rs:45-62)."""
+        row, i = self._slot(G_U32_INTERLEAVE)
+        self.connect(("w", row, 2 * i), x)
+        return ("w", row, 2 * i + 1)
+
+    def uninterleave_to_u32(self, x):
+        """UninterleaveToU32Gate op: wires 3i (x), 3i + 1 (evens), 3i + 2 (odds) (uninterleave_to_u32.rs:47-75)."""
+        row, i = self._slot(G_U32_UNINTERLEAVE)
+        self.connect(("w", row, 3 * i), x)
+        return ("w", row, 3 * i + 1), ("w", row, 3 * i + 2)
+
+    def mul_add_u32(self, x, y, z):
+        """U32ArithmeticGate op: wires 6i, 6i + 1, 6i + 2 (multiplicands, addend), 6i + 3 / 6i + 4 (low, high) (arithmetic_u32.rs:40-80)."""
+        row, i = self._slot(G_U32_ARITHMETIC)
+        for k, t in enumerate((x, y, z)):
+            self.connect(("w", row, 6 * i + k), t)
+        return ("w", row, 6 * i + 3), ("w", row, 6 * i + 4)
+
+    def poseidon2_permute(self, state):
+        """Poseidon2Hash::permute_targets (poseidon2.rs:585-609): one Poseidon2Gate row, swap = 0, inputs 0..11, outputs 12..23."""
+        row = len(self.rows)
+        self.rows.append([G_POSEIDON2, 0, 0])
+        self.connect(self.constant(0), ("w", row, 24))
+        for i, t in enumerate(state):
+            self.connect(t, ("w", row, i))
+        return [("w", row, 12 + i) for i in range(12)]
+
     # ------------------------------------------------------------------ build(): the tables of the blob
     def build(self):
         rows = [list(r) for r in self.rows]
@@ -118,9 +174,27 @@ class MiniCircuit:
         n_targets = n * W + self.n_virtual
         # gate set sorted by (degree, id); one selector group when max_degree + num_gates - 1 <= 9
         kinds = sorted({r[0] for r in rows}, key=lambda k: GATE_ORDER[k])
-        assert GATE_ORDER[kinds[-1]][0] + len(kinds) - 1 <= 9
         gate_index = {k: i for i, k in enumerate(kinds)}
-        selector = [gate_index[r[0]] for r in rows]
+        # selector polynomials (upstream selectors.rs::selector_polynomials): one if everything fits the degree bound, else
+        # greedy groups -- gates are taken while (gates in the group) + (degree of the next gate) < max_degree
+        degs = [GATE_ORDER[k][0] for k in kinds]
+        if degs[-1] + len(kinds) - 1 <= MAX_DEGREE:
+            groups = [(0, len(kinds))]
+        else:
+            groups, start = [], 0
+            while start < len(kinds):
+                size = 0
+                while start + size < len(kinds) and size + degs[start + size] < MAX_DEGREE:
+                    size += 1
+                assert size > 0
+                groups.append((start, start + size))
+                start += size
+        group_of = [next(g for g, (a, b) in enumerate(groups) if a <= i < b) for i in range(len(kinds))]
+        if len(groups) == 1:
+            selectors = [[gate_index[r[0]] for r in rows]]
+        else:
+            selectors = [[gate_index[r[0]] if group_of[gate_index[r[0]]] == g else UNUSED_SELECTOR for r in rows]
+                         for g in range(len(groups))]
         const_polys = [[r[1] for r in rows], [r[2] for r in rows]]
         # copy constraints -> partitions -> sigma polynomials
         parent = list(range(n_targets))
@@ -151,17 +225,37 @@ class MiniCircuit:
                   for col in range(NUM_ROUTED)]
         # per-row gate generators after the explicit ones; unused ops of an incomplete row are dropped
         used_ops = {row: op for (row, op) in self.open_arith.values()}
+        used_ops.update({row: op for (row, op) in self.open_ops.values()})
+
+        def w(row, col):
+            return ("w", row, col)
+
         for row, r in enumerate(rows):
             if r[0] == G_ARITHMETIC:
                 for i in range(used_ops.get(row, ARITH_OPS)):
                     gens.append((GEN_ARITHMETIC, r[1], r[2], 0, [("w", row, 4 * i + k) for k in range(3)],
                                  [("w", row, 4 * i + 3)]))
+            elif r[0] == G_U32_INTERLEAVE:      # interleave_u32.rs:305-334: x -> 32 bits (wires 6 + 32 i ..), interleaved
+                for i in range(used_ops.get(row, 3)):
+                    gens.append((GEN_U32_INTERLEAVE, 0, 0, 0, [w(row, 2 * i)],
+                                 [w(row, 6 + 32 * i + j) for j in range(32)] + [w(row, 2 * i + 1)]))
+            elif r[0] == G_U32_UNINTERLEAVE:    # uninterleave_to_u32.rs:353-390: x -> 64 bits (wires 6 + 64 i ..), evens, odds
+                for i in range(used_ops.get(row, 2)):
+                    gens.append((GEN_U32_UNINTERLEAVE, 0, 0, 0, [w(row, 3 * i)],
+                                 [w(row, 6 + 64 * i + j) for j in range(64)] + [w(row, 3 * i + 1), w(row, 3 * i + 2)]))
+            elif r[0] == G_U32_ARITHMETIC:      # arithmetic_u32.rs:389-439: m0, m1, addend -> low, high, inverse, 32 limbs (wires 18 + 32 i ..)
+                for i in range(used_ops.get(row, 3)):
+                    gens.append((GEN_U32_ARITHMETIC, 0, 0, 0, [w(row, 6 * i + k) for k in range(3)],
+                                 [w(row, 6 * i + 3), w(row, 6 * i + 4), w(row, 6 * i + 5)] + [w(row, 18 + 32 * i + j) for j in range(32)]))
+            elif r[0] == G_POSEIDON2:           # poseidon2_gate.rs:447-523: 12 inputs, swap -> 4 deltas, 106 S-box inputs, 12 outputs
+                gens.append((GEN_POSEIDON2, 0, 0, 0, [w(row, k) for k in range(12)] + [w(row, 24)],
+                             [w(row, 25 + k) for k in range(4)] + [w(row, 29 + k) for k in range(106)] + [w(row, 12 + k) for k in range(12)]))
         # FRI schedule: ConstantArityBits(4, 5) under rate_bits 3, cap_height 4
         arity, db = [], degree_bits
         while db > 5 and db + 3 - 4 >= 4:
             arity.append(4)
             db -= 4
-        return dict(degree_bits=degree_bits, rows=rows, kinds=kinds, selector=selector, const_polys=const_polys,
+        return dict(degree_bits=degree_bits, rows=rows, kinds=kinds, selectors=selectors, groups=groups, group_of=group_of, const_polys=const_polys,
                     sigmas=sigmas, k_is=k_is, rep=rep, gens=gens, pi_row=pi_row, arity=arity,
                     inputs=[tidx(t) for t in self.inputs], tidx=tidx, n_virtual=self.n_virtual)
 
@@ -186,7 +280,7 @@ class MiniCircuit:
         header[4], header[5], header[6], header[7] = 2, 8, 3, 4      # challenges, max quotient degree factor, rate_bits, cap_height
         header[8], header[9] = 16, 28                                # proof_of_work_bits, num_query_rounds
         header[10] = len(b["arity"])
-        header[11] = 1                                               # selector polynomials
+        header[11] = len(b["selectors"])                             # selector polynomials
         header[12] = max(GATE_CONSTRAINTS[k] for k in kinds)
         header[13] = -(-NUM_ROUTED // 8) - 1                         # partial products per challenge
         header[14] = len(kinds)
@@ -194,14 +288,16 @@ class MiniCircuit:
         header[16] = b["n_virtual"]
         header[17] = len(b["inputs"])
         header[18] = len(b["gens"])
-        header[19] = 1 + NUM_CONSTANTS + NUM_ROUTED
+        header[19] = len(b["selectors"]) + NUM_CONSTANTS + NUM_ROUTED
         header[20], header[21] = 4, 5                                # FRI ConstantArityBits(4, 5)
         u64s(header)
         for i, k in enumerate(kinds):
-            u64s([k, 0, 0, len(kinds)])                              # kind, selector index, group [start, end)
+            g = b["group_of"][i]
+            u64s([k, g, b["groups"][g][0], b["groups"][g][1]])         # kind, selector index, group [start, end)
         u64s(b["arity"])
         u32s([r[0] for r in b["rows"]])
-        u64s(b["selector"])
+        for p in b["selectors"]:
+            u64s(p)
         for p in b["const_polys"]:
             u64s(p)
         for p in b["sigmas"]:
@@ -235,4 +331,22 @@ def sum_of_products(k):
     for i in range(1, k):
         acc = c.add(acc, c.mul(xs[2 * i], xs[2 * i + 1]))
     c.connect(acc, y)
+    return c
+
+
+def reference_gates():
+    """The circuit of p25_circuit_build_gadget(14): the reference's four gates + ArithmeticGate (8 gate types, two selector groups)."""
+    c = MiniCircuit()
+    x, y, z = c.input(), c.input(), c.input()
+    m = c.mul(x, y)
+    xi = c.interleave_u32(x)
+    yi = c.interleave_u32(y)
+    ev, od = c.uninterleave_to_u32(xi)
+    lo, hi = c.mul_add_u32(x, y, z)
+    zero = c.constant(0)
+    out = c.poseidon2_permute([m, xi, yi, ev, od, lo, hi, x, zero, zero, zero, zero])
+    for t in (m, xi, yi, ev, od, lo, hi):
+        c.connect(t, c.input())
+    for i in range(4):
+        c.connect(out[i], c.input())
     return c
