@@ -1,6 +1,32 @@
 // ORACLE -- test infrastructure only (see ref_fft.h).
 #include "ref_fft.h"
 #include <utility>
+#include "ref_field_x8.h"   // AVX-512 butterflies of the tuned cpu_baseline leg (functions with target attributes)
+
+// The tuned leg (bench.py cpu_baseline, ref_set_tuned): stages whose half-length is >= 8 run eight butterflies per pass on
+// AVX-512 -- same butterflies, same canonical values, same order of results; the checker leaves it off.
+static bool g_fft_tuned = false;
+void ref_fft_set_tuned(bool on) { g_fft_tuned = on; }
+
+// one decimation-in-time stage (len >= 8): u = d[s+j], v = d[s+j+len] * w[j]; d[s+j] = u + v, d[s+j+len] = u - v
+__attribute__((target("avx512f,avx512dq"))) static void dit_stage_x8(u64* d, size_t n, size_t len, const u64* w) {
+  for (size_t s = 0; s < n; s += 2 * len)
+    for (size_t j = 0; j < len; j += 8) {
+      V u = _mm512_loadu_si512(d + s + j);
+      V v = v_mul(_mm512_loadu_si512(d + s + j + len), _mm512_loadu_si512(w + j));
+      _mm512_storeu_si512(d + s + j, v_add(u, v));
+      _mm512_storeu_si512(d + s + j + len, v_sub(u, v));
+    }
+}
+// one decimation-in-frequency stage (len >= 8): d[s+j] = u + v, d[s+j+len] = (u - v) * w[j]
+__attribute__((target("avx512f,avx512dq"))) static void dif_stage_x8(u64* d, size_t n, size_t len, const u64* w) {
+  for (size_t s = 0; s < n; s += 2 * len)
+    for (size_t j = 0; j < len; j += 8) {
+      V u = _mm512_loadu_si512(d + s + j), v = _mm512_loadu_si512(d + s + j + len);
+      _mm512_storeu_si512(d + s + j, v_add(u, v));
+      _mm512_storeu_si512(d + s + j + len, v_mul(v_sub(u, v), _mm512_loadu_si512(w + j)));
+    }
+}
 
 static unsigned log2_exact(size_t n) {
   unsigned l = 0;
@@ -54,6 +80,10 @@ static void fft_core(std::vector<u64>& a, u64 root) {
   }
   for (size_t len = 2; len < n; len <<= 1) {
     const u64* w = tw.data() + len;
+    if (g_fft_tuned && len >= 8) {
+      dit_stage_x8(d, n, len, w);
+      continue;
+    }
     for (size_t s = 0; s < n; s += 2 * len)
       for (size_t j = 0; j < len; j++) {
         u64 u = d[s + j], v = rf_mul(d[s + j + len], w[j]);
@@ -72,6 +102,10 @@ static void fft_dif_core(std::vector<u64>& a, u64 root) {
   u64* d = a.data();
   for (size_t len = n / 2; len >= 2; len >>= 1) {
     const u64* w = tw.data() + len;
+    if (g_fft_tuned && len >= 8) {
+      dif_stage_x8(d, n, len, w);
+      continue;
+    }
     for (size_t s = 0; s < n; s += 2 * len)
       for (size_t j = 0; j < len; j++) {
         u64 u = d[s + j], v = d[s + j + len];

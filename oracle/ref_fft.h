@@ -17,3 +17,6 @@ std::vector<u64> ref_lde_values(const std::vector<u64>& coeffs, unsigned rate_bi
 // the same values at BIT-REVERSED index (out[rbits(i)] = f(shift w^i)): the Merkle-leaf order, computed without a
 // permutation pass (decimation in frequency)
 std::vector<u64> ref_lde_values_bitrev(const std::vector<u64>& coeffs, unsigned rate_bits, u64 shift);
+
+// tuned cpu_baseline leg: AVX-512 butterflies in the stages with >= 8 butterflies per block (same values); off for the checker
+void ref_fft_set_tuned(bool on);

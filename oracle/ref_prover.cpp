@@ -23,6 +23,7 @@ void ref_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 static bool g_tuned = false;
 int ref_set_tuned(int on) {
   g_tuned = on && ref_x8_available();
+  ref_fft_set_tuned(g_tuned);
   return g_tuned ? 1 : 0;
 }
 void ref_set_thread_local_threads(int n) { tl_threads = n < 0 ? 0 : n; }
