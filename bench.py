@@ -825,7 +825,7 @@ def main():
                                  f"pinned thread: {wall1:.1f} s, status {int(st1[0])}",
                        "gpu_proof_bit_exact_vs_this_cpu_proof": bit_exact}
             # (i') the TUNED leg: the same prover with its Merkle hashing and its quotient evaluation eight
-            # at a time on AVX-512 (oracle/ref_hash_x8.cpp, ref_quotient_x8.cpp), same thread count, validated against the scalar
+            # at a time on AVX-512 (oracle/ref_hash_x8.cpp, ref_quotient_x8.cpp, the FFT stages of ref_fft.cpp), same thread count, validated against the scalar
             # proof byte for byte.  This is the number reported as cpu_baseline.value; the scalar one stays beside it.
             cb, tuned_note = None, "no AVX-512 on this host"
             if ora.set_tuned(True):
@@ -834,7 +834,7 @@ def main():
                                                            want_proofs=True)
                     same = bool((prt[0] == pr1[0]).all())
                     cb = {"value": 1.0 / wallt, "unit": "proofs/s", "cores": 1, "kind": "port-tuned", "cpu": model,
-                          "sample": f"1 full fib-64 proof by the oracle with AVX-512 Merkle hashing and quotient evaluation (8 lanes) "
+                          "sample": f"1 full fib-64 proof by the oracle with AVX-512 Merkle hashing, quotient evaluation and FFT butterflies (8 lanes) "
                                     f"on ONE pinned thread: {wallt:.1f} s, status {int(stt[0])}; the scalar oracle: {wall1:.1f} s",
                           "bytes_equal_to_the_scalar_oracle_proof": same,
                           "gpu_proof_bit_exact_vs_this_cpu_proof": bool(gpu_proof0 is not None and (prt[0] == gpu_proof0).all()),
