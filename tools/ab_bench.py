@@ -52,6 +52,8 @@ def child(lib, batch, steps, agg, pipe=0, tstreams="4,2,1"):
         base, cfg = p25.p3_proof_from_json(f.read())
     variants = [base] + [p25.p3_prove_fibonacci(6, 100, 16, pow_start=v << 24)[0] for v in range(1, 8)]
     c = p25.Circuit.build_p3_verifier(cfg)
+    if os.environ.get("P25_AB_STREAMS"):                 # proofs in flight (p25_circuit_set_streams), per variant: name=lib@P25_AB_STREAMS=20
+        c.set_streams(int(os.environ["P25_AB_STREAMS"]))
     c.digest()
     pw = int(c.info.proof_words)
     d_in = torch.from_numpy(np.stack([variants[i % 8] for i in range(batch)]).view(np.int64)).to(dev)
