@@ -1,12 +1,14 @@
 """GPU parity on verifier circuits for other plonky3 proof shapes (inputs from the native p3 prover):
-different circuit sizes (2^11, 2^12, 2^17 rows), FRI schedules and final-polynomial lengths."""
+every circuit size from 2^11 to 2^18 rows (2^16 and 2^19 are the fib-64 and config-5 tests), i.e. every NTT split between the
+single-pass 2^10 and the 2^9 x 2^10 of config 5, FRI schedules of two to four layers and final polynomials of 2^3 .. 2^6."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("log_n,queries,pow_bits", [(3, 4, 8), (4, 10, 8), (8, 100, 16)])
+@pytest.mark.parametrize("log_n,queries,pow_bits", [(3, 4, 8), (4, 10, 8), (6, 12, 8), (6, 25, 8), (6, 50, 8), (8, 100, 16),
+                                                    (11, 100, 16)])   # outer rows 2^11, 2^12, 2^13, 2^14, 2^15, 2^17, 2^18
 def test_gpu_equals_oracle_on_shape(gpu, oracle, log_n, queries, pow_bits):
     inp, cfg = gpu.p3_prove_fibonacci(log_n, queries, pow_bits)
     c = gpu.Circuit.build_p3_verifier(cfg)
