@@ -80,14 +80,12 @@ void lde_commit_dev(const u64* d_polys, unsigned log_n, size_t n_polys, bool fro
                     unsigned rate_bits, unsigned cap_height, u64* d_coeffs, u64* d_tmp, u64* d_lde,
                     u64* d_tree, hipStream_t st) {
   const size_t n = (size_t)1 << log_n;
-  const u64* coeffs = d_polys;
-  if (!from_coeffs) {
-    ntt_inverse(tables(), d_polys, n, false, d_tmp, n, d_coeffs, n, (int)log_n, (int)n_polys, 1, st);
-    coeffs = d_coeffs;
-  }
   const size_t big = n << rate_bits;
-  ntt_lde_bitrev(tables(), coeffs, n, d_lde, big, (int)log_n, (int)rate_bits, (int)n_polys,
-                 gl::GENERATOR, st);
+  if (!from_coeffs)     // values -> coefficients -> LDE: the prover's commit sequence (one combined entry, kernels.h)
+    ntt_inverse_then_lde(tables(), d_polys, n, d_tmp, n, d_coeffs, n, d_lde, big, (int)log_n, (int)rate_bits, (int)n_polys,
+                         gl::GENERATOR, st);
+  else
+    ntt_lde_bitrev(tables(), d_polys, n, d_lde, big, (int)log_n, (int)rate_bits, (int)n_polys, gl::GENERATOR, st);
   if (d_tree) launch_merkle_tree(d_lde, big, (int)n_polys, big, cap_height, d_tree, st);
 }
 }  // namespace p25

@@ -346,8 +346,8 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
   cs_tree_ = DevMem(tw);
   {
     DevMem tmp((size_t)ncs * n);
-    ntt_inverse(tables_, cs_vals_.p, n, false, tmp.p, n, cs_coeffs_.p, n, c_.degree_bits, ncs, 1, stream_);
-    ntt_lde_bitrev(tables_, cs_coeffs_.p, n, cs_lde_.p, big(), c_.degree_bits, c_.cfg.rate_bits, ncs, gl::GENERATOR, stream_);
+    ntt_inverse_then_lde(tables_, cs_vals_.p, n, tmp.p, n, cs_coeffs_.p, n, cs_lde_.p, big(), c_.degree_bits, c_.cfg.rate_bits, ncs,
+                         gl::GENERATOR, stream_);
     launch_merkle_tree(cs_lde_.p, big(), ncs, big(), c_.cfg.cap_height, cs_tree_.p, stream_);
     P25_HIP(hipStreamSynchronize(stream_));
   }
@@ -595,8 +595,7 @@ void DeviceCircuit::prove_one(Ctx& x, int buf, size_t Bstride, uint32_t p, u64* 
   P25_HIP(hipEventRecord(x.done[buf], st));  // last read of this witness-value buffer by this proof
   mark();  // 1
   // "compute wires commitment"
-  ntt_inverse(tables_, x.wires_vals.p, n, false, x.tmp.p, n, x.wires_coeffs.p, n, db, W, 1, st);
-  ntt_lde_bitrev(tables_, x.wires_coeffs.p, n, x.wires_lde.p, B, db, rb, W, gl::GENERATOR, st);
+  ntt_inverse_then_lde(tables_, x.wires_vals.p, n, x.tmp.p, n, x.wires_coeffs.p, n, x.wires_lde.p, B, db, rb, W, gl::GENERATOR, st);
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (kstats_on_) {
@@ -621,8 +620,7 @@ void DeviceCircuit::prove_one(Ctx& x, int buf, size_t Bstride, uint32_t p, u64* 
   enqueue_partial_products(x, st);
   mark();  // 3
   // "commit to partial products, Z's"
-  ntt_inverse(tables_, x.zs_vals.p, n, false, x.tmp.p, n, x.zs_coeffs.p, n, db, nz, 1, st);
-  ntt_lde_bitrev(tables_, x.zs_coeffs.p, n, x.zs_lde.p, B, db, rb, nz, gl::GENERATOR, st);
+  ntt_inverse_then_lde(tables_, x.zs_vals.p, n, x.tmp.p, n, x.zs_coeffs.p, n, x.zs_lde.p, B, db, rb, nz, gl::GENERATOR, st);
   launch_merkle_tree(x.zs_lde.p, B, nz, B, cap_h, x.zs_tree.p, st, nullptr, nullptr, single_proof_);
   const u64* zs_cap = x.zs_tree.p + tw - capw;
   d2d(d_proof + L.zs_cap, zs_cap, capw);
@@ -804,10 +802,8 @@ void DeviceCircuit::quotient(const u64* wires, const u64* zs_pp, const u64* beta
   }
   P25_HIP(hipMemcpyAsync(x.wires_vals.p, wires, (size_t)W * n * 8, hipMemcpyHostToDevice, st));
   P25_HIP(hipMemcpyAsync(x.zs_vals.p, zs_pp, (size_t)nz * n * 8, hipMemcpyHostToDevice, st));
-  ntt_inverse(tables_, x.wires_vals.p, n, false, x.tmp.p, n, x.wires_coeffs.p, n, db, W, 1, st);
-  ntt_lde_bitrev(tables_, x.wires_coeffs.p, n, x.wires_lde.p, B, db, rb, W, gl::GENERATOR, st);
-  ntt_inverse(tables_, x.zs_vals.p, n, false, x.tmp.p, n, x.zs_coeffs.p, n, db, nz, 1, st);
-  ntt_lde_bitrev(tables_, x.zs_coeffs.p, n, x.zs_lde.p, B, db, rb, nz, gl::GENERATOR, st);
+  ntt_inverse_then_lde(tables_, x.wires_vals.p, n, x.tmp.p, n, x.wires_coeffs.p, n, x.wires_lde.p, B, db, rb, W, gl::GENERATOR, st);
+  ntt_inverse_then_lde(tables_, x.zs_vals.p, n, x.tmp.p, n, x.zs_coeffs.p, n, x.zs_lde.p, B, db, rb, nz, gl::GENERATOR, st);
   enqueue_quotient(x, st);
   P25_HIP(hipMemcpyAsync(out, x.q_coeffs.p, (size_t)NC * B * 8, hipMemcpyDeviceToHost, st));
   // context 0 goes back to proving: a circuit without registered public inputs never rewrites the hash words, so put
