@@ -1,0 +1,169 @@
+// Lazy (non-canonical) Goldilocks arithmetic for the NTT butterflies: every operand and every result is ANY u64
+// congruent to the field element it stands for; `gl::canon` brings a value back before it leaves the kernel.
+//
+// Why: a canonical butterfly (gl::add + gl::sub + a canonical twiddle product) costs the compiler 37 VALU instructions
+// on gfx950 (64-bit compare-and-select reductions, v_cndmask pairs); the sequences below are 12 for the sum and the
+// difference together and 6 / 10 / 8 for a product by a power of two, with no compare and no select -- a wrap of the
+// 64-bit register is worth 2^64 = 2^32 - 1 (mod p), so every correction is "low word -= carry, high word += carry
+// unless the low word borrowed", driven by the carry bit itself.  A SECOND wrap is possible (a + b >= 2^64 + p, one
+// pair in 2^32 at random) and is corrected the same way; a third is not (proofs at each function).
+//
+// The plain C++ forms (`*_c`) are the definition: host code and tools/asmcheck.hip compare the gfx950 sequences with them
+// on the device over edge cases (all pairs of 24 boundary values) and random operands.
+//
+// gfx940-family hazard (as in gl.h): a VALU-written SGPR / VCC needs two wait states before a VALU reads it as a carry,
+// and inline asm is opaque to the compiler's hazard recogniser -- hence the interleaving of the two carry chains of a
+// butterfly and the explicit s_nop between dependent steps.
+#pragma once
+#include "gl.h"
+
+namespace gl {
+
+// ---- definitions (any u64 in, any u64 out) --------------------------------------------------------------------------
+// a + b = s + c * 2^64 = s + c * EPS.  If c: s <= 2^64 - 2, t = s + EPS wraps only when s >= p, and then
+// t' = s + EPS - 2^64 < EPS, so t' + EPS < 2^33 cannot wrap again.
+GL_HD u64 add_nc_c(u64 a, u64 b) {
+  u64 s = a + b;
+  if (s < a) {
+    u64 t = s + EPS;
+    if (t < s) t += EPS;
+    s = t;
+  }
+  return s;
+}
+// a - b = d - bw * 2^64 = d - bw * EPS.  If bw and d < EPS the subtraction borrows again: d - EPS + 2^64 >= 2^64 - EPS
+// >= EPS, so the second d - EPS cannot borrow.
+GL_HD u64 sub_nc_c(u64 a, u64 b) {
+  u64 d = a - b;
+  if (a < b) {
+    u64 t = d - EPS;
+    if (d < EPS) t -= EPS;
+    d = t;
+  }
+  return d;
+}
+// x * 2^e, 0 <= e < 96 (2^96 = -1 mod p: larger exponents are a sign, absorbed by the caller)
+GL_HD u64 shl_nc_c(u64 x, int e) {
+  if (e == 0) return x;
+  if (e < 64) return reduce128(x << e, x >> (64 - e));
+  return reduce128(x * (EPS << (e - 64)), mulhi64(x, EPS << (e - 64)));   // 2^64 = EPS
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 sequences -----------------------------------------------------------------------------------------------
+// lo + r2 * 2^64 - r3 * 2^96... i.e. (r3 : r2 : lo) mod p for 32-bit r2, r3 and any 64-bit lo: the tail of mul_nc_asm.
+//   V + c1*2^64 = lo + r2*(2^32-1);  W - bw*2^64 = V - r3;  result = W + (c1 - bw)*(2^32-1).
+// c1 = 1 => V <= 2^64 - 2^33, so W + EPS cannot wrap; bw = 1 => W > 2^64 - 2^32, so W - EPS cannot borrow.
+// 7 VALU + 2 SALU.
+__device__ __forceinline__ u64 fold128_asm(u64 lo, u32 r2, u32 r3) {
+  u64 V, c1, sx, sy;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(V), "=s"(c1) : "v"(r2), "v"(lo));
+  u32 v0 = (u32)V, v1 = (u32)(V >> 32);
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %4\n\ts_nop 1\n\t"      // W.lo = V.lo - r3
+      "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"          // W.hi ; vcc = bw
+      "v_subbrev_co_u32_e64 %0, %2, 0, %0, %5\n\t"            // + c1*(2^32-1): lo -= c1 ...
+      "s_andn2_b64 %2, %5, %2\n\t"
+      "v_addc_co_u32_e64 %1, %3, 0, %1, %2\n\t"               // ... hi += c1 & ~borrow
+      "v_addc_co_u32_e64 %0, %2, 0, %0, vcc\n\t"              // - bw*(2^32-1): lo += bw ...
+      "s_andn2_b64 %2, vcc, %2\n\t"
+      "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"                // ... hi -= bw & ~carry
+      : "+v"(v0), "+v"(v1), "=&s"(sx), "=&s"(sy)
+      : "v"(r3), "s"(c1)
+      : "vcc", "scc");
+  return make64(v0, v1);
+}
+// lo + r2 * 2^64 mod p (r2 32-bit): one multiply-add and one correction, 3 VALU + 1 SALU.
+__device__ __forceinline__ u64 fold96_asm(u64 lo, u32 r2) {
+  u64 V, c1, sx, sy;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(V), "=s"(c1) : "v"(r2), "v"(lo));
+  u32 v0 = (u32)V, v1 = (u32)(V >> 32);
+  asm("s_nop 1\n\t"
+      "v_subbrev_co_u32_e64 %0, %2, 0, %0, %4\n\t"
+      "s_andn2_b64 %2, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, %3, 0, %1, %2"
+      : "+v"(v0), "+v"(v1), "=&s"(sx), "=&s"(sy)
+      : "s"(c1)
+      : "scc");
+  return make64(v0, v1);
+}
+// y0 * 2^64 - Y for a 32-bit y0 and Y < 2^63: y0*EPS - Y, one borrow correction (the wrapped difference is
+// >= 2^64 - 2^63 >= EPS, so it cannot borrow twice).  5 VALU + 1 SALU.
+__device__ __forceinline__ u64 fold_hi_asm(u32 y0, u64 Y) {
+  u64 M, dm, sx, sy;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, 0" : "=v"(M), "=s"(dm) : "v"(y0));
+  u32 m0 = (u32)M, m1 = (u32)(M >> 32), q0 = (u32)Y, q1 = (u32)(Y >> 32);
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %4\n\ts_nop 1\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %5, vcc\n\ts_nop 1\n\t"   // vcc = bw
+      "v_addc_co_u32_e64 %0, %2, 0, %0, vcc\n\t"                // - bw*(2^32-1): lo += bw ...
+      "s_andn2_b64 %2, vcc, %2\n\t"
+      "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"                  // ... hi -= bw & ~carry
+      : "+v"(m0), "+v"(m1), "=&s"(sx), "=&s"(sy)
+      : "v"(q0), "v"(q1)
+      : "vcc", "scc");
+  return make64(m0, m1);
+}
+// x * 2^e for a compile-time e (after unrolling), 0 <= e < 96: the shifts are the compiler's, the folds the ones above.
+__device__ __forceinline__ u64 shl_nc_asm(u64 x, int e) {
+  if (e == 0) return x;
+  if (e < 32) return fold96_asm(x << e, (u32)(x >> (64 - e)));                       // 6 VALU
+  if (e < 64) {
+    const u64 h = x >> (64 - e);
+    return fold128_asm(x << e, (u32)h, (u32)(h >> 32));                                // 10 VALU
+  }
+  const int f = e - 64;   // x * 2^f = y2 : y1 : y0 (y2 < 2^f);  * 2^64 = y0 * EPS - y1 - y2 * 2^32   (2^96 = -1, 2^128 = -2^32)
+  if (f == 0) return fold_hi_asm((u32)x, x >> 32);
+  return fold_hi_asm((u32)x << f, x >> (32 - f));                                      // 8 VALU
+}
+// s = u + v, d = a - b with (a, b) = (u, v) or (v, u): the two carry chains interleaved, each with both corrections.
+// 12 VALU + 4 SALU, no compare, no select.
+__device__ __forceinline__ void bfly_nc_asm(u64 u, u64 v, bool swap, u64& s, u64& d) {
+  const u64 a = swap ? v : u, b = swap ? u : v;
+  u32 u0 = (u32)u, u1 = (u32)(u >> 32), v0 = (u32)v, v1 = (u32)(v >> 32);
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u32 s0, s1, d0, d1;
+  u64 cA, cB, tA, tB;
+  asm("v_add_co_u32_e64 %0, %4, %8, %10\n\t"
+      "v_sub_co_u32_e64 %2, %5, %12, %14\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32_e64 %1, %4, %9, %11, %4\n\t"       // cA = carry of u + v
+      "v_subb_co_u32_e64 %3, %5, %13, %15, %5\n\t"      // cB = borrow of a - b
+      "s_nop 0\n\t"
+      "v_subbrev_co_u32_e64 %0, %6, 0, %0, %4\n\t"      // s += cA * EPS: lo -= cA ...
+      "v_addc_co_u32_e64 %2, %7, 0, %2, %5\n\t"         // d -= cB * EPS: lo += cB ...
+      "s_andn2_b64 %6, %4, %6\n\t"
+      "s_andn2_b64 %7, %5, %7\n\t"
+      "v_addc_co_u32_e64 %1, %4, 0, %1, %6\n\t"         // ... hi += cA & ~borrow ; cA = second carry
+      "v_subbrev_co_u32_e64 %3, %5, 0, %3, %7\n\t"      // ... hi -= cB & ~carry  ; cB = second borrow
+      "s_nop 0\n\t"
+      "v_subbrev_co_u32_e64 %0, %6, 0, %0, %4\n\t"
+      "v_addc_co_u32_e64 %2, %7, 0, %2, %5\n\t"
+      "s_andn2_b64 %6, %4, %6\n\t"
+      "s_andn2_b64 %7, %5, %7\n\t"
+      "v_addc_co_u32_e64 %1, %4, 0, %1, %6\n\t"
+      "v_subbrev_co_u32_e64 %3, %5, 0, %3, %7"
+      : "=&v"(s0), "=&v"(s1), "=&v"(d0), "=&v"(d1), "=&s"(cA), "=&s"(cB), "=&s"(tA), "=&s"(tB)
+      : "v"(u0), "v"(u1), "v"(v0), "v"(v1), "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+      : "scc");
+  s = make64(s0, s1);
+  d = make64(d0, d1);
+}
+#endif
+
+// ---- the forms kernels call -------------------------------------------------------------------------------------------
+GL_HD void bfly_nc(u64 u, u64 v, bool swap, u64& s, u64& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  bfly_nc_asm(u, v, swap, s, d);
+#else
+  s = add_nc_c(u, v);
+  d = swap ? sub_nc_c(v, u) : sub_nc_c(u, v);
+#endif
+}
+GL_HD u64 shl_nc(u64 x, int e) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  return shl_nc_asm(x, e);
+#else
+  return shl_nc_c(x, e);
+#endif
+}
+
+}  // namespace gl

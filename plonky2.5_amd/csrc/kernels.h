@@ -72,6 +72,8 @@ struct NttPass {
   const u64* post_t;     // optional [NT]
   const u64* post_i;     // optional [R]
   int inverse;           // pow_table holds powers of the INVERSE root (selects the 16th-root constants of kernels_ntt.hip)
+  int lazy_out;          // the output is read by another pass of k_ntt_tile only: store any u64 congruent to the value
+                         // (the kernel computes in lazy arithmetic, gl_lazy.h); 0 = canonical, as everything else expects
   uint32_t n_tiles, n_cosets, xcd_map, full_table;  // set by launch_ntt_pass
   uint32_t n_polys, n_blocks_total;                  // set by launch_ntt_pass
 };

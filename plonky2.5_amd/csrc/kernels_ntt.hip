@@ -59,10 +59,10 @@ __device__ __forceinline__ void dif_group(u64* col, const u64* wl, int step, int
     for (int k = 0; k < K; k++) {
       if (k & hk) continue;
       const int j = ((k & (hk - 1)) << lstride) + l;
-      u64 u = x[k], v = x[k + hk];
-      x[k] = gl::add(u, v);
-      u64 d = gl::sub(u, v);
-      x[k + hk] = (hk == 1 && lstride == 0) ? d : gl::mul(d, wl[j << (s0 + m)]);
+      u64 sum, d;
+      gl::bfly_nc(x[k], x[k + hk], false, sum, d);
+      x[k] = sum;
+      x[k + hk] = (hk == 1 && lstride == 0) ? d : gl::mul_nc(d, wl[j << (s0 + m)]);
     }
   }
 #pragma unroll
@@ -84,7 +84,7 @@ __device__ __forceinline__ void dif16_group(u64* col, const u64* wl, int step, i
 #pragma unroll
     for (int k = 1; k < 16; k++) {
       const int f = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
-      x[k] = gl::mul(x[k], wl[(l * f) << s0]);
+      x[k] = gl::mul_nc(x[k], wl[(l * f) << s0]);
     }
   }
 #pragma unroll
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
     }
 #pragma unroll
     for (int k = 0; k < LB; k++) {
-      if constexpr (PRE == 1) lds[slot[k]] = gl::mul(xv[k], pv[k]);
-      else if constexpr (PRE == 2) lds[slot[k]] = gl::mul(gl::mul_nc(xv[k], pre_tv), pv[k]);
+      if constexpr (PRE == 1) lds[slot[k]] = gl::mul_nc(xv[k], pv[k]);
+      else if constexpr (PRE == 2) lds[slot[k]] = gl::mul_nc(gl::mul_nc(xv[k], pre_tv), pv[k]);
       else lds[slot[k]] = xv[k];
     }
   }
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
     int slot, ii;
     in_slot(e, addr, slot, ii);
     u64 x = in[addr];
-    if constexpr (PRE == 1) x = gl::mul(x, pre[addr]);
-    if constexpr (PRE == 2) x = gl::mul(gl::mul_nc(x, pre_tv), pre_i[ii]);
+    if constexpr (PRE == 1) x = gl::mul_nc(x, pre[addr]);
+    if constexpr (PRE == 2) x = gl::mul_nc(gl::mul_nc(x, pre_tv), pre_i[ii]);
     lds[slot] = x;
   }
   __syncthreads();
@@ -258,7 +258,10 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
         xv[k] = lds[slot];
       }
 #pragma unroll
-      for (int k = 0; k < LB; k++) out[addr[k]] = gl::mul(xv[k], wv[k]);
+      for (int k = 0; k < LB; k++) {
+        const u64 y = gl::mul_nc(xv[k], wv[k]);
+        out[addr[k]] = a.lazy_out ? y : gl::canon(y);
+      }
     }
   }
   for (; eo < T * R; eo += nth) {
@@ -266,10 +269,10 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
     int slot;
     u32 tw, j;
     out_slot(eo, addr, slot, tw, j);
-    u64 x = lds[slot];
-    if (a.use_twiddle) x = gl::mul(x, a.pow_table[(size_t)tw * j]);
-    if (a.post_t) x = gl::mul(x, gl::mul(a.post_t[tw], a.post_i[j]));
-    out[addr] = x;
+    u64 x = lds[slot];   // any u64 (lazy network)
+    if (a.use_twiddle) x = gl::mul_nc(x, a.pow_table[(size_t)tw * j]);
+    if (a.post_t) x = gl::mul_nc(x, gl::mul_nc(a.post_t[tw], a.post_i[j]));
+    out[addr] = a.lazy_out ? x : gl::canon(x);
   }
   }
 }
@@ -557,6 +560,7 @@ void ntt_inverse_then_lde(NttTables& tb, const u64* d_vals, size_t val_stride, u
     p.in_kind = 0;
     p.out_kind = 0; p.out_br_i = 0;
     p.use_twiddle = 1;
+    p.lazy_out = 1;
     launch_ntt_pass(p, n_polys, 1, st);
   }
   // the coset pre-scale table of ntt_lde_bitrev (shared cache)
@@ -687,6 +691,7 @@ void ntt_inverse(NttTables& tb, const u64* d_in, size_t in_stride, bool in_bitre
   if (in_bitrev) { p.in_kind = 1; p.in_br_t = 1; p.in_br_i = 1; } else { p.in_kind = 0; }
   p.out_kind = 0; p.out_br_i = 0;
   p.use_twiddle = 1;
+  p.lazy_out = 1;   // read by pass 2 only
   launch_ntt_pass(p, n_polys, 1, st);
   // pass 2: t = j2 (NT = R2), i = k1 (R = R1); output coefficient j2 + R2*j1, scaled
   NttPass q{};
@@ -773,6 +778,7 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
   p.log_r = l2; p.log_nt = l1; p.log_t = pick_log_t(l2, l1, true);
   p.in_kind = 0; p.out_kind = 0; p.out_br_i = 1;
   p.use_twiddle = 1;
+  p.lazy_out = 1;   // read by pass 2 only (in place)
   launch_ntt_pass(p, n_polys, nc, st);
   // pass 2: every row (all cosets: nc*R2 rows of R1 words) in place, bit-reversed within the row
   NttPass q{};

@@ -1,25 +1,18 @@
-// Radix-16 DIF transform on compile-time twiddles (shared by kernels_ntt.hip and its host-side unit test).
+// Radix-16 DIF transform on compile-time twiddles, in lazy (non-canonical) arithmetic (gl_lazy.h).
 #pragma once
-#include "gl.h"
+#include "gl_lazy.h"
 
 namespace p25 {
 
 // ---- radix-16 groups on compile-time twiddles --------------------------------------------------------------------
 // In Goldilocks 2 is a 192nd root of unity (2^96 = -1), so every 16th root of unity is a signed power of two: the
 // library's w_16 (root_of_unity(4)) is 2^156 = -2^60 and its inverse 2^36.  A 16-point DIF network therefore needs
-// no table and no general multiplication: (u - v) * w_16^J is a shift by a constant followed by the 128-bit
-// reduction, and the sign is absorbed by swapping the operands of the subtraction.  Four of the seventeen
-// non-trivial factors have an exponent >= 64 and go through the ordinary multiply with an immediate constant.
-GL_HD u64 mul_pow2(u64 x, int e) {  // x * 2^e, 0 <= e < 96, canonical in/out; e is a constant after unrolling
-  if (e == 0) return x;
-  if (e < 64) return gl::canon(gl::reduce128(x << e, x >> (64 - e)));
-  return gl::mul(x, (u64)0xFFFFFFFFull << (e - 64));  // 2^64 = 2^32 - 1 (mod p)
-}
-template <bool INV>
-GL_HD u64 diff_times_w16(u64 u, u64 v, int J) {  // (u - v) * w_16^J (inverse root if INV)
-  const int e = ((INV ? 36 : 156) * J) % 192;
-  return e >= 96 ? mul_pow2(gl::sub(v, u), e - 96) : mul_pow2(gl::sub(u, v), e);
-}
+// no table and no general multiplication: (u - v) * w_16^J is a shift by a constant followed by a fold of the bits
+// above 2^64 (gl::shl_nc: 6 / 10 / 8 VALU for exponents below 32 / below 64 / below 96), and the sign is absorbed by
+// swapping the operands of the subtraction.  Round 5: every value inside the network is ANY u64 congruent to the
+// element (the canonical form cost 1,043 VALU per 16 points, this one 530: 32 sum/difference pairs of 12 and the
+// seventeen non-trivial shifts 146).
+//
 // Pure 16-point DIF transform of x[0..16) in registers: natural in, bit-reversed out (x[k'] holds frequency rev4(k')).
 template <bool INV>
 GL_HD void dft16(u64 (&x)[16]) {
@@ -29,9 +22,12 @@ GL_HD void dft16(u64 (&x)[16]) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       if (k & hk) continue;
-      const u64 u = x[k], v = x[k + hk];
-      x[k] = gl::add(u, v);
-      x[k + hk] = diff_times_w16<INV>(u, v, (k & (hk - 1)) << m);
+      const int J = (k & (hk - 1)) << m;
+      const int e = ((INV ? 36 : 156) * J) % 192;   // w_16^J = 2^e, and 2^96 = -1
+      u64 s, d;
+      gl::bfly_nc(x[k], x[k + hk], e >= 96, s, d);
+      x[k] = s;
+      x[k + hk] = gl::shl_nc(d, e >= 96 ? e - 96 : e);
     }
   }
 }

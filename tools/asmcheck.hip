@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "poseidon.h"
+#include "ntt16.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 __global__ void k_mul(const u64* a, const u64* b, u64* out_asm, u64* out_c, size_t n) {
@@ -38,6 +39,57 @@ __global__ void k_mds(const u64* in, u64* out_asm, u64* out_c, size_t n, int row
     out_c[i * 12 + k] = gl::add(gl::canon(t[k]), c);
   }
 #endif
+}
+
+// ---- lazy arithmetic of the NTT butterflies (gl_lazy.h) against its C++ definition, and both against canonical arithmetic
+__global__ void k_bfly(const u64* a, const u64* b, u64* out_asm, u64* out_c, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (i >= n) return;
+  u64 s, d, s2, d2;
+  gl::bfly_nc_asm(a[i], b[i], false, s, d);
+  gl::bfly_nc_asm(a[i], b[i], true, s2, d2);
+  out_asm[4 * i] = gl::canon(s); out_asm[4 * i + 1] = gl::canon(d); out_asm[4 * i + 2] = gl::canon(s2); out_asm[4 * i + 3] = gl::canon(d2);
+  const u64 ca = gl::canon(a[i]), cb = gl::canon(b[i]);
+  out_c[4 * i] = gl::add(ca, cb); out_c[4 * i + 1] = gl::sub(ca, cb); out_c[4 * i + 2] = gl::add(ca, cb); out_c[4 * i + 3] = gl::sub(cb, ca);
+  // the C++ definition picks the same representative or at least the same element
+  if (gl::canon(gl::add_nc_c(a[i], b[i])) != out_c[4 * i] || gl::canon(gl::sub_nc_c(a[i], b[i])) != out_c[4 * i + 1]) out_c[4 * i] ^= 1;
+#endif
+}
+template <int E0>
+__global__ void k_shl(const u64* a, u64* out_asm, u64* out_c, size_t n) {   // exponents E0 .. E0 + 7, compile-time each
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (i >= n) return;
+  const u64 x = a[i], cx = gl::canon(x);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    constexpr int dummy = 0; (void)dummy;
+    const int e = E0 + k;
+    out_asm[8 * i + k] = gl::canon(gl::shl_nc_asm(x, e));
+    u64 r = cx;                                   // x * 2^e by e canonical doublings
+    for (int j = 0; j < e; j++) r = gl::add(r, r);
+    if (gl::canon(gl::shl_nc_c(x, e)) != r) r ^= 1;
+    out_c[8 * i + k] = r;
+  }
+#endif
+}
+template <bool INV>
+__global__ void k_dft16(const u64* a, u64* out_fast, u64* out_naive, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 x[16], c[16];
+  for (int k = 0; k < 16; k++) { x[k] = a[16 * i + k]; c[k] = gl::canon(x[k]); }
+  p25::dft16<INV>(x);
+  u64 w = gl::root_of_unity(4);
+  if (INV) w = gl::inv(w);
+  for (int j = 0; j < 16; j++) {
+    u64 acc = 0, wj = gl::pow(w, j), t = 1;
+    for (int k = 0; k < 16; k++) { acc = gl::add(acc, gl::mul(c[k], t)); t = gl::mul(t, wj); }
+    const int pos = ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3);   // frequency j sits at rev4(j)
+    out_naive[16 * i + pos] = acc;
+  }
+  for (int k = 0; k < 16; k++) out_fast[16 * i + k] = gl::canon(x[k]);
 }
 __global__ void k_dump(u64* out) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -114,6 +166,49 @@ int main() {
     bad = 0;
     for (size_t i = 0; i < n; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("mad mismatch a=%016llx b=%016llx asm=%016llx c=%016llx\n", (unsigned long long)a[i], (unsigned long long)b[i], (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
     printf("mad_nc_asm: %d mismatches of %zu\n", bad, n);
+    bad_total += bad;
+  }
+
+  // ---- lazy butterflies: all pairs of boundary values (the double wraps live there), then random operands biased to the top
+  {
+    const u64 edge2[] = {0, 1, 2, 0xFFFFFFFEull, 0xFFFFFFFFull, 0x100000000ull, 0x100000001ull, 0xFFFFFFFF00000000ull, P - 2, P - 1, P, P + 1, P + 2,
+                         ~0ull, ~0ull - 1, ~0ull - 2, 0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFull, 0xFFFFFFFEFFFFFFFFull, 0xFFFFFFFF00000002ull,
+                         0xFFFFFFFFFFFF0000ull, 0xFFFFFFFF0000FFFFull, 0x00000000FFFF0000ull, 0xFFFFFFFE00000000ull};
+    const int ne2 = sizeof(edge2) / 8;
+    size_t k = 0;
+    for (int i = 0; i < ne2; i++) for (int j = 0; j < ne2; j++) { a[k] = edge2[i]; b[k] = edge2[j]; k++; }
+    const size_t nb = 1 << 18;
+    for (; k < nb; k++) {
+      a[k] = rnd(); b[k] = rnd();
+      if ((k & 7) == 1) { a[k] |= 0xFFFFFFFF00000000ull; b[k] |= 0xFFFFFFFF00000000ull; }
+      if ((k & 7) == 2) { a[k] = ~0ull - (rnd() & 0xFFFFFFFFull); b[k] = ~0ull - (rnd() & 0xFFFFFFFFull); }
+      if ((k & 7) == 3) { a[k] &= 0xFFFFFFFFull; b[k] = ~0ull - (rnd() & 0x1FFFFFFFFull); }
+      if ((k & 7) == 4) { b[k] &= 0xFFFFFFFFull; a[k] = ~0ull - (rnd() & 0x1FFFFFFFFull); }
+      if ((k & 7) == 5) { a[k] = rnd() & 0x1FFFFFFFFull; b[k] = a[k] + (rnd() & 3) - 1; }
+    }
+    hipLaunchKernelGGL(k_bfly, dim3(nb / 256), dim3(256), 0, 0, a, b, o1, o2, nb);
+    CK(hipDeviceSynchronize());
+    int bad = 0;
+    for (size_t i = 0; i < nb * 4; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("bfly mismatch a=%016llx b=%016llx out %d asm=%016llx c=%016llx\n", (unsigned long long)a[i / 4], (unsigned long long)b[i / 4], (int)(i & 3), (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    printf("bfly_nc_asm: %d mismatches of %zu\n", bad, nb * 4);
+    bad_total += bad;
+    // shifts: every exponent 0..95 on the same operand list
+#define SHL_RUN(E0) hipLaunchKernelGGL(k_shl<E0>, dim3(nb / 256), dim3(256), 0, 0, a, o1, o2, nb); CK(hipDeviceSynchronize()); \
+    for (size_t i = 0; i < nb * 8; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("shl mismatch x=%016llx e=%d asm=%016llx c=%016llx\n", (unsigned long long)a[i / 8], (int)(E0 + (i & 7)), (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    bad = 0;
+    SHL_RUN(0) SHL_RUN(8) SHL_RUN(16) SHL_RUN(24) SHL_RUN(32) SHL_RUN(40) SHL_RUN(48) SHL_RUN(56) SHL_RUN(64) SHL_RUN(72) SHL_RUN(80) SHL_RUN(88)
+    printf("shl_nc_asm (e = 0..95): %d mismatches of %zu\n", bad, nb * 8 * 12);
+    bad_total += bad;
+    // the 16-point network against the naive DFT (operands: the same list, sixteen at a time)
+    const size_t nd = nb / 16;
+    hipLaunchKernelGGL(k_dft16<false>, dim3(nd / 64), dim3(64), 0, 0, a, o1, o2, nd);
+    CK(hipDeviceSynchronize());
+    bad = 0;
+    for (size_t i = 0; i < nd * 16; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("dft16 fwd mismatch at %zu: %016llx vs %016llx\n", i, (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    hipLaunchKernelGGL(k_dft16<true>, dim3(nd / 64), dim3(64), 0, 0, b, o1, o2, nd);
+    CK(hipDeviceSynchronize());
+    for (size_t i = 0; i < nd * 16; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("dft16 inv mismatch at %zu: %016llx vs %016llx\n", i, (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    printf("dft16 (lazy, fwd + inv) vs naive DFT: %d mismatches of %zu\n", bad, nd * 32);
     bad_total += bad;
   }
   const size_t m = 1 << 16;
