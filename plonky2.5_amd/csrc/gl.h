@@ -152,6 +152,43 @@ __device__ __forceinline__ u64 mad_nc_asm(u64 a, u64 b, u64 addend) {
       : "vcc", "scc");
   return make64(v0, v1);
 }
+// The same with a WAVE-UNIFORM second factor (a compile-time constant, a challenge, a kernel argument): its halves are
+// read straight from SGPRs as the multiply-adds' scalar operand, so a 64-bit constant costs two s_mov instead of two
+// v_mov per use (or two VGPRs for as long as it lives).  a, addend: any u64; non-canonical result.
+__device__ __forceinline__ u64 mad_nc_s_asm(u64 a, u64 b_uniform, u64 addend) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b_uniform, b1 = (u32)(b_uniform >> 32);
+  u64 T, U, P0, P3, c, c1, k0, dm, sx, sy, V;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(T), "=s"(dm) : "v"(a0), "s"(b1));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(U), "=s"(c) : "v"(a1), "s"(b0), "v"(T));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(P0), "=s"(k0) : "v"(a0), "s"(b0), "v"(addend));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(P3), "=s"(dm) : "v"(a1), "s"(b1));
+  u32 p0l = (u32)P0, p0h = (u32)(P0 >> 32), ul = (u32)U, uh = (u32)(U >> 32), p3l = (u32)P3, p3h = (u32)(P3 >> 32);
+  u32 r2;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %3\n\ts_nop 1\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %4, %5, vcc\n\ts_nop 1\n\t"
+      "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, %1, %6\n\ts_nop 1\n\t"
+      "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc"
+      : "+v"(p0h), "=&v"(r2), "+v"(p3h)
+      : "v"(ul), "v"(p3l), "v"(uh), "s"(k0)
+      : "vcc");
+  u64 lo = make64(p0l, p0h);
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(V), "=s"(c1) : "v"(r2), "v"(lo));
+  u32 v0 = (u32)V, v1 = (u32)(V >> 32);
+  asm("s_nop 1\n\t"
+      "v_subb_co_u32_e64 %0, vcc, %0, %4, %5\n\ts_nop 1\n\t"
+      "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_subbrev_co_u32_e64 %0, %2, 0, %0, %6\n\t"
+      "s_andn2_b64 %2, %6, %2\n\t"
+      "v_addc_co_u32_e64 %1, %3, 0, %1, %2\n\t"
+      "v_addc_co_u32_e64 %0, %2, 0, %0, vcc\n\t"
+      "s_andn2_b64 %2, vcc, %2\n\t"
+      "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"
+      : "+v"(v0), "+v"(v1), "=&s"(sx), "=&s"(sy)
+      : "v"(p3h), "s"(c), "s"(c1)
+      : "vcc", "scc");
+  return make64(v0, v1);
+}
 #endif
 // a*b + c, any u64 inputs -> non-canonical result
 GL_HD u64 mad_nc(u64 a, u64 b, u64 c) {
@@ -159,6 +196,15 @@ GL_HD u64 mad_nc(u64 a, u64 b, u64 c) {
   return mad_nc_asm(a, b, c);
 #else
   unsigned __int128 t = (unsigned __int128)a * b + c;
+  return reduce128((u64)t, (u64)(t >> 64));
+#endif
+}
+// a * b_uniform + c for a wave-uniform b (see mad_nc_s_asm)
+GL_HD u64 mad_nc_s(u64 a, u64 b_uniform, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  return mad_nc_s_asm(a, b_uniform, c);
+#else
+  unsigned __int128 t = (unsigned __int128)a * b_uniform + c;
   return reduce128((u64)t, (u64)(t >> 64));
 #endif
 }

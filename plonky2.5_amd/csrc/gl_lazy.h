@@ -147,6 +147,71 @@ __device__ __forceinline__ void bfly_nc_asm(u64 u, u64 v, bool swap, u64& s, u64
   s = make64(s0, s1);
   d = make64(d0, d1);
 }
+// ---- single operations (the quotient's gate evaluators) -------------------------------------------------------------------
+// a + b for ANY a and b <= p (a canonical value, typically a wire or a constant): the sum wraps at most once (after a
+// wrap s = a + b - 2^64 <= b - 1 < p, and s + EPS < 2^64 for s < p).  4 VALU + 1 SALU against the 8 of gl::add.
+__device__ __forceinline__ u64 add_c_asm(u64 a, u64 b) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 sx, sy;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %4\n\ts_nop 1\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %5, vcc\n\ts_nop 1\n\t"
+      "v_subbrev_co_u32_e64 %0, %2, 0, %0, vcc\n\t"
+      "s_andn2_b64 %2, vcc, %2\n\t"
+      "v_addc_co_u32_e64 %1, %3, 0, %1, %2"
+      : "+v"(a0), "+v"(a1), "=&s"(sx), "=&s"(sy)
+      : "v"(b0), "v"(b1)
+      : "vcc", "scc");
+  return make64(a0, a1);
+}
+// a - b for ANY a and b <= p: the difference borrows at most once (a second borrow needs d = a - b + 2^64 < EPS, i.e.
+// b - a > 2^64 - EPS = p).  4 VALU + 1 SALU against the 6 of gl::sub, and the minuend need not be canonical.
+__device__ __forceinline__ u64 sub_c_asm(u64 a, u64 b) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 sx, sy;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %4\n\ts_nop 1\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %5, vcc\n\ts_nop 1\n\t"
+      "v_addc_co_u32_e64 %0, %2, 0, %0, vcc\n\t"
+      "s_andn2_b64 %2, vcc, %2\n\t"
+      "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"
+      : "+v"(a0), "+v"(a1), "=&s"(sx), "=&s"(sy)
+      : "v"(b0), "v"(b1)
+      : "vcc", "scc");
+  return make64(a0, a1);
+}
+// a - b for ANY a and ANY b: both borrows corrected.  6 VALU + 2 SALU.
+__device__ __forceinline__ u64 sub_nc_asm(u64 a, u64 b) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 sx, sy;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %4\n\ts_nop 1\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %5, vcc\n\ts_nop 1\n\t"
+      "v_addc_co_u32_e64 %0, %2, 0, %0, vcc\n\t"
+      "s_andn2_b64 %2, vcc, %2\n\t"
+      "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2\n\ts_nop 1\n\t"    // %3 = second borrow
+      "v_addc_co_u32_e64 %0, %2, 0, %0, %3\n\t"
+      "s_andn2_b64 %2, %3, %2\n\t"
+      "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"
+      : "+v"(a0), "+v"(a1), "=&s"(sx), "=&s"(sy)
+      : "v"(b0), "v"(b1)
+      : "vcc", "scc");
+  return make64(a0, a1);
+}
+// a + b for ANY a and ANY b: both wraps corrected.  6 VALU + 2 SALU.
+__device__ __forceinline__ u64 add_nc_asm(u64 a, u64 b) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 sx, sy;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %4\n\ts_nop 1\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %5, vcc\n\ts_nop 1\n\t"
+      "v_subbrev_co_u32_e64 %0, %2, 0, %0, vcc\n\t"
+      "s_andn2_b64 %2, vcc, %2\n\t"
+      "v_addc_co_u32_e64 %1, %3, 0, %1, %2\n\ts_nop 1\n\t"       // %3 = second carry
+      "v_subbrev_co_u32_e64 %0, %2, 0, %0, %3\n\t"
+      "s_andn2_b64 %2, %3, %2\n\t"
+      "v_addc_co_u32_e64 %1, %3, 0, %1, %2"
+      : "+v"(a0), "+v"(a1), "=&s"(sx), "=&s"(sy)
+      : "v"(b0), "v"(b1)
+      : "vcc", "scc");
+  return make64(a0, a1);
+}
 #endif
 
 // ---- the forms kernels call -------------------------------------------------------------------------------------------
@@ -158,6 +223,41 @@ GL_HD void bfly_nc(u64 u, u64 v, bool swap, u64& s, u64& d) {
   d = swap ? sub_nc_c(v, u) : sub_nc_c(u, v);
 #endif
 }
+// any + any, any - any
+GL_HD u64 add_nc(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  return add_nc_asm(a, b);
+#else
+  return add_nc_c(a, b);
+#endif
+}
+GL_HD u64 sub_nc(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  return sub_nc_asm(a, b);
+#else
+  return sub_nc_c(a, b);
+#endif
+}
+// any + (b <= p), any - (b <= p): one correction.  The caller guarantees the bound on b (a value read from a committed
+// matrix, a challenge, a compile-time constant below p).
+GL_HD u64 add_c(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  return add_c_asm(a, b);
+#else
+  return add_nc_c(a, b);
+#endif
+}
+GL_HD u64 sub_c(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+  return sub_c_asm(a, b);
+#else
+  return sub_nc_c(a, b);
+#endif
+}
+// a - k (mod 2^64, NOT mod p) for a canonical a and a small k: a factor of a vanishing product a (a - 1) ... (a - m), m >= k.
+// The difference wraps only for a < k, and then the product holds the factor (a - a) = 0 exactly, so the product is
+// 0 = the true value whatever this factor reads -- the modular correction of gl::sub (5 instructions) is never needed.
+GL_HD u64 dec_wrap(u64 a, u64 k) { return a - k; }
 GL_HD u64 shl_nc(u64 x, int e) {
 #if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
   return shl_nc_asm(x, e);

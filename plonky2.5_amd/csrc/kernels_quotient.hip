@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include "builder.h"
 #include "kernels.h"
+#include "gl_lazy.h"
 #include "poseidon.h"
 #include "poseidon2.h"
 #include "coop.h"
@@ -90,27 +91,33 @@ struct Ctx {
       }
   }
   // sum_{h,k} acc[h][k] * 2^(32h + 22k) mod p
+  // (any u64 congruent to the sum: every consumer multiplies it)
   __device__ __forceinline__ u64 fold(int ch) const {
-    u64 r = gl::canon(acc[ch][0][0]);
-    r = gl::add(r, gl::mul(acc[ch][0][1], (u64)1 << 22));
-    r = gl::add(r, gl::mul(acc[ch][0][2], (u64)1 << 44));
-    r = gl::add(r, gl::mul(acc[ch][1][0], (u64)1 << 32));
-    r = gl::add(r, gl::mul(acc[ch][1][1], (u64)1 << 54));
+    u64 r = acc[ch][0][0];
+    r = gl::mad_nc_s(acc[ch][0][1], (u64)1 << 22, r);
+    r = gl::mad_nc_s(acc[ch][0][2], (u64)1 << 44, r);
+    r = gl::mad_nc_s(acc[ch][1][0], (u64)1 << 32, r);
+    r = gl::mad_nc_s(acc[ch][1][1], (u64)1 << 54, r);
     // 2^76 = 2^64 * 2^12 = (2^32 - 1) * 2^12 (mod p)
-    r = gl::add(r, gl::mul(acc[ch][1][2], (u64)0xFFFFFFFFull << 12));
+    r = gl::mad_nc_s(acc[ch][1][2], (u64)0xFFFFFFFFull << 12, r);
     return r;
   }
   __device__ __forceinline__ u64 acc0() const { return fold(0); }
   __device__ __forceinline__ u64 acc1() const { return fold(1); }
 };
 
+// Lazy arithmetic (gl_lazy.h) throughout the evaluators: a constraint value goes into the alpha fold (`at`) as ANY u64
+// congruent to it, so nothing here needs a canonical result; what the single-correction forms gl::add_c / gl::sub_c need is
+// a second operand <= p, and every wire, constant column, sigma, challenge and public-input hash word read from memory is
+// canonical.  `bool01(b)` = b (b - 1) and the base-4 range products use gl::dec_wrap (see there).
+__device__ __forceinline__ u64 bool01(u64 b) { return gl::mul_nc(b, gl::dec_wrap(b, 1)); }
 __device__ void gate_constant(Ctx& cx, u64 k0, u64 k1) {
-  cx.at(0, gl::sub(k0, cx.w(0)));
-  cx.at(1, gl::sub(k1, cx.w(1)));
+  cx.at(0, gl::sub_c(k0, cx.w(0)));
+  cx.at(1, gl::sub_c(k1, cx.w(1)));
 }
 __device__ void gate_public_input(Ctx& cx, const u64* __restrict__ pih) {
   // wire_i - public_inputs_hash_i (upstream gates/public_input.rs); the hash of the empty list is [0, 0, 0, 0]
-  for (int i = 0; i < 4; i++) cx.at(i, gl::sub(cx.w(i), pih[i]));
+  for (int i = 0; i < 4; i++) cx.at(i, gl::sub_c(cx.w(i), pih[i]));
 }
 __device__ void gate_base_sum(Ctx& cx) {
   // sum_i limb_i 2^i, i < 63: carry-free groups of eight limbs (cf. SmallLin below), most significant group
@@ -125,25 +132,31 @@ __device__ void gate_base_sum(Ctx& cx) {
       const u32 c = 1u << t;
       asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(al), "=s"(dm) : "v"((u32)l), "s"(c));
       asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(ah), "=s"(dm) : "v"((u32)(l >> 32)), "s"(c));
-      cx.at(1 + i, gl::mul_nc(l, gl::sub(l, 1)));
+      cx.at(1 + i, bool01(l));
     }
     sum = gl::mad_nc(sum, (u64)1 << 8, coop::reduce_row(al, ah));
   }
-  cx.at(0, gl::sub(sum, cx.w(0)));
+  cx.at(0, gl::sub_c(sum, cx.w(0)));
 }
 __device__ void gate_arithmetic(Ctx& cx, u64 k0, u64 k1) {
   for (int i = 0; i < 20; i++) {
     u64 m0 = cx.w(4 * i), m1 = cx.w(4 * i + 1), ad = cx.w(4 * i + 2), o = cx.w(4 * i + 3);
-    u64 comp = gl::add(gl::mul(gl::mul(m0, m1), k0), gl::mul(ad, k1));
-    cx.at(i, gl::sub(o, comp));
+    u64 comp = gl::mad_nc(gl::mul_nc(m0, m1), k0, gl::mul_nc(ad, k1));
+    cx.at(i, gl::sub_nc(o, comp));
   }
+}
+// (a * b) * k in F_p^2 = F_p[X] / (X^2 - 7), any-u64 components: 8 multiplications, no canonical step
+__device__ __forceinline__ gl::E2 e2_mul_scaled(gl::E2 x, gl::E2 y, u64 k) {
+  const u64 ra = gl::mad_nc_s(gl::mul_nc(x.b, y.b), gl::EXT_W, gl::mul_nc(x.a, y.a));
+  const u64 rb = gl::mad_nc(x.a, y.b, gl::mul_nc(x.b, y.a));
+  return gl::E2{gl::mul_nc(ra, k), gl::mul_nc(rb, k)};
 }
 __device__ void gate_mul_ext(Ctx& cx, u64 k0) {
   for (int i = 0; i < 13; i++) {
     gl::E2 a{cx.w(6 * i), cx.w(6 * i + 1)}, b{cx.w(6 * i + 2), cx.w(6 * i + 3)};
-    gl::E2 p = gl::mul(gl::mul(a, b), k0);
-    cx.at(2 * i, gl::sub(cx.w(6 * i + 4), p.a));
-    cx.at(2 * i + 1, gl::sub(cx.w(6 * i + 5), p.b));
+    gl::E2 p = e2_mul_scaled(a, b, k0);
+    cx.at(2 * i, gl::sub_nc(cx.w(6 * i + 4), p.a));
+    cx.at(2 * i + 1, gl::sub_nc(cx.w(6 * i + 5), p.b));
   }
 }
 // Every evaluator below reads its wires ONE ITERATION AHEAD (`nb`, `ni`, `nxt` ...): left to itself the compiler emits
@@ -161,11 +174,11 @@ __device__ void gate_exponentiation(Ctx& cx) {
       nb = cx.w(1 + (EXP_POWER_BITS - 2 - i));
       ni = cx.w(3 + EXP_POWER_BITS + i);
     }
-    u64 sel = gl::mad_nc(bit, base, gl::sub(1, bit));              // bit * base + (1 - bit)
-    cx.at(i, gl::sub(gl::mul_nc(prev, sel), inter));
+    u64 sel = gl::mad_nc(bit, base, gl::sub_c(1, bit));            // bit * base + (1 - bit)
+    cx.at(i, gl::sub_c(gl::mul_nc(prev, sel), inter));
     prev_inter = inter;
   }
-  cx.at(EXP_POWER_BITS, gl::sub(cx.w(1 + EXP_POWER_BITS), prev_inter));
+  cx.at(EXP_POWER_BITS, gl::sub_c(cx.w(1 + EXP_POWER_BITS), prev_inter));
 }
 // sum_i v_i * c_i for small constants c_i (wave-uniform, < 2^15) and 64-bit field values v_i: two carry-free
 // multiply-adds per term on the 32-bit halves, one 5-instruction reduction at the end -- instead of the
@@ -191,12 +204,12 @@ __device__ void gate_u32_arithmetic(Ctx& cx) {
     const int cb = 36 * i;
     u64 m0 = cx.w(6 * i), m1 = cx.w(6 * i + 1), ad = cx.w(6 * i + 2);
     u64 lo = cx.w(6 * i + 3), hi = cx.w(6 * i + 4), inv = cx.w(6 * i + 5);
-    u64 computed = gl::add(gl::mul(m0, m1), ad);
-    u64 diff = gl::sub(0xFFFFFFFFull, hi);
-    u64 hi_not_max = gl::sub(gl::mul(inv, diff), 1);
+    u64 computed = gl::mad_nc(m0, m1, ad);
+    u64 diff = gl::sub_c(0xFFFFFFFFull, hi);
+    u64 hi_not_max = gl::sub_c(gl::mul_nc(inv, diff), 1);
     cx.at(cb, gl::mul_nc(hi_not_max, lo));
-    u64 combined = gl::add(gl::mul(hi, (u64)1 << 32), lo);
-    cx.at(cb + 1, gl::sub(combined, computed));
+    u64 combined = gl::mad_nc_s(hi, (u64)1 << 32, lo);
+    cx.at(cb + 1, gl::sub_nc(combined, computed));
     // 32 base-4 limbs, most significant first: limbs 31..16 make the high word, 15..0 the low word
     u64 part[4];
     u64 nxt = cx.w(18 + 32 * i + 31);
@@ -207,15 +220,15 @@ __device__ void gate_u32_arithmetic(Ctx& cx) {
         const int j = 31 - 8 * q - t;
         const u64 l = nxt;
         if (j > 0) nxt = cx.w(18 + 32 * i + j - 1);
-        u64 pr = gl::mul_nc(gl::mul_nc(l, gl::sub(l, 1)), gl::mul_nc(gl::sub(l, 2), gl::sub(l, 3)));
+        u64 pr = gl::mul_nc(gl::mul_nc(l, gl::dec_wrap(l, 1)), gl::mul_nc(gl::dec_wrap(l, 2), gl::dec_wrap(l, 3)));
         cx.at(cb + 2 + (31 - j), pr);
         acc.add(l, 1u << (2 * (7 - t)));
       }
       part[q] = acc.value();
     }
     const u64 ch = gl::mad_nc(part[0], (u64)1 << 16, part[1]), cl = gl::mad_nc(part[2], (u64)1 << 16, part[3]);
-    cx.at(cb + 34, gl::sub(cl, lo));
-    cx.at(cb + 35, gl::sub(ch, hi));
+    cx.at(cb + 34, gl::sub_c(cl, lo));
+    cx.at(cb + 35, gl::sub_c(ch, hi));
   }
 }
 __device__ void gate_u32_interleave(Ctx& cx) {
@@ -232,13 +245,13 @@ __device__ void gate_u32_interleave(Ctx& cx) {
         if (b < 31) nxt = cx.w(6 + 32 * i + b + 1);
         ax.add(bit, 1u << (7 - t));
         axi.add(bit, 1u << (2 * (7 - t)));
-        cx.at(cb + 2 + b, gl::mul_nc(bit, gl::sub(bit, 1)));
+        cx.at(cb + 2 + b, bool01(bit));
       }
       xq[q] = ax.value();
       xiq[q] = axi.value();
     }
-    cx.at(cb, gl::sub(join4(xq, 8), cx.w(2 * i)));
-    cx.at(cb + 1, gl::sub(join4(xiq, 16), cx.w(2 * i + 1)));
+    cx.at(cb, gl::sub_c(join4(xq, 8), cx.w(2 * i)));
+    cx.at(cb + 1, gl::sub_c(join4(xiq, 16), cx.w(2 * i + 1)));
   }
 }
 __device__ void gate_u32_uninterleave(Ctx& cx) {
@@ -260,78 +273,166 @@ __device__ void gate_u32_uninterleave(Ctx& cx) {
         ax.add(bo, 1u << (2 * (7 - t)));
         aev.add(be, 1u << (7 - t));
         aod.add(bo, 1u << (7 - t));
-        cx.at(cb + 3 + 2 * j, gl::mul_nc(be, gl::sub(be, 1)));
-        cx.at(cb + 3 + 2 * j + 1, gl::mul_nc(bo, gl::sub(bo, 1)));
+        cx.at(cb + 3 + 2 * j, bool01(be));
+        cx.at(cb + 3 + 2 * j + 1, bool01(bo));
       }
       xq[q] = ax.value();
       evq[q] = aev.value();
       odq[q] = aod.value();
     }
-    cx.at(cb, gl::sub(join4(xq, 16), cx.w(3 * i)));
-    cx.at(cb + 1, gl::sub(join4(evq, 8), cx.w(3 * i + 1)));
-    cx.at(cb + 2, gl::sub(join4(odq, 8), cx.w(3 * i + 2)));
+    cx.at(cb, gl::sub_c(join4(xq, 16), cx.w(3 * i)));
+    cx.at(cb + 1, gl::sub_c(join4(evq, 8), cx.w(3 * i + 1)));
+    cx.at(cb + 2, gl::sub_c(join4(odq, 8), cx.w(3 * i + 2)));
   }
 }
+// ---- Poseidon2's linear layers for the gate evaluator, in lazy arithmetic (any u64 in, any u64 out) -----------------------
+// The external layer (poseidon2.rs:126-147: M4 on each block of four, then the column sums) is the 12 x 12 matrix
+// circ(2 M4, M4, M4), M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]: entries <= 14, row sums 64.  As 62 modular additions it
+// costs ~500 VALU; on the 32-bit halves it is 24 carry-free v_mad_u64_u32 with inline-constant entries per output word and
+// the 5-instruction row reduction of poseidon_p3r.h -- 348 -- and the constants the NEXT round adds ride in as the addend of
+// each row's first multiply-add, read from SGPRs, exactly as in the Poseidon MDS layer (poseidon.h: mds_rc).
+namespace p2lazy {
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int ext_coef(int i, int j) {
+  constexpr int M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
+  return M4[i & 3][j & 3] * ((i >> 2) == (j >> 2) ? 2 : 1);
+}
+// rows of zero-extended (lo, hi) halves: 0..7 the full rounds' constants, 8 = (RC_MID[0], 0, ..., 0) (the layer that
+// leads into the partial rounds), 9 = zeros (the last layer)
+struct RcSplit {
+  u64 v[10 * 12 * 2];
+};
+constexpr RcSplit make_rc_split() {
+  RcSplit t{};
+  for (int i = 0; i < 96; i++) {
+    t.v[2 * i] = poseidon2::P2_RC[i] & 0xFFFFFFFFull;
+    t.v[2 * i + 1] = poseidon2::P2_RC[i] >> 32;
+  }
+  t.v[2 * 96] = poseidon2::P2_RC_MID[0] & 0xFFFFFFFFull;
+  t.v[2 * 96 + 1] = poseidon2::P2_RC_MID[0] >> 32;
+  return t;
+}
+static constexpr RcSplit RC_SPLIT = make_rc_split();
+typedef const u64 __attribute__((address_space(4))) * rc_ptr;   // constant address space: scalar loads
+
+template <int I, int J>
+__device__ __forceinline__ void ext_terms(u64& al, u64& ah, const u32* lo, const u32* hi) {
+  if constexpr (J < 12) {
+    poseidon::mad_k<ext_coef(I, J)>(al, lo[J]);
+    poseidon::mad_k<ext_coef(I, J)>(ah, hi[J]);
+    ext_terms<I, J + 1>(al, ah, lo, hi);
+  }
+}
+template <int I>
+__device__ __forceinline__ void ext_rows(u64* s, const u32* lo, const u32* hi, rc_ptr k) {
+  if constexpr (I < 12) {
+    u64 al, ah, dm;
+    asm("v_mad_u64_u32 %0, %1, %2, %4, %3" : "=v"(al), "=s"(dm) : "v"(lo[0]), "s"(k[2 * I]), "n"(ext_coef(I, 0)));
+    asm("v_mad_u64_u32 %0, %1, %2, %4, %3" : "=v"(ah), "=s"(dm) : "v"(hi[0]), "s"(k[2 * I + 1]), "n"(ext_coef(I, 0)));
+    ext_terms<I, 1>(al, ah, lo, hi);
+    s[I] = poseidon::p3r::reduce_row(al, ah);   // al, ah < 2^32 * 65
+    ext_rows<I + 1>(s, lo, hi, k);
+  }
+}
+// s <- E s + (constants row `row` of RC_SPLIT)
+__device__ __forceinline__ void external(u64 s[12], int row) {
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+  ext_rows<0>(s, lo, hi, (rc_ptr)RC_SPLIT.v + 24 * row);
+}
+// s_i <- s_i (d_i - 1) + sum_j s_j (poseidon2.rs:163-182): the sum carry-free on the halves, one fused multiply-add per
+// word with the diagonal entry read from SGPRs; no canonical step
+template <int I>
+__device__ __forceinline__ void int_rows(u64* s, u64 sum) {
+  if constexpr (I < 12) {
+    s[I] = gl::mad_nc_s(s[I], poseidon2::P2_MAT_DIAG_M_1[I] - 1, sum);
+    int_rows<I + 1>(s, sum);
+  }
+}
+__device__ __forceinline__ void internal(u64 s[12]) {
+  u64 al = 0, ah = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    poseidon::mad_k<1>(al, (u32)s[i]);
+    poseidon::mad_k<1>(ah, (u32)(s[i] >> 32));
+  }
+  int_rows<0>(s, poseidon::p3r::reduce_row(al, ah));
+}
+__device__ __forceinline__ u64 sbox(u64 x) {   // x^7, any u64 in and out
+  const u64 x2 = gl::mul_nc(x, x), x4 = gl::mul_nc(x2, x2), x3 = gl::mul_nc(x, x2);
+  return gl::mul_nc(x3, x4);
+}
+#else   // the host pass only parses the kernels
+__device__ __forceinline__ void external(u64*, int) {}
+__device__ __forceinline__ void internal(u64*) {}
+__device__ __forceinline__ u64 sbox(u64 x) { return x; }
+#endif
+}  // namespace p2lazy
+
 // poseidon2_gate.rs:233-310
-__device__ void gate_poseidon2(Ctx& cx) {
+__device__ __forceinline__ void gate_poseidon2(Ctx& cx) {
   using namespace poseidon2;
   int nc = 0;
   u64 swap = cx.w(24);
-  cx.at(nc++, gl::mul_nc(swap, gl::sub(swap, 1)));
+  cx.at(nc++, bool01(swap));
   u64 st[12];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     u64 lhs = cx.w(i), rhs = cx.w(i + 4), delta = cx.w(25 + i);
-    cx.at(nc++, gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
-    st[i] = gl::add(lhs, delta);
-    st[i + 4] = gl::sub(rhs, delta);
+    cx.at(nc++, gl::sub_c(gl::mul_nc(swap, gl::sub_c(rhs, lhs)), delta));
+    st[i] = gl::add_c(lhs, delta);
+    st[i + 4] = gl::sub_c(rhs, delta);
   }
 #pragma unroll
   for (int i = 8; i < 12; i++) st[i] = cx.w(i);
-  matmul_external(st);
+  p2lazy::external(st, 0);              // ... + the constants of round 0
   for (int r = 0; r < ROUND_F_BEGIN; r++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2_RC[12 * r + i]);
     if (r != 0) {
       u64 nxt = cx.w(29 + 12 * (r - 1));
 #pragma unroll
       for (int i = 0; i < 12; i++) {
         const u64 sb = nxt;
         if (i < 11) nxt = cx.w(29 + 12 * (r - 1) + i + 1);
-        cx.at(nc++, gl::sub(st[i], sb));
+        cx.at(nc++, gl::sub_c(st[i], sb));
         st[i] = sb;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = sbox(st[i]);
-    matmul_external(st);
+    for (int i = 0; i < 12; i++) st[i] = p2lazy::sbox(st[i]);
+    p2lazy::external(st, r + 1 < ROUND_F_BEGIN ? r + 1 : 8);   // ... + round r + 1's constants / RC_MID[0] on word 0
   }
   u64 nsb = cx.w(65);
   for (int r = 0; r < ROUND_P; r++) {
-    st[0] = gl::add(st[0], P2_RC_MID[r]);
     const u64 sb = nsb;
     if (r + 1 < ROUND_P) nsb = cx.w(66 + r);
-    cx.at(nc++, gl::sub(st[0], sb));
-    st[0] = sbox(sb);
-    matmul_internal(st);
+    cx.at(nc++, gl::sub_c(st[0], sb));
+    st[0] = p2lazy::sbox(sb);
+    p2lazy::internal(st);
+    if (r + 1 < ROUND_P) st[0] = gl::add_c(st[0], P2_RC_MID[r + 1]);
   }
   for (int r = ROUND_F_BEGIN; r < ROUND_F_END; r++) {
+    if (r == ROUND_F_BEGIN) {   // the internal layer carries no constants: round 4's are added here
 #pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2_RC[12 * r + i]);
+      for (int i = 0; i < 12; i++) st[i] = gl::add_c(st[i], P2_RC[12 * ROUND_F_BEGIN + i]);
+    }
     u64 nxt = cx.w(87 + 12 * (r - ROUND_F_BEGIN));
 #pragma unroll
     for (int i = 0; i < 12; i++) {
       const u64 sb = nxt;
       if (i < 11) nxt = cx.w(87 + 12 * (r - ROUND_F_BEGIN) + i + 1);
-      cx.at(nc++, gl::sub(st[i], sb));
+      cx.at(nc++, gl::sub_c(st[i], sb));
       st[i] = sb;
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = sbox(st[i]);
-    matmul_external(st);
+    for (int i = 0; i < 12; i++) st[i] = p2lazy::sbox(st[i]);
+    p2lazy::external(st, r + 1 < ROUND_F_END ? r + 1 : 9);
   }
 #pragma unroll
-  for (int i = 0; i < 12; i++) cx.at(nc++, gl::sub(st[i], cx.w(12 + i)));
+  for (int i = 0; i < 12; i++) cx.at(nc++, gl::sub_c(st[i], cx.w(12 + i)));
 }
 
 // upstream gates/arithmetic_extension.rs: out - (c0 * m0 * m1 + c1 * addend) in F_p^2, 10 ops of 8 wires
@@ -607,11 +708,11 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   u64 res[2] = {0, 0};
   // --- L_0(x) (Z_c(x) - 1): terms 0..NC
   {
-    u64 l0 = gl::mul(zhx, a.l0_inv[p]);  // 1 / (n (x - 1)), per circuit (k_l0_inv)
+    u64 l0 = gl::mul_nc(zhx, a.l0_inv[p]);  // 1 / (n (x - 1)), per circuit (k_l0_inv)
     for (int c = 0; c < NC; c++) {
-      u64 t = gl::mul(l0, gl::sub(zsc.col(c), 1));
-      res[0] = gl::add(res[0], gl::mul(t, ap[c]));
-      res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + c]));
+      u64 t = gl::mul_nc(l0, gl::sub_c(zsc.col(c), 1));
+      res[0] = gl::mad_nc(t, ap[c], res[0]);          // res: any u64 from here on, canonical again in the final product
+      res[1] = gl::mad_nc(t, ap[ALPHA_POWS + c], res[1]);
     }
   }
   auto gate_filter = [&](uint32_t gi) {
@@ -619,8 +720,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const u64 s = csc.col(ge.selector_index);
     u64 filter = 1;
     for (uint32_t k = ge.group_start; k < ge.group_end; k++)
-      if (k != gi) filter = gl::mul(filter, gl::sub((u64)k, s));
-    if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
+      if (k != gi) filter = gl::mul_nc(filter, gl::sub_c((u64)k, s));
+    if (a.num_selectors > 1) filter = gl::mul_nc(filter, gl::sub_c(0xFFFFFFFFull, s));
     return filter;
   };
   // --- partial-product checks: terms NC + c*nch + k.  Both challenges in ONE pass over the routed wires and their
@@ -640,13 +741,13 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   auto perm_chunk = [&](int k, u64 n0, u64 d0, u64 n1, u64 d1) {
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      const u64 np = gl::canon(c ? n1 : n0), dp = gl::canon(c ? d1 : d0);
+      const u64 np = c ? n1 : n0, dp = c ? d1 : d0;
       u64 prev = k == 0 ? zsc.col(c) : zsc.col(NC + c * NP + k - 1);
       u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zsc.col(NC + c * NP + k);
-      u64 t = gl::sub(gl::mul(prev, np), gl::mul(next, dp));
+      u64 t = gl::sub_nc(gl::mul_nc(prev, np), gl::mul_nc(next, dp));
       int ti = NC + c * nch + k;
-      res[0] = gl::add(res[0], gl::mul(t, ap[ti]));
-      res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + ti]));
+      res[0] = gl::mad_nc(t, ap[ti], res[0]);
+      res[1] = gl::mad_nc(t, ap[ALPHA_POWS + ti], res[1]);
     }
   };
   bool perm_done = false;
@@ -694,7 +795,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     if (P25_Q_MERGE_PERM) {   /* the permutation argument on the same read of the wire (both challenges) */        \
       const u64 sg = snext;                                                                                     \
       if (j + 1 < 80) snext = csc.col(n_consts + 2 + j + 1);                                                     \
-      const u64 wg0 = gl::add(w, gamma0), wg1 = gl::add(w, gamma1);                                             \
+      const u64 wg0 = gl::add_c(w, gamma0), wg1 = gl::add_c(w, gamma1);                                         \
       if ((JJ) % 8 == 0) {                                                                                      \
         pn0 = gl::mad_nc(kb[j], x, wg0);                                                                        \
         pd0 = gl::mad_nc(beta0, sg, wg0);                                                                       \
@@ -709,15 +810,15 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
       if ((JJ) % 8 == 7) perm_chunk(j >> 3, pn0, pd0, pn1, pd1);                                                \
     }                                                                                                           \
     if ((JJ) < 4 && base == 0) {                                                                                \
-      if (h_const && (JJ) < 2) mc.at((JJ), gl::mul_nc(gl::sub((JJ) == 0 ? k0 : k1, w), f_const));              \
-      if (h_pi) mc.at((JJ), gl::mul_nc(gl::sub(w, a.pi_hash[(JJ)]), f_pi));                                     \
+      if (h_const && (JJ) < 2) mc.at((JJ), gl::mul_nc(gl::sub_c((JJ) == 0 ? k0 : k1, w), f_const));            \
+      if (h_pi) mc.at((JJ), gl::mul_nc(gl::sub_c(w, a.pi_hash[(JJ)]), f_pi));                                   \
     }                                                                                                           \
     if (h_bsum) {                                                                                               \
       if (j == 0) bs_w0 = w;                                                                                    \
       if (j >= 1 && j <= BASE_SUM_LIMBS) {                                                                      \
         constexpr int t = ((JJ) + 7) % 8;   /* limb i = j - 1, position i mod 8 of its group of eight */          \
         bs_acc.add(w, 1u << t);                                                                                 \
-        mc.at(j, gl::mul_nc(gl::mul_nc(w, gl::sub(w, 1)), f_bsum));                                             \
+        mc.at(j, gl::mul_nc(bool01(w), f_bsum));                                                                \
         if (t == 7 || j == BASE_SUM_LIMBS) {                                                                    \
           bs_sum = gl::mad_nc(bs_acc.value(), (u64)1 << (8 * (((j - 1) >> 3) & 7)), bs_sum);                          \
           bs_acc = SmallLin();                                                                                  \
@@ -729,8 +830,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
       else if ((JJ) % 4 == 1) ar1 = w;                                                                          \
       else if ((JJ) % 4 == 2) ar2 = w;                                                                          \
       else {                                                                                                    \
-        const u64 comp = gl::add(gl::mul(gl::mul(ar0, ar1), k0), gl::mul(ar2, k1));                             \
-        mc.at(j >> 2, gl::mul_nc(gl::sub(w, comp), f_arith));                                                   \
+        const u64 comp = gl::mad_nc(gl::mul_nc(ar0, ar1), k0, gl::mul_nc(ar2, k1));                             \
+        mc.at(j >> 2, gl::mul_nc(gl::sub_nc(w, comp), f_arith));                                                \
       }                                                                                                         \
     }                                                                                                           \
     if (h_mext && j < 78) {                                                                                     \
@@ -740,10 +841,10 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
       else if ((JJ) % 6 == 3) mx3 = w;                                                                          \
       else if ((JJ) % 6 == 4) mx4 = w;                                                                          \
       else {                                                                                                    \
-        const gl::E2 pr = gl::mul(gl::mul(gl::E2{mx0, mx1}, gl::E2{mx2, mx3}), k0);                             \
+        const gl::E2 pr = e2_mul_scaled(gl::E2{mx0, mx1}, gl::E2{mx2, mx3}, k0);                                \
         const int op = j / 6;                                                                                   \
-        mc.at(2 * op, gl::mul_nc(gl::sub(mx4, pr.a), f_mext));                                                  \
-        mc.at(2 * op + 1, gl::mul_nc(gl::sub(w, pr.b), f_mext));                                                \
+        mc.at(2 * op, gl::mul_nc(gl::sub_nc(mx4, pr.a), f_mext));                                               \
+        mc.at(2 * op + 1, gl::mul_nc(gl::sub_nc(w, pr.b), f_mext));                                             \
       }                                                                                                         \
     }                                                                                                           \
   }
@@ -758,7 +859,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     }
 #undef P25_Q_WIRES8
 #undef P25_Q_WIRE
-    if (h_bsum) mc.at(0, gl::mul_nc(gl::sub(bs_sum, bs_w0), f_bsum));
+    if (h_bsum) mc.at(0, gl::mul_nc(gl::sub_c(bs_sum, bs_w0), f_bsum));
     mg0 = mc.acc0();
     mg1 = mc.acc1();
     perm_done = P25_Q_MERGE_PERM;
@@ -788,7 +889,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
             wq[d] = wrc.col(j + PF);
             sq[d] = csc.col(n_consts + 2 + j + PF);
           }
-          const u64 wg0 = gl::add(w, gamma0), wg1 = gl::add(w, gamma1);
+          const u64 wg0 = gl::add_c(w, gamma0), wg1 = gl::add_c(w, gamma1);
           np0 = gl::mul_nc(np0, gl::mad_nc(kb[j], x, wg0));
           dp0 = gl::mul_nc(dp0, gl::mad_nc(beta0, sg, wg0));
           np1 = gl::mul_nc(np1, gl::mad_nc(kb[RW + j], x, wg1));
@@ -797,13 +898,13 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
       }
 #pragma unroll
       for (int c = 0; c < NC; c++) {
-        const u64 np = gl::canon(c ? np1 : np0), dp = gl::canon(c ? dp1 : dp0);
+        const u64 np = c ? np1 : np0, dp = c ? dp1 : dp0;
         u64 prev = k == 0 ? zsc.col(c) : zsc.col(NC + c * NP + k - 1);
         u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zsc.col(NC + c * NP + k);
-        u64 t = gl::sub(gl::mul(prev, np), gl::mul(next, dp));
+        u64 t = gl::sub_nc(gl::mul_nc(prev, np), gl::mul_nc(next, dp));
         int ti = NC + c * nch + k;
-        res[0] = gl::add(res[0], gl::mul(t, ap[ti]));
-        res[1] = gl::add(res[1], gl::mul(t, ap[ALPHA_POWS + ti]));
+        res[0] = gl::mad_nc(t, ap[ti], res[0]);
+        res[1] = gl::mad_nc(t, ap[ALPHA_POWS + ti], res[1]);
       }
     }
   }
@@ -865,12 +966,12 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
           break;
         default: break;  // NoopGate: no constraints
       }
-      g0 = gl::add(g0, gl::mul(filter, cx.acc0()));
-      g1 = gl::add(g1, gl::mul(filter, cx.acc1()));
+      g0 = gl::mad_nc(filter, cx.acc0(), g0);
+      g1 = gl::mad_nc(filter, cx.acc1(), g1);
     }
     const int off = NC * (1 + nch);
-    res[0] = gl::add(res[0], gl::mul(g0, ap[off]));
-    res[1] = gl::add(res[1], gl::mul(g1, ap[ALPHA_POWS + off]));
+    res[0] = gl::mad_nc(g0, ap[off], res[0]);
+    res[1] = gl::mad_nc(g1, ap[ALPHA_POWS + off], res[1]);
   }
   a.out[p] = gl::mul(res[0], zhi);
   a.out[big + p] = gl::mul(res[1], zhi);

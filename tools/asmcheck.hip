@@ -91,6 +91,31 @@ __global__ void k_dft16(const u64* a, u64* out_fast, u64* out_naive, size_t n) {
   }
   for (int k = 0; k < 16; k++) out_fast[16 * i + k] = gl::canon(x[k]);
 }
+
+// single lazy operations of the quotient's evaluators: any + any, any - any, any +/- (b <= p), the scalar-operand multiply-add,
+// and the wrapped decrements inside vanishing products (canonical a)
+__global__ void k_single(const u64* a, const u64* b, u64* out_asm, u64* out_c, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (i >= n) return;
+  const u64 x = a[i], y = b[i], cx = gl::canon(x), cy = gl::canon(y);
+  const u64 yb = y > gl::P ? gl::P : y;          // a legal second operand of the single-correction forms (<= p)
+  u64* o = out_asm + 8 * i; u64* r = out_c + 8 * i;
+  o[0] = gl::canon(gl::add_nc_asm(x, y));  r[0] = gl::add(cx, cy);
+  o[1] = gl::canon(gl::sub_nc_asm(x, y));  r[1] = gl::sub(cx, cy);
+  o[2] = gl::canon(gl::add_c_asm(x, yb));  r[2] = gl::add(cx, gl::canon(yb));
+  o[3] = gl::canon(gl::sub_c_asm(x, yb));  r[3] = gl::sub(cx, gl::canon(yb));
+  // wave-uniform factor: the block's first operand, made uniform per wave
+  const u64 ku = b[(i / 64) * 64];
+  o[4] = gl::canon(gl::mad_nc_s_asm(x, ku, y));  r[4] = gl::add(gl::mul(cx, gl::canon(ku)), cy);
+  // vanishing products on canonical values, small ones included
+  const u64 l = (i & 1) ? (cx & 7) : cx;
+  o[5] = gl::canon(gl::mul_nc(l, gl::dec_wrap(l, 1)));  r[5] = gl::mul(l, gl::sub(l, 1));
+  o[6] = gl::canon(gl::mul_nc(gl::mul_nc(l, gl::dec_wrap(l, 1)), gl::mul_nc(gl::dec_wrap(l, 2), gl::dec_wrap(l, 3))));
+  r[6] = gl::mul(gl::mul(l, gl::sub(l, 1)), gl::mul(gl::sub(l, 2), gl::sub(l, 3)));
+  o[7] = gl::canon(gl::sub_c_asm(y, 1) );  r[7] = gl::sub(cy, 1);
+#endif
+}
 __global__ void k_dump(u64* out) {
 #if defined(__HIP_DEVICE_COMPILE__)
   for (int i = 0; i < 48; i++) out[i] = poseidon::RC_SPLIT.v[696 + i];
@@ -191,6 +216,12 @@ int main() {
     int bad = 0;
     for (size_t i = 0; i < nb * 4; i++) if (o1[i] != o2[i]) { if (bad < 5) printf("bfly mismatch a=%016llx b=%016llx out %d asm=%016llx c=%016llx\n", (unsigned long long)a[i / 4], (unsigned long long)b[i / 4], (int)(i & 3), (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
     printf("bfly_nc_asm: %d mismatches of %zu\n", bad, nb * 4);
+    bad_total += bad;
+    hipLaunchKernelGGL(k_single, dim3(nb / 256), dim3(256), 0, 0, a, b, o1, o2, nb);
+    CK(hipDeviceSynchronize());
+    bad = 0;
+    for (size_t i = 0; i < nb * 8; i++) if (o1[i] != o2[i]) { if (bad < 8) printf("single-op mismatch a=%016llx b=%016llx op %d asm=%016llx c=%016llx\n", (unsigned long long)a[i / 8], (unsigned long long)b[i / 8], (int)(i & 7), (unsigned long long)o1[i], (unsigned long long)o2[i]); bad++; }
+    printf("add_nc / sub_nc / add_c / sub_c / mad_nc_s / vanishing products: %d mismatches of %zu\n", bad, nb * 8);
     bad_total += bad;
     // shifts: every exponent 0..95 on the same operand list
 #define SHL_RUN(E0) hipLaunchKernelGGL(k_shl<E0>, dim3(nb / 256), dim3(256), 0, 0, a, o1, o2, nb); CK(hipDeviceSynchronize()); \
