@@ -266,4 +266,13 @@ GL_HD u64 shl_nc(u64 x, int e) {
 #endif
 }
 
+// x * y in F_p[X] / (X^2 - 7), any-u64 components in and out: five multiplications, two of them fused multiply-adds,
+// no canonical step (gl::mul(E2, E2) pays five canonical products and two canonical additions: 106 VALU against 74)
+GL_HD E2 e2_mul_nc(E2 x, E2 y) {
+  const u64 a = mad_nc_s(mul_nc(x.b, y.b), EXT_W, mul_nc(x.a, y.a));
+  const u64 b = mad_nc(x.a, y.b, mul_nc(x.b, y.a));
+  return E2{a, b};
+}
+GL_HD E2 e2_canon(E2 x) { return E2{canon(x.a), canon(x.b)}; }
+
 }  // namespace gl

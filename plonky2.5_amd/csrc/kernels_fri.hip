@@ -7,6 +7,7 @@
 //   fri_prover_query_rounds              -> launch_queries
 // SURVEY.md App. A.7-A.8.  Extension-field vectors are stored as two component arrays (a[], b[]).
 #include "kernels.h"
+#include "gl_lazy.h"
 #include "coop.h"
 #include "coop_lat.h"
 #include "poseidon.h"
@@ -22,9 +23,13 @@ __global__ void k_ext_pows(const u64* __restrict__ point, u64 scale, uint32_t co
   if (t > count) return;
   gl::E2 z = gl::mul(gl::E2{point[0], point[1]}, scale);
   if (invert) z = gl::inv(z);
-  gl::E2 r = gl::pow(z, (u64)t);
-  out[2 * t] = r.a;
-  out[2 * t + 1] = r.b;
+  gl::E2 r = gl::e2(1);   // square-and-multiply in lazy arithmetic (gl_lazy.h), canonical at the store
+  for (uint32_t e = t; e; e >>= 1) {
+    if (e & 1) r = gl::e2_mul_nc(r, z);
+    z = gl::e2_mul_nc(z, z);
+  }
+  out[2 * t] = gl::canon(r.a);
+  out[2 * t + 1] = gl::canon(r.b);
 }
 
 // one block per polynomial: sum_k c_k z^k with lane t taking the coefficients k = t (mod S).  S = 1024
@@ -45,11 +50,11 @@ __global__ __launch_bounds__(1024) void k_eval_polys(const u64* __restrict__ coe
   gl::E2 acc = gl::e2(0);
   if (t < S) {
     gl::E2 y{pows[2 * S], pows[2 * S + 1]};  // z^S
-    for (int k = (int)(n / S) - 1; k >= 0; k--) {
-      acc = gl::mul(acc, y);
-      acc.a = gl::add(acc.a, c[(size_t)k * S + t]);
+    for (int k = (int)(n / S) - 1; k >= 0; k--) {   // Horner in lazy arithmetic; the coefficient (canonical) enters with one correction
+      acc = gl::e2_mul_nc(acc, y);
+      acc.a = gl::add_c(acc.a, c[(size_t)k * S + t]);
     }
-    acc = gl::mul(acc, gl::E2{pows[2 * t], pows[2 * t + 1]});
+    acc = gl::e2_canon(gl::e2_mul_nc(acc, gl::E2{pows[2 * t], pows[2 * t + 1]}));
   }
   sa[t] = acc.a;
   sb[t] = acc.b;
@@ -122,17 +127,17 @@ __global__ __launch_bounds__(256) void k_fri_comp(CombineK a) {
   for (int o = 0; o < 4; o++)
     for (uint32_t p = 0; p < a.n_polys[o]; p++, j++) {
       u64 c = a.coeffs[o][(size_t)p * n + k];
-      s0.a = gl::add(s0.a, gl::mul(ap[2 * j], c));
-      s0.b = gl::add(s0.b, gl::mul(ap[2 * j + 1], c));
+      s0.a = gl::mad_nc(ap[2 * j], c, s0.a);       // any-u64 running sums, canonical at the store
+      s0.b = gl::mad_nc(ap[2 * j + 1], c, s0.b);
     }
   gl::E2 s1 = gl::e2(0);
   for (uint32_t c = 0; c < a.num_challenges; c++) {
     u64 v = a.coeffs[2][(size_t)c * n + k];
-    s1.a = gl::add(s1.a, gl::mul(ap[2 * c], v));
-    s1.b = gl::add(s1.b, gl::mul(ap[2 * c + 1], v));
+    s1.a = gl::mad_nc(ap[2 * c], v, s1.a);
+    s1.b = gl::mad_nc(ap[2 * c + 1], v, s1.b);
   }
-  gl::E2 d0 = gl::mul(s0, gl::E2{a.zpow[0][2 * k], a.zpow[0][2 * k + 1]});
-  gl::E2 d1 = gl::mul(s1, gl::E2{a.zpow[1][2 * k], a.zpow[1][2 * k + 1]});
+  gl::E2 d0 = gl::e2_canon(gl::e2_mul_nc(s0, gl::E2{a.zpow[0][2 * k], a.zpow[0][2 * k + 1]}));
+  gl::E2 d1 = gl::e2_canon(gl::e2_mul_nc(s1, gl::E2{a.zpow[1][2 * k], a.zpow[1][2 * k + 1]}));
   a.comp[0 * (size_t)n + k] = d0.a;
   a.comp[1 * (size_t)n + k] = d0.b;
   a.comp[2 * (size_t)n + k] = d1.a;

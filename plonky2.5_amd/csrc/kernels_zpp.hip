@@ -12,6 +12,7 @@
 // Kernels 2-4: running product over rows as a three-phase scan (block scan in LDS, scan of block
 //   totals, apply), replacing upstream's sequential loop over 2^16 rows.
 #include "kernels.h"
+#include "gl_lazy.h"
 #include "prover_kernels.h"
 
 namespace p25 {
@@ -30,15 +31,16 @@ __global__ __launch_bounds__(256) void k_zpp_chunks(ZppArgs a) {
   for (int k = 0; k < nch; k++) {
     u64 np = 1, dp = 1;
     for (int j = k * per; j < (k + 1) * per && j < (int)a.num_routed; j++) {
-      u64 w = a.wires[(size_t)j * a.n + r];
-      u64 s_id = gl::mul(a.k_is[j], x);
-      u64 nu = gl::add(gl::add(w, gl::mul(beta, s_id)), gamma);
-      u64 de = gl::add(gl::add(w, gl::mul(beta, a.sigmas[(size_t)j * a.n + r])), gamma);
-      np = gl::mul(np, nu);
-      dp = gl::mul(dp, de);
+      // lazy arithmetic (gl_lazy.h): w + gamma with one correction (both canonical), the two affine forms as fused
+      // multiply-adds, the running products on any-u64 values; canonical once per chunk
+      const u64 wg = gl::add_c(a.wires[(size_t)j * a.n + r], gamma);
+      const u64 nu = gl::mad_nc(beta, gl::mul_nc(a.k_is[j], x), wg);
+      const u64 de = gl::mad_nc(beta, a.sigmas[(size_t)j * a.n + r], wg);
+      np = gl::mul_nc(np, nu);
+      dp = gl::mul_nc(dp, de);
     }
-    num[k] = np;
-    den[k] = dp;
+    num[k] = gl::canon(np);
+    den[k] = gl::canon(dp);
   }
   // batch inverse of den[0..nch)
   u64 pre[MAX_CHUNKS];
