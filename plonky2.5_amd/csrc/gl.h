@@ -5,9 +5,9 @@
 // plonky2_field @ 3de92d9 as used throughout /root/reference (e.g. modulus at
 // src/p3/mod.rs:55, W = 7 at src/p3/extension.rs:147-152, 2^32-th root at extension.rs:155).
 //
-// Representation invariant: every value stored in memory is canonical (< p).  Inside a kernel a
-// value may be held non-canonically (any u64) between `mul_nc`/`reduce*` calls; `canon` brings it
-// back.  All arithmetic is exact integer arithmetic -> results are bit-identical on CPU and GPU.
+// Representation invariant: every value stored in memory is canonical (< p) -- except what pass 1 of a two-pass NTT
+// hands to pass 2 (NttPass::lazy_out).  Inside a kernel a value may be held non-canonically (any u64) between
+// `mul_nc`/`reduce*` calls and through the lazy operations of gl_lazy.h; `canon` brings it back.  All arithmetic is exact integer arithmetic -> results are bit-identical on CPU and GPU.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
