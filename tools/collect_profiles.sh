@@ -14,7 +14,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 want() { [ "$WHAT" = all ] || [[ " $WHAT " == *" $1 "* ]]; }
 if want tests; then
-python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -14 > $OUT/${TAG}_pytest_gpu.txt
+# (written as it runs: output held back by a pipe into tail makes a long run look hung to gpurun's silence detector)
+python -m pytest tests -m gpu -q --durations=8 > $OUT/${TAG}_pytest_gpu.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/${TAG}_pytest_gpu.txt 2>&1
 tail -3 $OUT/${TAG}_pytest_gpu.txt
 fi
