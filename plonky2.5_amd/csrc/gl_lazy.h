@@ -1,19 +1,23 @@
-// Lazy (non-canonical) Goldilocks arithmetic for the NTT butterflies: every operand and every result is ANY u64
-// congruent to the field element it stands for; `gl::canon` brings a value back before it leaves the kernel.
+// Lazy (non-canonical) Goldilocks arithmetic: every operand and every result is ANY u64 congruent to the field element it
+// stands for; `gl::canon` brings a value back before it leaves the kernel.  Used by the NTT butterflies (ntt16.h,
+// kernels_ntt.hip), the quotient's gate evaluators (kernels_quotient.hip) and the openings / FRI / partial-product kernels.
 //
-// Why: a canonical butterfly (gl::add + gl::sub + a canonical twiddle product) costs the compiler 37 VALU instructions
-// on gfx950 (64-bit compare-and-select reductions, v_cndmask pairs); the sequences below are 12 for the sum and the
-// difference together and 6 / 10 / 8 for a product by a power of two, with no compare and no select -- a wrap of the
-// 64-bit register is worth 2^64 = 2^32 - 1 (mod p), so every correction is "low word -= carry, high word += carry
-// unless the low word borrowed", driven by the carry bit itself.  A SECOND wrap is possible (a + b >= 2^64 + p, one
-// pair in 2^32 at random) and is corrected the same way; a third is not (proofs at each function).
+// Why: the compiler's canonical forms cost 8 VALU instructions for gl::add (64-bit add, two 64-bit compares, a subtract, two
+// selects), 6 for gl::sub, 22 for a product by a power of two and 4 for every canonical step after a multiply -- a canonical
+// radix-2 butterfly on a power-of-two twiddle is 37.  The sequences below are 12 for a sum and a difference together, 4 / 6
+// for a single add or subtract (second operand canonical / any) and 6 / 10 / 8 for a product by a power of two, with no
+// compare and no select: a wrap of the 64-bit register is worth 2^64 = 2^32 - 1 (mod p), so every correction is "low word
+// -= carry, high word += carry unless the low word borrowed", driven by the carry bit itself.  A SECOND wrap is possible
+// (a + b >= 2^64 + p, one pair in 2^32 at random) and is corrected the same way; a third is not (proofs at each function).
 //
-// The plain C++ forms (`*_c`) are the definition: host code and tools/asmcheck.hip compare the gfx950 sequences with them
-// on the device over edge cases (all pairs of 24 boundary values) and random operands.
+// The plain C++ forms (`*_c`) are the definition: tests/native/lazy_defs.cpp checks them against 128-bit integer arithmetic
+// on the CPU, tools/asmcheck.hip compares the gfx950 sequences with them and with canonical arithmetic on the device (all
+// pairs of 24 boundary values, random operands biased to the top of the range, every shift exponent).
 //
-// gfx940-family hazard (as in gl.h): a VALU-written SGPR / VCC needs two wait states before a VALU reads it as a carry,
-// and inline asm is opaque to the compiler's hazard recogniser -- hence the interleaving of the two carry chains of a
-// butterfly and the explicit s_nop between dependent steps.
+// gfx940-family hazard (as in gl.h): a VALU-written SGPR / VCC needs two wait states before a VALU reads it as a carry, and
+// the inside of an asm block is opaque to the compiler's hazard recogniser -- hence the interleaving of the two carry chains
+// of a butterfly and the explicit s_nop between dependent steps.  (A timing-only build without them bounds their cost at
+// <= 0.3 % of the pipeline: profiles/r05_v_hazard_nops_bound.txt.)
 #pragma once
 #include "gl.h"
 
