@@ -112,8 +112,7 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
                     size_t lde_stride, int log_n, int rate_bits, int n_polys, u64 shift,
                     hipStream_t st);
 
-// values -> coefficients (kept) -> LDE: ntt_inverse followed by ntt_lde_bitrev, fusing pass 2 of the former with pass 1 of
-// the latter when built with P25_NTT_FUSE and the shapes allow it (log_n even, 12..16).  d_tmp must not alias anything.
+// values -> coefficients (kept) -> LDE: ntt_inverse followed by ntt_lde_bitrev.  d_tmp must not alias anything.
 void ntt_inverse_then_lde(NttTables& tb, const u64* d_vals, size_t val_stride, u64* d_tmp, size_t tmp_stride, u64* d_coeffs,
                           size_t coeff_stride, u64* d_lde, size_t lde_stride, int log_n, int rate_bits, int n_polys, u64 shift,
                           hipStream_t st);

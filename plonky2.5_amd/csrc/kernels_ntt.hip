@@ -369,242 +369,16 @@ static int pick_log_t(int log_r, int log_nt, bool strided) {
   return lt;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// iNTT pass 2 FUSED with pass 1 of the LDE (round 5; VERDICT r2-r4 "the same LDS tile shape at n = 2^16").
-// When N = R * R (log_n even), pass 2 of the inverse transform works on T rows j2 of R contiguous words and leaves the
-// coefficients j2 + R * j1 (all j1) of those rows in LDS -- exactly the tile pass 1 of every coset transform reads (T adjacent
-// k1 = j2, all k2 = j1).  One block therefore: loads its rows, runs the inverse sub-transforms, scales, writes the
-// coefficients (the openings and FRI read them later), then for each coset reads its own stores back (L2), pre-scales them
-// into LDS, runs the forward sub-transforms and stores with the four-step twiddle.  The coefficients do not make the round
-// trip through HBM and the separate pass-2 launch is gone; the arithmetic is the same operation for operation.
-struct NttFusedArgs {
-  const u64* in;      // iNTT pass-1 output: row j2 = R contiguous words
-  u64* coef;          // coefficients out (natural order)
-  u64* lde;           // LDE pass-1 out
-  size_t in_poly_stride, coef_poly_stride, lde_poly_stride;
-  size_t coset_out_off[8];
-  int log_r, log_t;
-  const u64* pow_inv;   // w_N^-e
-  const u64* pow_fwd;   // w_N^e
-  int log_n_table;
-  const u64* post_t;    // [R]  n^-1 (row factor of the inverse transform's scaling; the coset shift is 1 here)
-  const u64* post_i;    // [R]
-  const u64* pre;       // [n_cosets][N] coset pre-scale
-  uint32_t n_cosets, n_tiles;
-};
-// the DIF network of one tile, natural in -> bit-reversed out (the loop of k_ntt_tile, full twiddle table)
-template <bool INV>
-__device__ __forceinline__ void tile_dif_full(u64* lds, const u64* wl, int log_r, int log_t, int T, int TP, int tid, int nth) {
-  for (int s0 = 0; s0 < log_r;) {
-    const int g = log_r - s0 < 4 ? log_r - s0 : 4;
-    const int lstride = log_r - s0 - g;
-    const int items = T << (log_r - g);
-    for (int b = tid; b < items; b += nth) {
-      const int t = b & (T - 1), q = b >> log_t;
-      const int l = q & ((1 << lstride) - 1), h = q >> lstride;
-      u64* col = lds + ((h << (log_r - s0)) + l) * TP + t;
-      switch (g) {
-        case 4: dif16_group<INV>(col, wl, TP << lstride, l, s0); break;
-        case 3: dif_group<3>(col, wl, TP << lstride, l, lstride, s0); break;
-        case 2: dif_group<2>(col, wl, TP << lstride, l, lstride, s0); break;
-        default: dif_group<1>(col, wl, TP << lstride, l, lstride, s0); break;
-      }
-    }
-    __syncthreads();
-    s0 += g;
-  }
-}
-// Run-time loops over the lane's elements, eight in flight per batch, like k_ntt_tile's load and store phases (fully
-// unrolled over the 16 elements of a lane the compiler hoists every address: 105 spilled VGPRs at four waves per SIMD).
-__global__ __launch_bounds__(256, 4) void k_ntt_fused(NttFusedArgs a) {
-  P25_WAVE_PRIO(P25_PRIO_BULK);
-  extern __shared__ u64 lds[];
-  const int R = 1 << a.log_r, T = 1 << a.log_t, TP = T + 1;
-  u64* wl_inv = lds + (size_t)R * TP;
-  u64* wl_fwd = wl_inv + R;
-  const int tid = threadIdx.x;
-  constexpr int nth = 256, LB = 8;
-  const int wstride_log = a.log_n_table - a.log_r;
-  for (int k = tid; k < R; k += nth) {
-    wl_inv[k] = a.pow_inv[(size_t)k << wstride_log];
-    wl_fwd[k] = a.pow_fwd[(size_t)k << wstride_log];
-  }
-  // 1-D grid decoded as in k_ntt_tile: an XCD only ever works on tiles = xcd (mod 8), so its share of the coset pre-scale
-  // table (8 x 1/8 of 512 KB per coset at n = 2^16) stays in that XCD's L2 across the polynomials
-  u32 tile, poly;
-  if ((a.n_tiles & 7u) == 0) {
-    const u32 L = blockIdx.x, xcd = L & 7u, m = L >> 3, tiles8 = a.n_tiles >> 3;
-    tile = (m % tiles8) * 8 + xcd;
-    poly = m / tiles8;
-  } else {
-    tile = blockIdx.x % a.n_tiles;
-    poly = blockIdx.x / a.n_tiles;
-  }
-  const u32 tg0 = tile * T;
-  const u64* in = a.in + (size_t)poly * a.in_poly_stride;
-  u64* coef = a.coef + (size_t)poly * a.coef_poly_stride;
-  const int TR = T * R;     // a multiple of LB * nth for R >= 128 (T = 16); R = 64: the tail loop
-  // rows tg0 .. tg0 + T - 1 of R contiguous words each -> LDS slot (i, t) = i * TP + t
-  {
-    int e = tid;
-    for (; e + (LB - 1) * nth < TR; e += LB * nth) {
-      u64 xv[LB];
-#pragma unroll
-      for (int k = 0; k < LB; k++) {
-        const int ee = e + k * nth;
-        xv[k] = in[(size_t)(tg0 + (ee >> a.log_r)) * R + (ee & (R - 1))];
-      }
-#pragma unroll
-      for (int k = 0; k < LB; k++) {
-        const int ee = e + k * nth;
-        lds[(ee & (R - 1)) * TP + (ee >> a.log_r)] = xv[k];
-      }
-    }
-    for (; e < TR; e += nth) lds[(e & (R - 1)) * TP + (e >> a.log_r)] = in[(size_t)(tg0 + (e >> a.log_r)) * R + (e & (R - 1))];
-  }
-  __syncthreads();
-  tile_dif_full<true>(lds, wl_inv, a.log_r, a.log_t, T, TP, tid, nth);
-  // coefficients: LDS position q of row t holds frequency j = rev(q); scaled and stored at (tg0 + t) + j * R.  Every lane reads
-  // ITS OWN stores back for each coset below (the same addresses, program order: the lines are still in this XCD's L2 --
-  // sixteen kept values per lane took the kernel to 242 VGPRs).
-  const int t_own = tid & (T - 1);
-  const size_t row0 = (size_t)(tg0 + t_own);
-  {
-    const u64 pt = a.post_t[tg0 + t_own];
-    for (int e = tid; e < TR; e += nth) {
-      const int q = e >> a.log_t;
-      const u32 j = gl::bitrev((u32)q, a.log_r);
-      coef[row0 + (size_t)j * R] = gl::mul(lds[q * TP + t_own], gl::mul(pt, a.post_i[j]));
-    }
-  }
-  const size_t N = (size_t)R * R;
-  for (u32 c = 0; c < a.n_cosets; c++) {
-    __syncthreads();   // the previous phase has finished reading the tile
-    const u64* pre = a.pre + (size_t)c * N;
-    {
-      int e = tid;
-      for (; e + (LB - 1) * nth < TR; e += LB * nth) {
-        u64 pv[LB], cv[LB];
-#pragma unroll
-        for (int k = 0; k < LB; k++) {
-          const u32 j = gl::bitrev((u32)((e + k * nth) >> a.log_t), a.log_r);
-          pv[k] = pre[row0 + (size_t)j * R];
-          cv[k] = coef[row0 + (size_t)j * R];
-        }
-#pragma unroll
-        for (int k = 0; k < LB; k++) {
-          const u32 j = gl::bitrev((u32)((e + k * nth) >> a.log_t), a.log_r);
-          lds[j * TP + t_own] = gl::mul(cv[k], pv[k]);     // natural position of coefficient index j within row t
-        }
-      }
-      for (; e < TR; e += nth) {
-        const u32 j = gl::bitrev((u32)(e >> a.log_t), a.log_r);
-        lds[j * TP + t_own] = gl::mul(coef[row0 + (size_t)j * R], pre[row0 + (size_t)j * R]);
-      }
-    }
-    __syncthreads();
-    tile_dif_full<false>(lds, wl_fwd, a.log_r, a.log_t, T, TP, tid, nth);
-    u64* out = a.lde + (size_t)poly * a.lde_poly_stride + a.coset_out_off[c];
-    {
-      int e = tid;
-      for (; e + (LB - 1) * nth < TR; e += LB * nth) {
-        u64 wv[LB], xv[LB];
-#pragma unroll
-        for (int k = 0; k < LB; k++) {
-          const int q = (e + k * nth) >> a.log_t;
-          wv[k] = a.pow_fwd[row0 * gl::bitrev((u32)q, a.log_r)];
-          xv[k] = lds[q * TP + t_own];
-        }
-#pragma unroll
-        for (int k = 0; k < LB; k++) {
-          const int q = (e + k * nth) >> a.log_t;
-          out[row0 + (size_t)q * R] = gl::mul(xv[k], wv[k]);
-        }
-      }
-      for (; e < TR; e += nth) {
-        const int q = e >> a.log_t;
-        out[row0 + (size_t)q * R] = gl::mul(lds[q * TP + t_own], a.pow_fwd[row0 * gl::bitrev((u32)q, a.log_r)]);
-      }
-    }
-  }
-}
-
-#ifndef P25_NTT_FUSE
-#define P25_NTT_FUSE 0
-#endif
-// values -> coefficients -> LDE for a batch of polynomials: the two-call sequence of the prover's commits, with pass 2 of
-// the inverse transform and pass 1 of the LDE in one launch when the shapes allow it (P25_NTT_FUSE, log_n even, 12..16).
+// values -> coefficients -> LDE for a batch of polynomials: the two-call sequence of the prover's commits.
+// (Round 5 measured pass 2 of the inverse transform fused with pass 1 of the LDE in one launch -- the tile the former leaves
+// in LDS is the tile the latter loads when n = 2^16 -- as `k_ntt_fused`: bit-exact, 4 % fewer NTT instructions, slower and
+// more traffic than the XCD-grouped coset blocks; the kernel lives on as tools/exp/ntt_fused_inverse_pass2_lde_pass1.patch,
+// DESIGN section 3.)
 void ntt_inverse_then_lde(NttTables& tb, const u64* d_vals, size_t val_stride, u64* d_tmp, size_t tmp_stride, u64* d_coeffs,
                           size_t coeff_stride, u64* d_lde, size_t lde_stride, int log_n, int rate_bits, int n_polys, u64 shift,
                           hipStream_t st) {
-  const int lr = log_n / 2;
-  const bool fusable = P25_NTT_FUSE && log_n >= 12 && log_n <= 16 && (log_n & 1) == 0 && rate_bits <= 3;
-  if (!fusable) {
-    ntt_inverse(tb, d_vals, val_stride, false, d_tmp, tmp_stride, d_coeffs, coeff_stride, log_n, n_polys, 1, st);
-    ntt_lde_bitrev(tb, d_coeffs, coeff_stride, d_lde, lde_stride, log_n, rate_bits, n_polys, shift, st);
-    return;
-  }
-  const size_t n = (size_t)1 << log_n;
-  const int nc = 1 << rate_bits;
-  const u64* pw_inv = tb.pow_table(log_n, true);
-  const u64* pw_fwd = tb.pow_table(log_n, false);
-  // iNTT pass 1 exactly as ntt_inverse issues it
-  {
-    NttPass p{};
-    p.pow_table = pw_inv;
-    p.log_n_table = log_n;
-    p.inverse = 1;
-    p.in = d_vals; p.out = d_tmp;
-    p.in_poly_stride = val_stride; p.out_poly_stride = tmp_stride;
-    p.log_r = lr; p.log_nt = lr; p.log_t = pick_log_t(lr, lr, true);
-    p.in_kind = 0;
-    p.out_kind = 0; p.out_br_i = 0;
-    p.use_twiddle = 1;
-    p.lazy_out = 1;
-    launch_ntt_pass(p, n_polys, 1, st);
-  }
-  // the coset pre-scale table of ntt_lde_bitrev (shared cache)
-  auto& cache = tb.coset_cache();
-  auto key = std::make_tuple(log_n, rate_bits, shift);
-  auto it = cache.find(key);
-  if (it == cache.end()) {
-    const u64 w_big = gl::root_of_unity(log_n + rate_bits);
-    std::vector<u64> h((size_t)nc * n);
-    for (int c = 0; c < nc; c++) {
-      u64 sc = gl::mul(shift, gl::pow(w_big, c)), x = 1;
-      for (size_t k = 0; k < n; k++) {
-        h[(size_t)c * n + k] = x;
-        x = gl::mul(x, sc);
-      }
-    }
-    it = cache.emplace(key, tb.upload(h)).first;
-  }
-  NttFusedArgs f{};
-  f.in = d_tmp; f.coef = d_coeffs; f.lde = d_lde;
-  f.in_poly_stride = tmp_stride; f.coef_poly_stride = coeff_stride; f.lde_poly_stride = lde_stride;
-  for (int c = 0; c < nc; c++) f.coset_out_off[c] = (size_t)gl::bitrev(c, rate_bits) * n;
-  f.log_r = lr;
-  f.log_t = 4;
-  f.pow_inv = pw_inv; f.pow_fwd = pw_fwd; f.log_n_table = log_n;
-  const u64 n_inv = gl::inv((u64)1 << log_n);
-  f.post_t = tb.geom_table(n_inv, 1, (size_t)1 << lr);
-  f.post_i = tb.geom_table(1, 1, (size_t)1 << lr);
-  f.pre = it->second;
-  f.n_cosets = (uint32_t)nc;
-  const size_t R = (size_t)1 << lr, T = 16, lds = (R * (T + 1) + 2 * R) * sizeof(u64);
-  f.n_tiles = (uint32_t)(R / T);
-  const dim3 grid((unsigned)(R / T) * (unsigned)n_polys);
-  hipLaunchKernelGGL(k_ntt_fused, grid, dim3(256), lds, st, f);
-  // LDE pass 2 exactly as ntt_lde_bitrev issues it
-  {
-    NttPass q{};
-    q.pow_table = pw_fwd; q.log_n_table = log_n;
-    q.in = d_lde; q.out = d_lde;
-    q.in_poly_stride = lde_stride; q.out_poly_stride = lde_stride;
-    q.log_r = lr; q.log_nt = lr + rate_bits; q.log_t = pick_log_t(lr, lr + rate_bits, false);
-    q.in_kind = 1; q.out_kind = 1; q.out_br_i = 1;
-    launch_ntt_pass(q, n_polys, 1, st);
-  }
+  ntt_inverse(tb, d_vals, val_stride, false, d_tmp, tmp_stride, d_coeffs, coeff_stride, log_n, n_polys, 1, st);
+  ntt_lde_bitrev(tb, d_coeffs, coeff_stride, d_lde, lde_stride, log_n, rate_bits, n_polys, shift, st);
 }
 
 NttTables::~NttTables() {
