@@ -10,7 +10,7 @@
 // Sponge conventions (upstream hashing.rs): overwrite mode, rate 8, capacity 4, 4-word digest;
 // `two_to_one(l, r)` = permute(l || r || 0000)[0..4]; `hash_or_noop` pads inputs of <= 4 words.
 #pragma once
-#include "gl.h"
+#include "gl_lazy.h"
 
 namespace poseidon {
 

@@ -295,8 +295,10 @@ __device__ __forceinline__ void load_row(Row16& cf, const Row16 __attribute__((a
 #pragma unroll
   for (int j = 0; j < 16; j++) cf.c[j] = src->c[j];
 }
-__device__ __forceinline__ void delta(u64 x_canonical, u32& dlo, u32& dhi) {
-  const u64 d = gl::sub(sbox(x_canonical), x_canonical);  // sbox(x) - x: any u64 minus a canonical value
+// d = sbox(x) - x for ANY u64 x (the row reduction's output as it is): the lazy subtraction of gl_lazy.h, both borrows
+// corrected, 6 VALU -- the canonical form (gl::canon of x, then gl::sub) cost 10 per partial round.
+__device__ __forceinline__ void delta(u64 x, u32& dlo, u32& dhi) {
+  const u64 d = gl::sub_nc(sbox(x), x);
   dlo = (u32)d;
   dhi = (u32)(d >> 32);
 }
@@ -313,13 +315,13 @@ __device__ __forceinline__ void three_rounds(u64 s[WIDTH], tbl_ptr tp, k_ptr kc)
     hi[i] = (u32)(s[i] >> 32);
   }
   u32 dlo[3] = {0, 0, 0}, dhi[3] = {0, 0, 0};
-  if (!HEAD) delta(gl::canon(s[0]), dlo[0], dhi[0]);
-  u64 x = gl::canon(row0_m<!HEAD>(lo, hi, dlo[0], dhi[0], kc[0], kc[1]));
+  if (!HEAD) delta(s[0], dlo[0], dhi[0]);
+  u64 x = row0_m<!HEAD>(lo, hi, dlo[0], dhi[0], kc[0], kc[1]);
   delta(x, dlo[1], dhi[1]);
   {
     Row16 cf;
     load_row(cf, &tp->r2);
-    x = gl::canon(row<HEAD ? 1 : 0, HEAD ? 1 : 2>(lo, hi, cf, dlo, dhi, kc[2], kc[3]));
+    x = row<HEAD ? 1 : 0, HEAD ? 1 : 2>(lo, hi, cf, dlo, dhi, kc[2], kc[3]);
   }
   delta(x, dlo[2], dhi[2]);
 #pragma unroll
@@ -342,8 +344,8 @@ __device__ __forceinline__ void two_rounds(u64 s[WIDTH], tbl_ptr tp) {
   }
   const k_ptr kc = tp->kt;
   u32 dlo[2], dhi[2];
-  delta(gl::canon(s[0]), dlo[0], dhi[0]);
-  const u64 x = gl::canon(row0_m<true>(lo, hi, dlo[0], dhi[0], kc[0], kc[1]));
+  delta(s[0], dlo[0], dhi[0]);
+  const u64 x = row0_m<true>(lo, hi, dlo[0], dhi[0], kc[0], kc[1]);
   delta(x, dlo[1], dhi[1]);
 #pragma unroll
   for (int r = 0; r < WIDTH; r++) {
