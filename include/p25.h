@@ -33,18 +33,25 @@ enum {
   P25_ERR_GENERATORS_NOT_RUN = 5,   /* "N generators weren't run" */
   P25_ERR_OPENING_IN_SUBGROUP = 6,  /* Err("Opening point is in the subgroup.") */
   P25_ERR_INTERNAL = 7,
-  P25_ERR_PARSE = 8
+  P25_ERR_PARSE = 8,
+  /* p25_device_init_ex only: the device IS selected and usable, but the hardware-queue request probably came too late to have
+   * an effect (below).  The one status that is a warning, not a failure. */
+  P25_WARN_HW_QUEUES_LATE = 9,
+  /* p25_comm_* / p25_gather_proofs: librccl could not be loaded, or an RCCL call failed (p25_last_error has its text) */
+  P25_ERR_RCCL = 10
 };
 
 /* Last error message of the calling thread ("" if none). */
 const char* p25_last_error(void);
 /* Library version string. */
 const char* p25_version(void);
-/* Select the HIP device used by this PROCESS (one process per GPU); call once, before creating circuits.
+/* Select the HIP device used by this PROCESS (one process per GPU); call once, before creating circuits AND BEFORE ANYTHING
+ * ELSE IN THE PROCESS TOUCHES HIP -- required for full throughput (the hardware-queue request below is read when the HIP
+ * runtime initialises; a host that must touch HIP first exports GPU_MAX_HW_QUEUES=24 itself).
  * The index is recorded and re-applied (hipSetDevice is per host thread) at every entry point, so calls from
- * any host thread run on this device.  Without it the first call adopts the thread's current device.
- * P25_ERR_NO_DEVICE if none. */
-p25_status p25_device_init(int device_index);     /* = p25_device_init_ex(device_index, P25_DEFAULT_HW_QUEUES) */
+ * any host thread run on this device.  Without it the first call adopts the thread's current device and applies the same
+ * default hardware-queue request.  P25_ERR_NO_DEVICE if none. */
+p25_status p25_device_init(int device_index);     /* = p25_device_init_ex(device_index, P25_DEFAULT_HW_QUEUES), warning dropped */
 /* Same with the number of hardware queues the HIP runtime may spread its streams over made explicit.  The library keeps
  * 16 proofs in flight on 16 + 2 streams; ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
  * streams sharing a queue run in order (4 -> 16 queues: 78.8 -> 91.7 proofs/s).  hw_queues > 0: the variable is set for this
@@ -53,7 +60,23 @@ p25_status p25_device_init(int device_index);     /* = p25_device_init_ex(device
  * the environment is left alone.  Loading the library changes nothing in the process (rounds 1-4 set the variable from a
  * load-time constructor). */
 #define P25_DEFAULT_HW_QUEUES 24
+/* Returns P25_WARN_HW_QUEUES_LATE (device selected, library usable, p25_last_error() = the explanation) when hw_queues > 0, the
+ * host had not exported GPU_MAX_HW_QUEUES, and this process already had the GPU driver open before the call (the host, torch
+ * or a profiler's preloaded tool initialised the runtime first): the request then probably has no effect and 16 proving
+ * streams share 4 hardware queues -- 10-40 % of the throughput, silently, before round 6. */
 p25_status p25_device_init_ex(int device_index, int hw_queues);
+/* What the process actually runs with (fill-in struct; every field also valid before p25_device_init). */
+typedef struct {
+  int32_t device_index;              /* -1 = not selected yet */
+  int32_t hw_queues_requested;       /* what the library asked for at its first call (0 = nothing / not yet) */
+  int32_t hw_queues_env;             /* GPU_MAX_HW_QUEUES as the environment holds it now (0 = absent) */
+  int32_t hw_queues_host_exported;   /* 1 = the variable was the host's: the library left it alone */
+  int32_t runtime_open_before_init;  /* 1 = this process held /dev/kfd before the library's first HIP call */
+  int32_t hw_queues_setting_late;    /* 1 = requested, not host-exported, runtime already open: probably without effect */
+  int32_t proving_streams, main_streams;   /* the process-wide stream pool: 16 + 2 */
+  int32_t reserved[8];
+} p25_runtime_info_t;
+p25_status p25_runtime_info(p25_runtime_info_t* out);
 
 /* ------------------------------------------------------------------------------------------
  * Primitives (host buffers; used by the parity tests).
@@ -361,6 +384,51 @@ p25_status p25_shader_clock_hz(double* hz_out);
 /* Witness only (parity tests): wires_out[num_wires][2^degree_bits], column-major. */
 p25_status p25_witness(p25_circuit* c, const uint64_t* inputs, uint64_t seed, uint64_t* wires_out,
                        p25_status* proof_status);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, every rank proves its own shard of the batch on its own replica of the circuit tables
+ * (`prove(&self, ..)` borrows the circuit immutably: /root/reference/src/p3/mod.rs:260 -- nothing is exchanged inside a
+ * proof), and ONE collective moves the finished proofs: the "final aggregation step" of north_star, RCCL over xGMI.
+ * The reference has no counterpart (it has no multi-device code at all); these entry points are what a Rust host binds for
+ * N > 1.  librccl is loaded on first use (dlopen "librccl.so.1"); P25_ERR_RCCL if it is absent.
+ *
+ *   rank 0:      p25_comm_unique_id(id)  -> hand the 128 bytes to every rank out of band (the launcher's channel)
+ *   every rank:  p25_device_init(local_gpu); p25_comm_init(id, rank, world, &comm)
+ *   every step:  p25_prove_batch_dev(c, ...);  p25_circuit_mark(c, slot);
+ *                p25_gather_proofs(comm, c, slot, d_proofs, stride, d_status, counts, 0, d_all, d_all_status);
+ *                   -- enqueue-only: runs on the communicator's own stream, which waits ON THE DEVICE for the mark, so the
+ *                      gather of step k overlaps the proving of step k + 1 (double-buffer d_proofs; before a buffer is
+ *                      proved into again: p25_circuit_wait_stream(c, p25_comm_stream(comm)))
+ *   at the end:  p25_comm_sync(comm)  (host waits for the gathers), p25_comm_destroy(comm)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct p25_comm p25_comm;
+#define P25_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
+p25_status p25_comm_unique_id(uint8_t* id_out /* [P25_COMM_ID_BYTES] */);
+/* Collective: every rank of the job calls it with the same id.  The communicator lives on the device p25_device_init
+ * selected (one rank per GPU: RCCL refuses two ranks on one device). */
+p25_status p25_comm_init(const uint8_t* id, int32_t rank, int32_t world, p25_comm** out);
+p25_status p25_comm_destroy(p25_comm* comm);   /* waits for the communicator's stream first */
+int32_t p25_comm_rank(const p25_comm* comm);
+int32_t p25_comm_world(const p25_comm* comm);
+/* The hipStream_t every collective of this communicator is enqueued on (for p25_circuit_wait_stream, or the host's own
+ * event / copy work behind a gather). */
+void* p25_comm_stream(p25_comm* comm);
+p25_status p25_comm_sync(p25_comm* comm);      /* host waits for everything enqueued on the communicator's stream */
+/* Host-synchronous helpers for the timing protocol of a batch job (barrier on both sides of the timed region, MAX of the
+ * per-rank elapsed time): one 8-byte ncclAllReduce on the communicator's stream. */
+p25_status p25_comm_barrier(p25_comm* comm);
+p25_status p25_comm_max_f64(p25_comm* comm, double* value /* in: this rank's, out: the maximum */);
+/* Gather: rank q contributes counts[q] proofs, d_proofs[counts[rank]][proof_stride_words] with their statuses
+ * d_status[counts[rank]] (what p25_prove_batch_dev wrote); dst_rank receives all of them in rank order -- global proof order
+ * for the contiguous block partition -- into d_all_proofs[sum counts][proof_stride_words] and d_all_status[sum counts] (both
+ * ignored on the other ranks, may be NULL there).  counts[world] must be the same on every rank; shards may differ in size
+ * and may be empty.  Grouped ncclSend / ncclRecv (every sender has its own xGMI link to the root), the root's own block a
+ * device-to-device copy.  Ordered behind `circuit` on the device: mark_slot >= 0 waits for that p25_circuit_mark, mark_slot < 0
+ * for everything the circuit has been asked for so far (p25_circuit_stream_join); circuit == NULL: no wait (buffers the host
+ * has synchronised itself).  Enqueue-only: returns at once; p25_comm_sync (or work on p25_comm_stream) observes completion. */
+p25_status p25_gather_proofs(p25_comm* comm, p25_circuit* circuit, int32_t mark_slot, const uint64_t* d_proofs,
+                             size_t proof_stride_words, const uint32_t* d_status, const size_t* counts, int32_t dst_rank,
+                             uint64_t* d_all_proofs, uint32_t* d_all_status);
 
 /* ------------------------------------------------------------------------------------------
  * Stages of the prover on their own (host buffers; the fine-grained entry points of SURVEY.md 8b, used by the

@@ -7,7 +7,8 @@ import numpy as np
 __all__ = ["P25Error", "lib", "lib_path", "device_init", "shader_clock_hz", "poseidon_permute", "poseidon2_permute",
            "merkle_commit", "merkle_tree_words", "lde_commit", "EXPORTED_SYMBOLS", "P",
            "P3Config", "Circuit", "p3_proof_from_json", "Timings", "p3_prove_fibonacci", "p3_inputs_to_json",
-           "Air", "p3_prove_air", "transcript", "fri_prove", "eval_polys"]
+           "Air", "p3_prove_air", "transcript", "fri_prove", "eval_polys", "RuntimeInfo", "runtime_info", "Comm",
+           "comm_unique_id", "WARN_HW_QUEUES_LATE"]
 
 P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -16,7 +17,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 lib_path = os.path.join(_HERE, "libp25.so")
 
 STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "NO_DEVICE", 3: "HIP", 4: "WITNESS_CONFLICT",
-                5: "GENERATORS_NOT_RUN", 6: "OPENING_IN_SUBGROUP", 7: "INTERNAL", 8: "PARSE"}
+                5: "GENERATORS_NOT_RUN", 6: "OPENING_IN_SUBGROUP", 7: "INTERNAL", 8: "PARSE",
+                9: "WARN_HW_QUEUES_LATE", 10: "RCCL"}
+WARN_HW_QUEUES_LATE = 9
+COMM_ID_BYTES = 128
 
 
 class P25Error(RuntimeError):
@@ -115,6 +119,16 @@ class Timings(C.Structure):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
 
 
+class RuntimeInfo(C.Structure):
+    """p25_runtime_info_t: what the process actually runs with (hardware-queue request, stream pool)."""
+    _fields_ = [(n, C.c_int32) for n in ("device_index", "hw_queues_requested", "hw_queues_env", "hw_queues_host_exported",
+                                         "runtime_open_before_init", "hw_queues_setting_late", "proving_streams",
+                                         "main_streams")] + [("reserved", C.c_int32 * 8)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
 _lib = None
 vp, sz, ui, i32 = C.c_void_p, C.c_size_t, C.c_uint, C.c_int32
 
@@ -174,6 +188,17 @@ EXPORTED_SYMBOLS = {
     "p25_p3_prove_fibonacci": (i32, [i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
     "p25_p3_inputs_to_json": (i32, [vp, sz, C.POINTER(P3Config), vp, sz, C.POINTER(sz)]),
     "p25_circuit_build_p3_verifier_air": (i32, [C.POINTER(P3Config), C.POINTER(AirC), C.POINTER(vp)]),
+    "p25_runtime_info": (i32, [C.POINTER(RuntimeInfo)]),
+    "p25_comm_unique_id": (i32, [vp]),
+    "p25_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
+    "p25_comm_destroy": (i32, [vp]),
+    "p25_comm_rank": (i32, [vp]),
+    "p25_comm_world": (i32, [vp]),
+    "p25_comm_stream": (vp, [vp]),
+    "p25_comm_sync": (i32, [vp]),
+    "p25_comm_barrier": (i32, [vp]),
+    "p25_comm_max_f64": (i32, [vp, C.POINTER(C.c_double)]),
+    "p25_gather_proofs": (i32, [vp, vp, i32, vp, sz, vp, C.POINTER(sz), i32, vp, vp]),
     "p25_p3_prove_air": (i32, [C.POINTER(AirC), vp, i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz),
                                C.POINTER(P3Config)]),
 }
@@ -208,11 +233,73 @@ def _ptr(a):
 
 
 def device_init(index=0, hw_queues=None):
-    """p25_device_init / p25_device_init_ex: hw_queues None = the library's default (24), 0 = leave GPU_MAX_HW_QUEUES alone."""
+    """p25_device_init / p25_device_init_ex: hw_queues None = the library's default (24), 0 = leave GPU_MAX_HW_QUEUES alone.
+    Returns True when the hardware-queue request probably came too late to have an effect (P25_WARN_HW_QUEUES_LATE: the process
+    had the GPU runtime open already and GPU_MAX_HW_QUEUES was not exported) -- also readable from runtime_info()."""
     if hw_queues is None:
         _check(lib().p25_device_init(index))
-    else:
-        _check(lib().p25_device_init_ex(index, hw_queues))
+        return bool(runtime_info().hw_queues_setting_late)
+    st = lib().p25_device_init_ex(index, hw_queues)
+    if st == WARN_HW_QUEUES_LATE:
+        return True
+    _check(st)
+    return False
+
+
+def runtime_info():
+    ri = RuntimeInfo()
+    _check(lib().p25_runtime_info(C.byref(ri)))
+    return ri
+
+
+def comm_unique_id():
+    """p25_comm_unique_id: 128 bytes rank 0 hands to every rank out of band (ncclGetUniqueId)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().p25_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """p25_comm: the library-owned RCCL communicator + side stream of the final aggregation step (one rank per GPU)."""
+
+    def __init__(self, unique_id, rank, world):
+        assert len(unique_id) == COMM_ID_BYTES
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().p25_comm_init(buf, rank, world, C.byref(h)))
+        self.h, self.rank, self.world = h, rank, world
+
+    @property
+    def stream(self):
+        return lib().p25_comm_stream(self.h)
+
+    def gather(self, circuit, mark_slot, d_proofs, proof_stride, d_status, counts, dst, d_all_proofs, d_all_status):
+        """p25_gather_proofs with device addresses (ints); circuit may be None (no device-side wait)."""
+        cnt = (C.c_size_t * self.world)(*[int(x) for x in counts])
+        _check(lib().p25_gather_proofs(self.h, circuit.h if circuit is not None else None, int(mark_slot), d_proofs,
+                                       proof_stride, d_status, cnt, dst, d_all_proofs, d_all_status))
+
+    def sync(self):
+        _check(lib().p25_comm_sync(self.h))
+
+    def barrier(self):
+        _check(lib().p25_comm_barrier(self.h))
+
+    def max_f64(self, value):
+        v = C.c_double(float(value))
+        _check(lib().p25_comm_max_f64(self.h, C.byref(v)))
+        return float(v.value)
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, None
+            _check(lib().p25_comm_destroy(h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shader_clock_hz():

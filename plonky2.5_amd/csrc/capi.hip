@@ -1,5 +1,6 @@
 // C ABI of libp25 (declared in include/p25.h).  Thin: argument checks, device buffers, launches.
 #include <stdlib.h>
+#include <unistd.h>
 #include <cstring>
 #include <memory>
 #include <atomic>
@@ -17,6 +18,50 @@ static std::once_flag g_tables_once;
 static std::unique_ptr<NttTables> g_tables;
 static std::mutex g_primitives_mutex;  // the primitive entry points share g_tables (NttTables caches are not thread-safe)
 
+// What p25_runtime_info reports about the hardware-queue setting (p25.h).  Filled by the first of p25_device_init[_ex] /
+// ensure_device to run, before that call's first HIP call.
+struct HwQueueState {
+  std::mutex mu;
+  bool decided = false;
+  int requested = 0;          // what the library asked for (0 = nothing)
+  bool host_exported = false; // GPU_MAX_HW_QUEUES was in the environment already: the host's value stands
+  bool runtime_was_up = false;  // this process had the GPU driver open before the library's first HIP call
+};
+static HwQueueState g_hwq;
+
+// True if this process already holds /dev/kfd: the ROCm runtime under HIP has been initialised (by the host, by torch, or by
+// a profiler's preloaded tool library), so an environment variable set NOW may no longer be read.
+static bool gpu_driver_open() {
+  char link[64], target[256];
+  for (int fd = 0; fd < 1024; fd++) {
+    snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
+    ssize_t k = readlink(link, target, sizeof target - 1);
+    if (k <= 0) continue;
+    target[k] = 0;
+    if (!strcmp(target, "/dev/kfd")) return true;
+  }
+  return false;
+}
+
+// Ask the HIP runtime for `hw_queues` hardware queues (never overriding a value the host exported) BEFORE the library's first
+// HIP call, and remember whether that can still have had an effect.  Returns true when it probably had none.
+static bool apply_hw_queues(int hw_queues) {
+  std::lock_guard<std::mutex> l(g_hwq.mu);
+  if (!g_hwq.decided) {
+    g_hwq.decided = true;
+    g_hwq.host_exported = getenv("GPU_MAX_HW_QUEUES") != nullptr;
+    g_hwq.runtime_was_up = gpu_driver_open();
+    g_hwq.requested = hw_queues;
+    if (hw_queues > 0) setenv("GPU_MAX_HW_QUEUES", std::to_string(hw_queues).c_str(), 0);
+  }
+  return g_hwq.requested > 0 && !g_hwq.host_exported && g_hwq.runtime_was_up;
+}
+static const char* const HWQ_LATE_MSG =
+    "warning: GPU_MAX_HW_QUEUES was not in the environment and the GPU runtime was already open in this process when libp25 "
+    "first ran (the host, torch or a profiler touched HIP first): if HIP had been initialised too the setting has no effect "
+    "and the 16 proving streams share the runtime's default 4 hardware queues (measured 78.8 vs 91.7+ proofs/s); export "
+    "GPU_MAX_HW_QUEUES=24 before the process touches HIP";
+
 NttTables& tables() {
   std::call_once(g_tables_once, [] { g_tables.reset(new NttTables()); });
   return *g_tables;
@@ -25,6 +70,8 @@ NttTables& tables() {
 p25_status ensure_device() {
   int d = g_device.load(std::memory_order_acquire);
   if (d < 0) {
+    // a host that skipped p25_device_init: the library's default still applies, before this first HIP call
+    (void)apply_hw_queues(P25_DEFAULT_HW_QUEUES);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -105,14 +152,17 @@ const char* p25_version(void) { return "libp25 0.1 (gfx950)"; }
 // argument, before its first HIP call, never overriding a value the host has exported -- and NOT when it is loaded (rounds
 // 1-4 did that from a constructor: a process-wide side effect a host had no say in).  A host that initialises HIP before
 // that call exports the variable itself.
-p25_status p25_device_init(int device_index) { return p25_device_init_ex(device_index, P25_DEFAULT_HW_QUEUES); }
+p25_status p25_device_init(int device_index) {
+  const p25_status s = p25_device_init_ex(device_index, P25_DEFAULT_HW_QUEUES);
+  return s == P25_WARN_HW_QUEUES_LATE ? P25_OK : s;   // the plain form never warns through its status (p25_runtime_info does)
+}
 
 p25_status p25_device_init_ex(int device_index, int hw_queues) {
   if (hw_queues < 0 || hw_queues > 128) {
     g_last_error = "hw_queues out of range (0 = leave the runtime's setting alone)";
     return P25_ERR_INVALID_ARG;
   }
-  if (hw_queues > 0) setenv("GPU_MAX_HW_QUEUES", std::to_string(hw_queues).c_str(), 0);   // before the first HIP call below
+  const bool late = apply_hw_queues(hw_queues);   // before the first HIP call below
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     g_last_error = "no HIP device available (libp25 has no CPU fallback)";
@@ -127,6 +177,31 @@ p25_status p25_device_init_ex(int device_index, int hw_queues) {
     return P25_ERR_HIP;
   }
   g_device.store(device_index, std::memory_order_release);
+  if (late) {
+    g_last_error = HWQ_LATE_MSG;
+    return P25_WARN_HW_QUEUES_LATE;
+  }
+  return P25_OK;
+}
+
+p25_status p25_runtime_info(p25_runtime_info_t* out) {
+  if (!out) {
+    g_last_error = "out is null";
+    return P25_ERR_INVALID_ARG;
+  }
+  memset(out, 0, sizeof *out);
+  out->device_index = g_device.load(std::memory_order_acquire);
+  {
+    std::lock_guard<std::mutex> l(g_hwq.mu);
+    out->hw_queues_requested = g_hwq.requested;
+    out->hw_queues_host_exported = g_hwq.host_exported ? 1 : 0;
+    out->runtime_open_before_init = g_hwq.runtime_was_up ? 1 : 0;
+    out->hw_queues_setting_late = (g_hwq.decided && g_hwq.requested > 0 && !g_hwq.host_exported && g_hwq.runtime_was_up) ? 1 : 0;
+  }
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  out->hw_queues_env = e ? (int32_t)strtol(e, nullptr, 10) : 0;
+  out->proving_streams = 16;
+  out->main_streams = 2;
   return P25_OK;
 }
 

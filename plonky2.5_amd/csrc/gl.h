@@ -70,9 +70,6 @@ GL_HD u64 reduce96(u64 lo, u32 hi) {
   if (t2 < t1) t2 += EPS;
   return t2;
 }
-#ifndef P25_ASM_MUL
-#define P25_ASM_MUL 1
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 GL_HD u64 make64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 // Hand-scheduled gfx950 product + reduction: 14 VALU (5 v_mad_u64_u32 + 9 carry ops) against the ~30
@@ -192,7 +189,7 @@ __device__ __forceinline__ u64 mad_nc_s_asm(u64 a, u64 b_uniform, u64 addend) {
 #endif
 // a*b + c, any u64 inputs -> non-canonical result
 GL_HD u64 mad_nc(u64 a, u64 b, u64 c) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   return mad_nc_asm(a, b, c);
 #else
   unsigned __int128 t = (unsigned __int128)a * b + c;
@@ -201,7 +198,7 @@ GL_HD u64 mad_nc(u64 a, u64 b, u64 c) {
 }
 // a * b_uniform + c for a wave-uniform b (see mad_nc_s_asm)
 GL_HD u64 mad_nc_s(u64 a, u64 b_uniform, u64 c) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   return mad_nc_s_asm(a, b_uniform, c);
 #else
   unsigned __int128 t = (unsigned __int128)a * b_uniform + c;
@@ -210,7 +207,7 @@ GL_HD u64 mad_nc_s(u64 a, u64 b_uniform, u64 c) {
 }
 // any u64 inputs (non-canonical allowed) -> non-canonical product
 GL_HD u64 mul_nc(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   return mul_nc_asm(a, b);
 #else
   return reduce128(a * b, mulhi64(a, b));

@@ -220,7 +220,7 @@ __device__ __forceinline__ u64 add_nc_asm(u64 a, u64 b) {
 
 // ---- the forms kernels call -------------------------------------------------------------------------------------------
 GL_HD void bfly_nc(u64 u, u64 v, bool swap, u64& s, u64& d) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   bfly_nc_asm(u, v, swap, s, d);
 #else
   s = add_nc_c(u, v);
@@ -229,14 +229,14 @@ GL_HD void bfly_nc(u64 u, u64 v, bool swap, u64& s, u64& d) {
 }
 // any + any, any - any
 GL_HD u64 add_nc(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   return add_nc_asm(a, b);
 #else
   return add_nc_c(a, b);
 #endif
 }
 GL_HD u64 sub_nc(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   return sub_nc_asm(a, b);
 #else
   return sub_nc_c(a, b);
@@ -245,14 +245,14 @@ GL_HD u64 sub_nc(u64 a, u64 b) {
 // any + (b <= p), any - (b <= p): one correction.  The caller guarantees the bound on b (a value read from a committed
 // matrix, a challenge, a compile-time constant below p).
 GL_HD u64 add_c(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   return add_c_asm(a, b);
 #else
   return add_nc_c(a, b);
 #endif
 }
 GL_HD u64 sub_c(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   return sub_c_asm(a, b);
 #else
   return sub_nc_c(a, b);
@@ -263,7 +263,7 @@ GL_HD u64 sub_c(u64 a, u64 b) {
 // 0 = the true value whatever this factor reads -- the modular correction of gl::sub (5 instructions) is never needed.
 GL_HD u64 dec_wrap(u64 a, u64 k) { return a - k; }
 GL_HD u64 shl_nc(u64 x, int e) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   return shl_nc_asm(x, e);
 #else
   return shl_nc_c(x, e);

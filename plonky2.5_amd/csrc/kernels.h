@@ -20,12 +20,8 @@
 #else
 #define P25_WAVE_PRIO(n) ((void)0)
 #endif
-#ifndef P25_PRIO_BULK
 #define P25_PRIO_BULK 2
-#endif
-#ifndef P25_PRIO_CHAIN
 #define P25_PRIO_CHAIN 3
-#endif
 namespace p25 {
 
 struct HipError : std::runtime_error {
@@ -74,8 +70,7 @@ struct NttPass {
   int inverse;           // pow_table holds powers of the INVERSE root (selects the 16th-root constants of kernels_ntt.hip)
   int lazy_out;          // the output is read by another pass of k_ntt_tile only: store any u64 congruent to the value
                          // (the kernel computes in lazy arithmetic, gl_lazy.h); 0 = canonical, as everything else expects
-  uint32_t n_tiles, n_cosets, xcd_map, full_table;  // set by launch_ntt_pass
-  uint32_t n_polys, n_blocks_total;                  // set by launch_ntt_pass
+  uint32_t n_tiles, n_cosets, log_g, full_table;  // set by launch_ntt_pass (log_g: block decode of k_ntt_tile)
 };
 void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st);
 // Shader clock (Hz) under a full-chip Poseidon load, from in-kernel cycle and wall-clock counters (kernels_hash.hip).

@@ -10,45 +10,11 @@
 // the 64 lanes of a wave read 64 consecutive u64 of one column per load -- fully coalesced with no
 // transpose pass (upstream transposes the LDE to row-major leaves first; the digest is the same).
 // Digests are stored as 4 consecutive u64 per node (32 B per lane, contiguous across lanes).
-#include <stdlib.h>
 #include "kernels.h"
 #include "poseidon.h"
 #include "poseidon2.h"
 #include "coop.h"
 #include "coop_lat.h"
-// Build switches (tools/hash_variants.sh builds the variants): which kernels take the wave-wide permutation of
-// tools/poseidon_mfma.h (full-round MDS layers on the matrix cores; an experiment kept under tools/, not product code)
-// and the occupancy they are compiled for.
-// Measured on MI355X (profiles/r03_mfma_*.txt): the MFMA form executes 10 % fewer VALU instructions per permutation and
-// is 5 % faster standalone (2726 vs 2593 Mperm/s), but needs 128 VGPRs (4 waves per SIMD instead of 6) and each of its
-// 168 MFMAs holds the SIMD's VALU issue for ~13 cycles; in the 16-stream proving pipeline that is +0.4 % (leaf + tree)
-// to +0.9 % (leaf only) -- inside the run-to-run spread -- so the product default stays the VALU form at 6 waves per SIMD.
-#ifndef P25_LEAF_MX
-#define P25_LEAF_MX 0
-#endif
-#ifndef P25_TREE_MX
-#define P25_TREE_MX 0
-#endif
-#if P25_LEAF_MX || P25_TREE_MX
-#include "poseidon_mfma.h"   // tools/poseidon_mfma.h: experiment builds only (tools/hash_variants.sh adds -I tools); never in libp25.so
-#endif
-#ifndef P25_LEAF_MINW
-#define P25_LEAF_MINW (P25_LEAF_MX ? 4 : 6)
-#endif
-#ifndef P25_TREE_MINW
-#define P25_TREE_MINW (P25_TREE_MX ? 4 : 6)
-#endif
-// Experiment switch (round 5): hold the bulk hash kernels to FEWER waves per SIMD than their registers
-// allow, so that a wave of another kernel fits beside them -- P25_HASH_NUM_VGPR caps the allocation (e.g. 104 with
-// P25_*_MINW 4: four waves take 416 of the SIMD's 512 registers and leave 96).  0 = off (the product).
-#ifndef P25_HASH_NUM_VGPR
-#define P25_HASH_NUM_VGPR 0
-#endif
-#if P25_HASH_NUM_VGPR
-#define P25_HASH_VGPR_ATTR __attribute__((amdgpu_num_vgpr(P25_HASH_NUM_VGPR)))
-#else
-#define P25_HASH_VGPR_ATTR
-#endif
 
 namespace p25 {
 
@@ -79,36 +45,9 @@ __global__ __launch_bounds__(256) void k_poseidon2_permute(u64* states, size_t n
 // columns), and one wave per workgroup lets the dispatcher back-fill SIMDs as soon as a single wave
 // retires (tools/hashbench.hip: 5 % over 256-lane workgroups).
 // 80 VGPRs (6 waves per SIMD) leave room for other streams' waves next to it.
-// With P25_LEAF_MX a workgroup whose 64 leaves all exist runs the wave-wide permutation of poseidon_mfma.h (the MDS
-// layers of the full rounds on the matrix cores; 128 VGPRs, 4 waves per SIMD); a ragged last workgroup and leaves
-// of <= 4 words take the per-lane path.  Same digests either way.
-__device__ __forceinline__ void hash_leaf_block(size_t block, const u64* __restrict__ cols, size_t col_stride, int width,
-                                                size_t n_leaves, u64* __restrict__ digests) {
-  size_t l = block * 64 + threadIdx.x;   // launched with 64 lanes per workgroup
-#if defined(__HIP_DEVICE_COMPILE__) && P25_LEAF_MX
-  if ((block + 1) * 64 <= n_leaves && width > 4) {
-    const poseidon::mx::Ctx c = poseidon::mx::make_ctx(threadIdx.x);
-    const u64* in = cols + l;
-    u64 s[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = 0;
-    for (int off = 0; off < width; off += poseidon::RATE) {
-      const int m = width - off < poseidon::RATE ? width - off : poseidon::RATE;
-#pragma unroll
-      for (int i = 0; i < poseidon::RATE; i++)
-        if (i < m) s[i] = in[(size_t)(off + i) * col_stride];
-      // the inputs land here, not somewhere inside the permutation (left to itself the compiler's placement of this
-      // wait costs 12 % of the kernel: tools/hashbench.hip "explicit wait")
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int next = width - (off + poseidon::RATE);
-      poseidon::mx::permute_wave(s, next <= 0 ? poseidon::ROWS_DIGEST : (next >= poseidon::RATE ? poseidon::ROWS_CAPACITY : poseidon::ROWS_ALL), c);
-    }
-    u64* d = digests + 4 * l;
-#pragma unroll
-    for (int i = 0; i < 4; i++) d[i] = s[i];
-    return;
-  }
-#endif
+__device__ __forceinline__ void hash_leaf(const u64* __restrict__ cols, size_t col_stride, int width,
+                                          size_t n_leaves, u64* __restrict__ digests) {
+  size_t l = (size_t)blockIdx.x * 64 + threadIdx.x;   // launched with 64 lanes per workgroup
   if (l >= n_leaves) return;
   u64 out[4];
   poseidon::hash_or_noop_strided(cols + l, col_stride, width, out);
@@ -116,66 +55,21 @@ __device__ __forceinline__ void hash_leaf_block(size_t block, const u64* __restr
 #pragma unroll
   for (int i = 0; i < 4; i++) d[i] = out[i];
 }
-// P25_HASH_PERSIST (experiment, tools/knobs_build.sh): the grid may be SMALLER than the number of 64-leaf blocks; every
-// workgroup then walks the blocks grid-stride.  A launch of fewer workgroups than the chip has wave slots is dispatched at
-// once and leaves its hardware queue's pipe free for the next queue (profiles/r05_c_timeline_batch192.txt).
-#ifndef P25_HASH_PERSIST
-#define P25_HASH_PERSIST 0
-#endif
-__device__ __forceinline__ void hash_leaf(const u64* __restrict__ cols, size_t col_stride, int width,
-                                          size_t n_leaves, u64* __restrict__ digests) {
-#if P25_HASH_PERSIST
-  const size_t n_blocks = (n_leaves + 63) / 64;
-  for (size_t b = blockIdx.x; b < n_blocks; b += gridDim.x) hash_leaf_block(b, cols, col_stride, width, n_leaves, digests);
-#else
-  hash_leaf_block(blockIdx.x, cols, col_stride, width, n_leaves, digests);
-#endif
-}
-__global__ __launch_bounds__(64, P25_LEAF_MINW) P25_HASH_VGPR_ATTR void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
+__global__ __launch_bounds__(64, 6) void k_hash_leaves(const u64* __restrict__ cols, size_t col_stride,
                                                        int width, size_t n_leaves, u64* __restrict__ digests) {
   hash_leaf(cols, col_stride, width, n_leaves, digests);
 }
 // The same kernel under its own symbol for wide matrices (the 135-column wires LDE: the dominant launch
 // of a proof), so that profiler summaries list it separately from the 20- and 16-column commits.
-__global__ __launch_bounds__(64, P25_LEAF_MINW) P25_HASH_VGPR_ATTR void k_hash_leaves_wide(const u64* __restrict__ cols, size_t col_stride,
+__global__ __launch_bounds__(64, 6) void k_hash_leaves_wide(const u64* __restrict__ cols, size_t col_stride,
                                                             int width, size_t n_leaves, u64* __restrict__ digests) {
   hash_leaf(cols, col_stride, width, n_leaves, digests);
 }
 
 // parents[m] = two_to_one(children[2m], children[2m+1])
-__global__ __launch_bounds__(64, P25_TREE_MINW) P25_HASH_VGPR_ATTR void k_tree_level(const u64* __restrict__ children,
+__global__ __launch_bounds__(64, 6) void k_tree_level(const u64* __restrict__ children,
                                                     u64* __restrict__ parents, size_t n_parents) {
-#if P25_HASH_PERSIST
-  for (size_t blk = blockIdx.x; blk * 64 < n_parents; blk += gridDim.x) {
-    const size_t m = blk * 64 + threadIdx.x;
-    if (m >= n_parents) break;
-    u64 l[4], r[4], o[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      l[i] = children[8 * m + i];
-      r[i] = children[8 * m + 4 + i];
-    }
-    poseidon::two_to_one(l, r, o);
-#pragma unroll
-    for (int i = 0; i < 4; i++) parents[4 * m + i] = o[i];
-  }
-  return;
-#endif
   size_t m = (size_t)blockIdx.x * 64 + threadIdx.x;
-#if defined(__HIP_DEVICE_COMPILE__) && P25_TREE_MX
-  if (((size_t)blockIdx.x + 1) * 64 <= n_parents) {   // whole wave: the wave-wide permutation (poseidon_mfma.h)
-    const poseidon::mx::Ctx c = poseidon::mx::make_ctx(threadIdx.x);
-    u64 s[12];
-#pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = children[8 * m + i];
-#pragma unroll
-    for (int i = 8; i < 12; i++) s[i] = 0;
-    poseidon::mx::permute_wave(s, poseidon::ROWS_DIGEST, c);
-#pragma unroll
-    for (int i = 0; i < 4; i++) parents[4 * m + i] = s[i];
-    return;
-  }
-#endif
   if (m >= n_parents) return;
   u64 l[4], r[4], o[4];
 #pragma unroll
@@ -253,24 +147,12 @@ __global__ __launch_bounds__(256) void k_tree_top_coop(u64* __restrict__ nodes, 
 // form leaves most SIMDs with one wave or none, and the level takes a full permutation latency.
 constexpr size_t COOP_PARENTS_BATCH = 512, COOP_PARENTS_SINGLE = 32768;
 
-// Workgroups a bulk hash launch of `blocks` 64-lane blocks gets: all of them, unless the experiment build caps the grid
-// (P25_X_HASH_GRID, with P25_HASH_PERSIST) and more than one proof is in flight.
-static unsigned hash_grid(size_t blocks, bool single_proof) {
-#if defined(P25_EXPERIMENT_KNOBS) && P25_HASH_PERSIST
-  static const size_t cap = [] {
-    const char* e = getenv("P25_X_HASH_GRID");
-    return e ? (size_t)strtoul(e, nullptr, 0) : 0;
-  }();
-  if (cap && !single_proof && blocks > cap) return (unsigned)cap;
-#endif
-  return (unsigned)blocks;
-}
 static void launch_level(const u64* cur, u64* nxt, size_t m, hipStream_t st, bool single_proof) {
   if (m <= (single_proof ? COOP_PARENTS_SINGLE : COOP_PARENTS_BATCH)) {
     size_t th = m * coop::GROUP;
     hipLaunchKernelGGL(k_tree_level_coop, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, cur, nxt, m);
   } else {
-    hipLaunchKernelGGL(k_tree_level, dim3(hash_grid((m + 63) / 64, single_proof)), dim3(64), 0, st, cur, nxt, m);
+    hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, cur, nxt, m);
   }
 }
 // Levels from `cur` (m nodes) up to the cap: one launch per level while a cap entry has more than TOP_MAX_NODES
@@ -376,10 +258,10 @@ u64* launch_merkle_tree(const u64* d_cols, size_t col_stride, int width, size_t 
                         hipEvent_t ev_end, bool single_proof) {
   if (ev_begin) (void)hipEventRecord(ev_begin, st);
   if (width >= 128)
-    hipLaunchKernelGGL(k_hash_leaves_wide, dim3(hash_grid((n_leaves + 63) / 64, single_proof)), dim3(64), 0, st, d_cols,
+    hipLaunchKernelGGL(k_hash_leaves_wide, dim3((unsigned)((n_leaves + 63) / 64)), dim3(64), 0, st, d_cols,
                        col_stride, width, n_leaves, d_tree);
   else
-    hipLaunchKernelGGL(k_hash_leaves, dim3(hash_grid((n_leaves + 63) / 64, single_proof)), dim3(64), 0, st, d_cols,
+    hipLaunchKernelGGL(k_hash_leaves, dim3((unsigned)((n_leaves + 63) / 64)), dim3(64), 0, st, d_cols,
                        col_stride, width, n_leaves, d_tree);
   if (ev_end) (void)hipEventRecord(ev_end, st);
   return launch_levels_to_cap(d_tree, n_leaves, cap_height, st, single_proof);

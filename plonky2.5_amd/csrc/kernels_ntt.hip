@@ -22,22 +22,16 @@
 //   kind 0 ("t-contiguous"): addr = t + imap(i) * NT
 //   kind 1 ("i-contiguous"): addr = tmap(t) * R + imap(i)
 // where imap/tmap are the identity or a bit reversal.  All values are canonical field elements.
-#include <stdlib.h>
 #include <mutex>
 #include <set>
 #include <tuple>
 #include "kernels.h"
 #include "ntt16.h"
 
-// transforms above 2^P25_NTT_FACTOR_LOG points take the coset pre-scale as two factor tables (ntt_lde_bitrev)
 // (Phase priorities -- load / store phases of k_ntt_tile above or below its butterflies -- were measured in round 4 and
 // change nothing: profiles/r04_ab_ntt_phase_priority.txt.)
-#ifndef P25_NTT_PERSIST
-#define P25_NTT_PERSIST 0
-#endif
-#ifndef P25_NTT_FACTOR_LOG
-#define P25_NTT_FACTOR_LOG 16
-#endif
+// transforms above 2^NTT_FACTOR_LOG points take the coset pre-scale as two factor tables (ntt_lde_bitrev)
+constexpr int NTT_FACTOR_LOG = 16;
 
 namespace p25 {
 
@@ -102,39 +96,21 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
   const int TP = T > 1 ? T + 1 : 1;  // row padding: conflict-free for both access directions
   u64* wl = lds + (size_t)R * TP;    // twiddles of the sub-transform: w_R^e, e < R/2 (e < R with full_table)
   const u32 NT = 1u << a.log_nt;
-  // Block -> (tile, polynomial, coset).  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.
-  // With xcd_map the 1-D grid is decoded so that the n_cosets blocks reading the SAME coefficient tile run on the
-  // same XCD back to back (the tile is fetched from HBM once, not once per coset) and an XCD only ever touches
-  // tiles = xcd (mod 8), i.e. 1/8 of the per-coset pre-scale table, which then stays L2-resident across polynomials.
   const int tid = threadIdx.x, nth = blockDim.x;
   const int wstride_log = a.log_n_table - a.log_r;  // w_R^k = w_N^(k * N/R)
   for (int k = tid; k < (a.full_table ? R : R / 2); k += nth) wl[k] = a.pow_table[(size_t)k << wstride_log];
-  // P25_NTT_PERSIST (experiment, tools/knobs_build.sh): a 1-D grid that may hold fewer blocks than there are tiles; a block
-  // then walks the tiles grid-stride (a multiple of 8 apart, so it stays on its XCD's share), twiddles staged once.
-#if P25_NTT_PERSIST
-  for (u32 L = blockIdx.x; L < a.n_blocks_total; L += gridDim.x) {
-  if (L != blockIdx.x) __syncthreads();   // the previous tile's stores have read the LDS this tile's loads overwrite
-#else
-  {
+  // Block -> (tile, polynomial, coset), ONE decode for every launch.  The grid is 1-D and workgroups are dealt round-robin
+  // to the 8 XCDs, each with its own 4 MB L2: the low log_g bits of the block index (g = min(8, tiles)) pick the tile's
+  // residue, so an XCD only ever touches tiles = xcd (mod 8) -- 1/8 of the per-coset pre-scale table, which then stays
+  // L2-resident across polynomials -- and the n_cosets blocks reading the SAME coefficient tile run on the same XCD back to
+  // back (the tile is fetched from HBM once, not once per coset).  With one coset this is tile = L mod tiles, poly = L / tiles.
   const u32 L = blockIdx.x;
-#endif
-  u32 tile, poly, coset;
-  if (a.xcd_map) {
-    const u32 xcd = L & 7u, m = L >> 3;
-    const u32 tiles8 = a.n_tiles >> 3;
-    coset = m % a.n_cosets;
-    const u32 r = m / a.n_cosets;
-    tile = (r % tiles8) * 8 + xcd;
-    poly = r / tiles8;
-  } else if (P25_NTT_PERSIST) {   // 1-D grid: tile fastest, then polynomial, then coset (the 3-D grid's order)
-    tile = L % a.n_tiles;
-    poly = (L / a.n_tiles) % a.n_polys;
-    coset = L / (a.n_tiles * a.n_polys);
-  } else {
-    tile = blockIdx.x;
-    poly = blockIdx.y;
-    coset = blockIdx.z;
-  }
+  const u32 m = L >> a.log_g;
+  const u32 tiles_g = a.n_tiles >> a.log_g;
+  const u32 coset = m % a.n_cosets;
+  const u32 r = m / a.n_cosets;
+  const u32 tile = (r % tiles_g) * (1u << a.log_g) + (L & ((1u << a.log_g) - 1u));
+  const u32 poly = r / tiles_g;
   const u32 tg0 = tile * T;
   const u64* in = a.in + (size_t)poly * a.in_poly_stride;
   u64* out = a.out + (size_t)poly * a.out_poly_stride + a.coset_out_off[coset];
@@ -274,7 +250,6 @@ __global__ __launch_bounds__(NTH) void k_ntt_tile(NttPass a) {
     if (a.post_t) x = gl::mul_nc(x, gl::mul_nc(a.post_t[tw], a.post_i[j]));
     out[addr] = a.lazy_out ? x : gl::canon(x);
   }
-  }
 }
 
 // LDS bytes of a tile: R rows of T (+1 padding) words + the sub-transform's twiddle table
@@ -289,30 +264,11 @@ void launch_ntt_pass(const NttPass& p, int n_polys, int n_cosets, hipStream_t st
   // not fit the LDS a block may take with it and keeps the half table and the radix-2 network
   q.full_table = p.log_r <= 10;
   size_t lds = tile_lds_bytes(p.log_r, p.log_t);
-#ifdef P25_EXPERIMENT_KNOBS
-  // tools/knobs_build.sh only (never the shipped library): extra dynamic LDS per block, to hold the kernel to fewer blocks per CU
-  static const size_t pad = [] {
-    const char* e = getenv("P25_X_NTT_LDS_PAD");
-    return e ? (size_t)strtoul(e, nullptr, 0) : 0;
-  }();
-  if (lds + pad <= 160 * 1024) lds += pad;
-#endif
   q.n_tiles = 1u << (p.log_nt - p.log_t);
   q.n_cosets = (uint32_t)n_cosets;
-  q.xcd_map = n_cosets > 1 && (q.n_tiles & 7u) == 0;
-  dim3 grid = q.xcd_map ? dim3(q.n_tiles * (uint32_t)n_polys * (uint32_t)n_cosets) : dim3(q.n_tiles, n_polys, n_cosets);
-  q.n_polys = (uint32_t)n_polys;
-  q.n_blocks_total = q.n_tiles * (uint32_t)n_polys * (uint32_t)n_cosets;
-#if P25_NTT_PERSIST
-  grid = dim3(q.n_blocks_total);
-#if defined(P25_EXPERIMENT_KNOBS)
-  static const unsigned cap = [] {
-    const char* e = getenv("P25_X_NTT_GRID");
-    return e ? (unsigned)strtoul(e, nullptr, 0) & ~7u : 0u;
-  }();
-  if (cap && grid.x > cap) grid = dim3(cap);
-#endif
-#endif
+  q.log_g = 0;
+  while (q.log_g < 3 && (2u << q.log_g) <= q.n_tiles) q.log_g++;
+  const dim3 grid(q.n_tiles * (uint32_t)n_polys * (uint32_t)n_cosets);
   // tiles of 2^13 elements (16-wide tiles of 512-point sub-transforms: 2^19-point transforms, BASELINE config 5) take
   // 512 threads, so that a CU's two resident blocks still give every SIMD four waves; above 64 KB of dynamic LDS the
   // function attribute has to allow it (a workgroup may take up to 160 KB on gfx950)
@@ -496,7 +452,7 @@ void ntt_lde_bitrev(NttTables& tb, const u64* d_coeffs, size_t coeff_stride, u64
   // fits the L2s next to the data (n <= 2^16: 4 MB, 1/8 of it per XCD).  Above that the two-pass transform takes the
   // factors shift_c^k1 (k1 < R1) and (shift_c^R1)^k2 (k2 < R2) instead: 12 K words for n = 2^19 instead of 4 M.
   auto& cache = tb.coset_cache();
-  const bool factored = l1 != 0 && log_n > P25_NTT_FACTOR_LOG;
+  const bool factored = l1 != 0 && log_n > NTT_FACTOR_LOG;
   auto key = std::make_tuple(factored ? -log_n : log_n, rate_bits, shift);
   auto it = cache.find(key);
   if (it == cache.end()) {

@@ -629,32 +629,12 @@ void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st) {
 // 1.78 ms and the batch 110 -> 119 proofs/s (3, 4, 6 waves: 2.15, 1.85, 1.77 ms).  Round 3 (wires read one iteration
 // ahead, wave priority 2): 4 / 5 / 6 waves measure 137.3 / 136.7 / 135.8 proofs/s -- with its loads overlapped the kernel
 // no longer needs the fifth wave, and at 128 VGPRs it spills less.
-#ifndef P25_Q_WAVES
-#define P25_Q_WAVES 4
-#endif
-// The recursion instantiation (k_quotient_rec: aggregation circuits): waves per SIMD, and whether the merged pass over
-// the routed wires (below) is compiled in for it too
-#ifndef P25_QREC_WAVES
-#define P25_QREC_WAVES 3
-#endif
-#ifndef P25_QREC_MERGED
-#define P25_QREC_MERGED 1
-#endif
-// prefetch distance of the permutation-argument pass (1, 2, 4 or 8)
-#ifndef P25_Q_PF
-#define P25_Q_PF 1
-#endif
-// P25_Q_MERGE_PERM (round 5 experiment): the permutation argument evaluated INSIDE the merged pass over the routed wires -- each
-// routed wire column is then read once by the kernel's first two stages instead of twice (80 of ~620 column reads per point).
-#ifndef P25_Q_MERGE_PERM
-#define P25_Q_MERGE_PERM 0
-#endif
-#ifndef P25_Q_PERSIST
-#define P25_Q_PERSIST 0
-#endif
-#ifndef P25_QREC_PRIO
-#define P25_QREC_PRIO P25_PRIO_BULK
-#endif
+constexpr int Q_WAVES = 4;
+// The recursion instantiation (k_quotient_rec: aggregation circuits) is held to 3 waves per SIMD; the merged pass over the
+// routed wires (below) is compiled in for it too.
+constexpr int QREC_WAVES = 3;
+// prefetch distance of the permutation-argument pass (1, 2, 4 and 8 were measured: profiles/r04_ab_quotient_variants.txt)
+constexpr int Q_PF = 1;
 // REC: the gate set of recursive-verifier circuits (adds ArithmeticExtensionGate and PoseidonGate).  The fib-64 hot
 // path runs the REC = false instantiation, whose code is what it was before those gates existed.
 template <bool REC>
@@ -678,18 +658,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   __syncthreads();
   const uint32_t lde_bits = a.degree_bits + a.rate_bits;
   const size_t big = (size_t)1 << lde_bits;
-  // P25_Q_PERSIST (experiment, tools/knobs_build.sh): the grid may hold fewer blocks than there are 128-point blocks; a
-  // block then walks them grid-stride, its alpha-power tables staged once.  A launch that fits the chip is dispatched at
-  // once (its hardware queue's pipe is free for the next queue) and holds at most grid / 256 blocks per CU.
-#if P25_Q_PERSIST
-  for (size_t pblk = blockIdx.x; pblk * blockDim.x < big; pblk += gridDim.x) {
-  const size_t p = pblk * blockDim.x + threadIdx.x;  // bit-reversed position
-  if (p >= big) break;
-#else
-  {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // bit-reversed position
   if (p >= big) return;
-#endif
   const uint32_t i_nat = gl::bitrev((u32)p, lde_bits);
   const u64 x = gl::mul(gl::GENERATOR, a.pow_big[i_nat]);
   const uint32_t rate_mask = (1u << a.rate_bits) - 1;
@@ -732,25 +702,11 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   // per column, but 192 spilled registers instead of 116 and no gain.)  Those gates share ONE alpha-fold accumulator: each
   // constraint is multiplied by its gate's filter first (116 multiplications, paid for by the five per-gate folds of the
   // accumulator limbs that are no longer needed);  sum_g f_g sum_j alpha^j c_gj = sum_j alpha^j sum_g f_g c_gj.
-  const bool fast = (!REC || P25_QREC_MERGED) && per == 8 && RW == 80 && NP == 9 && a.num_wires >= 80;
+  const bool fast = per == 8 && RW == 80 && NP == 9 && a.num_wires >= 80;
   uint32_t merged_mask = 0;   // gate kinds evaluated by the merged pass
   u64 mg0 = 0, mg1 = 0;       // their filtered, alpha-folded sums
   const u64 beta0 = a.chal[CH_BETAS], beta1 = a.chal[CH_BETAS + 1];
   const u64 gamma0 = a.chal[CH_GAMMAS], gamma1 = a.chal[CH_GAMMAS + 1];
-  // chunk k of the partial-product check, both challenges: prev * numerator - next * denominator, folded with alpha
-  auto perm_chunk = [&](int k, u64 n0, u64 d0, u64 n1, u64 d1) {
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const u64 np = c ? n1 : n0, dp = c ? d1 : d0;
-      u64 prev = k == 0 ? zsc.col(c) : zsc.col(NC + c * NP + k - 1);
-      u64 next = k == NP ? a.zs_lde[(size_t)c * big + p_next] : zsc.col(NC + c * NP + k);
-      u64 t = gl::sub_nc(gl::mul_nc(prev, np), gl::mul_nc(next, dp));
-      int ti = NC + c * nch + k;
-      res[0] = gl::mad_nc(t, ap[ti], res[0]);
-      res[1] = gl::mad_nc(t, ap[ALPHA_POWS + ti], res[1]);
-    }
-  };
-  bool perm_done = false;
   if (fast) {
     for (uint32_t gi = 0; gi < a.n_gates; gi++) {
       const uint32_t kind = a.gates[gi].kind;
@@ -781,8 +737,6 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     mc.reset();
     u64 bs_sum = 0, bs_w0 = 0;
     u64 wnext = wrc.col(0);   // the wire read one position ahead
-    u64 snext = P25_Q_MERGE_PERM ? csc.col(n_consts + 2) : 0;   // ... and its sigma (merged permutation argument)
-    u64 pn0 = 1, pd0 = 1, pn1 = 1, pd1 = 1;
     SmallLin bs_acc;
     u64 ar0 = 0, ar1 = 0, ar2 = 0;                    // arithmetic: multiplicand 0, multiplicand 1, addend of the current op
     u64 mx0 = 0, mx1 = 0, mx2 = 0, mx3 = 0, mx4 = 0;  // mul-extension: a, b and output.a of the current op
@@ -792,23 +746,6 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const int j = base + (JJ);                                                                                  \
     const u64 w = wnext;                                                                                        \
     if (j + 1 < 80) wnext = wrc.col(j + 1);                                                                      \
-    if (P25_Q_MERGE_PERM) {   /* the permutation argument on the same read of the wire (both challenges) */        \
-      const u64 sg = snext;                                                                                     \
-      if (j + 1 < 80) snext = csc.col(n_consts + 2 + j + 1);                                                     \
-      const u64 wg0 = gl::add_c(w, gamma0), wg1 = gl::add_c(w, gamma1);                                         \
-      if ((JJ) % 8 == 0) {                                                                                      \
-        pn0 = gl::mad_nc(kb[j], x, wg0);                                                                        \
-        pd0 = gl::mad_nc(beta0, sg, wg0);                                                                       \
-        pn1 = gl::mad_nc(kb[80 + j], x, wg1);                                                                   \
-        pd1 = gl::mad_nc(beta1, sg, wg1);                                                                       \
-      } else {                                                                                                  \
-        pn0 = gl::mul_nc(pn0, gl::mad_nc(kb[j], x, wg0));                                                       \
-        pd0 = gl::mul_nc(pd0, gl::mad_nc(beta0, sg, wg0));                                                      \
-        pn1 = gl::mul_nc(pn1, gl::mad_nc(kb[80 + j], x, wg1));                                                  \
-        pd1 = gl::mul_nc(pd1, gl::mad_nc(beta1, sg, wg1));                                                      \
-      }                                                                                                         \
-      if ((JJ) % 8 == 7) perm_chunk(j >> 3, pn0, pd0, pn1, pd1);                                                \
-    }                                                                                                           \
     if ((JJ) < 4 && base == 0) {                                                                                \
       if (h_const && (JJ) < 2) mc.at((JJ), gl::mul_nc(gl::sub_c((JJ) == 0 ? k0 : k1, w), f_const));            \
       if (h_pi) mc.at((JJ), gl::mul_nc(gl::sub_c(w, a.pi_hash[(JJ)]), f_pi));                                   \
@@ -862,14 +799,13 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     if (h_bsum) mc.at(0, gl::mul_nc(gl::sub_c(bs_sum, bs_w0), f_bsum));
     mg0 = mc.acc0();
     mg1 = mc.acc1();
-    perm_done = P25_Q_MERGE_PERM;
   } else {
     merged_mask = 0;
   }
-  if (!perm_done) {
-    // wires and sigmas read P25_Q_PF positions ahead (a ring of that many register pairs; the chunk length, 8, is a
+  {
+    // wires and sigmas read Q_PF positions ahead (a ring of that many register pairs; the chunk length, 8, is a
     // multiple of it, so the ring index is static in the unrolled loop)
-    constexpr int PF = P25_Q_PF;
+    constexpr int PF = Q_PF;
     u64 wq[PF], sq[PF];
 #pragma unroll
     for (int d = 0; d < PF; d++) {
@@ -929,9 +865,6 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
         asm volatile("" : "+s"(bg));
         cx.wires.big = bg;
       }
-#ifdef P25_PROFILE_GATE_MASK  // profiling builds only (tools/qmask.sh); never compiled into libp25.so
-      if (!((a.debug_gate_mask >> ge.kind) & 1u)) continue;
-#endif
       switch (ge.kind) {
         case G_CONSTANT: gate_constant(cx, k0, k1); break;
         case G_PUBLIC_INPUT: gate_public_input(cx, a.pi_hash); break;
@@ -975,13 +908,12 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
   }
   a.out[p] = gl::mul(res[0], zhi);
   a.out[big + p] = gl::mul(res[1], zhi);
-  }
 }
 
-__global__ __launch_bounds__(128, P25_Q_WAVES) void k_quotient(QuotientArgs a) {
+__global__ __launch_bounds__(128, Q_WAVES) void k_quotient(QuotientArgs a) {
   P25_WAVE_PRIO(P25_PRIO_BULK); quotient_body<false>(a); }
-__global__ __launch_bounds__(128, P25_QREC_WAVES) void k_quotient_rec(QuotientArgs a) {
-  P25_WAVE_PRIO(P25_QREC_PRIO); quotient_body<true>(a); }
+__global__ __launch_bounds__(128, QREC_WAVES) void k_quotient_rec(QuotientArgs a) {
+  P25_WAVE_PRIO(P25_PRIO_BULK); quotient_body<true>(a); }
 
 // out[p] = 1 / (n (x_p - 1)), x_p = g w_big^rev(p): the point-dependent factor of L_0(x) = Z_H(x) / (n (x - 1)).
 __global__ __launch_bounds__(256) void k_l0_inv(const u64* __restrict__ pow_big, uint32_t degree_bits,
@@ -998,17 +930,7 @@ void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bit
                      degree_bits + rate_bits, d_out);
 }
 
-void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
-  QuotientArgs a = a_in;
-#ifdef P25_PROFILE_GATE_MASK
-  // Per-gate instruction split for tools/qmask.sh: a separately built profiling library evaluates a subset
-  // of the gates (and so produces WRONG proofs).  The shipped library has no such switch.
-  static const uint32_t mask = [] {
-    const char* e = getenv("P25_Q_MASK");
-    return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
-  }();
-  a.debug_gate_mask = mask;
-#endif
+void launch_quotient(const QuotientArgs& a, hipStream_t st) {
   if (a.num_routed > (uint32_t)MAX_ROUTED) throw std::runtime_error("quotient: more than MAX_ROUTED routed wires");
   for (uint32_t gi = 0; gi < a.n_gates; gi++)  // the carry-free alpha fold holds 512 terms per gate
     if (gate_info((GateKind)a.gates[gi].kind).num_constraints > MAX_TERMS_PER_FOLD ||
@@ -1017,28 +939,11 @@ void launch_quotient(const QuotientArgs& a_in, hipStream_t st) {
   const size_t big = (size_t)1 << (a.degree_bits + a.rate_bits);
   bool rec = false;
   for (uint32_t gi = 0; gi < a.n_gates; gi++) rec |= a.gates[gi].kind >= G_ARITH_EXT;   // the recursion gate set
-  size_t lds_pad = 0;
-#ifdef P25_EXPERIMENT_KNOBS
-  // tools/knobs_build.sh only (never the shipped library): dynamic LDS the launch reserves and never touches, to hold the
-  // kernel to fewer workgroups per CU than its registers allow (round 5: does a capped quotient leave the hash kernels room?)
-  static const size_t pad = [] {
-    const char* e = getenv("P25_X_Q_LDS_PAD");
-    return e ? (size_t)strtoul(e, nullptr, 0) : 0;
-  }();
-  lds_pad = pad;
-#endif
-  unsigned grid = (unsigned)((big + 127) / 128);
-#if defined(P25_EXPERIMENT_KNOBS) && P25_Q_PERSIST
-  static const unsigned cap = [] {
-    const char* e = getenv("P25_X_Q_GRID");
-    return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
-  }();
-  if (cap && grid > cap) grid = cap;
-#endif
+  const unsigned grid = (unsigned)((big + 127) / 128);
   if (rec)
-    hipLaunchKernelGGL(k_quotient_rec, dim3(grid), dim3(128), lds_pad, st, a);
+    hipLaunchKernelGGL(k_quotient_rec, dim3(grid), dim3(128), 0, st, a);
   else
-    hipLaunchKernelGGL(k_quotient, dim3(grid), dim3(128), lds_pad, st, a);
+    hipLaunchKernelGGL(k_quotient, dim3(grid), dim3(128), 0, st, a);
 }
 
 }  // namespace p25

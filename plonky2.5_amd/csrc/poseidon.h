@@ -176,9 +176,6 @@ static_assert(MDS_CIRC[0] == 17 && MDS_CIRC[1] == 15 && MDS_CIRC[2] == 41 && MDS
                   MDS_CIRC[9] == 18 && MDS_CIRC[10] == 34 && MDS_CIRC[11] == 20 && MDS_DIAG0 == 8,
               "mds_rc hard-codes the MDS entries as inline constants");
 
-#ifndef P25_PARTIAL3
-#define P25_PARTIAL3 1
-#endif
 #include "poseidon_p3r.h"
 
 // x^7 of the round-0 constants of the capacity words: what the first S-box layer yields for them when the capacity
@@ -199,7 +196,6 @@ __device__ __forceinline__ void permute_dev(u64 s[WIDTH], u32 rows, bool cap0 = 
   rc_ptr rc = (rc_ptr)RC_SPLIT.v;
   asm("" : "+s"(rc));
   int r = 1;
-#if P25_PARTIAL3
   // full round 0: the capacity words' S-boxes are constants when the capacity is zero
 #pragma unroll
   for (int i = 0; i < RATE; i++) s[i] = sbox(s[i]);
@@ -227,19 +223,6 @@ __device__ __forceinline__ void permute_dev(u64 s[WIDTH], u32 rows, bool cap0 = 
   for (int b = 0; b < p3r::BLOCKS; b++) p3r::three_rounds<false>(s, tp, tp->kc[b]);
   p3r::two_rounds(s, tp);
   r = HALF_FULL + N_PARTIAL + 1;
-#else
-#pragma unroll
-  for (int i = RATE; i < WIDTH; i++) s[i] = add_rc(s[i], RC[i]);
-  for (int k = 0; k < HALF_FULL; k++, r++) {
-#pragma unroll
-    for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
-    mds_rc(s, rc + 2 * WIDTH * r);
-  }
-  for (int k = 0; k < N_PARTIAL; k++, r++) {
-    s[0] = sbox(s[0]);
-    mds_rc(s, rc + 2 * WIDTH * r);
-  }
-#endif
   for (int k = 0; k < HALF_FULL - 1; k++, r++) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = sbox(s[i]);
@@ -259,7 +242,7 @@ __device__ __forceinline__ void permute_dev(u64 s[WIDTH], u32 rows, bool cap0 = 
 // absorbing permutation is followed by 8 fresh inputs, so only its capacity words 8..11 matter, and the
 // last one only yields the 4 digest words: 8 of the 12 rows of the final MDS layer are never computed.
 GL_HD void permute_rows(u64 s[WIDTH], u32 rows, bool cap0 = false) {
-#if defined(__HIP_DEVICE_COMPILE__) && P25_ASM_MUL
+#if defined(__HIP_DEVICE_COMPILE__)
   permute_dev(s, rows, cap0);
 #else
   (void)rows;

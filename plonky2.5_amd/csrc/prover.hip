@@ -14,19 +14,17 @@ namespace p25 {
 // aggregation circuit's 17) cost the active one 9 % (120.7 against 131.8 aggregate proofs/s, round 4,
 // profiles/r04_stream_pool.txt), and more hardware queues cost more than they return.  Context i of a circuit takes
 // pool stream (first + i) mod P, `first` = where the pool's cursor stood when the circuit made its first context, so the
-// few contexts of the upper levels of an aggregation tree land on different streams; P = P25_STREAM_POOL (16), or the
+// few contexts of the upper levels of an aggregation tree land on different streams; P = STREAM_POOL (16), or the
 // largest proofs-in-flight count any circuit has asked for.  Two circuits proving at the same time interleave their
 // proofs on the shared streams (every ordering inside the library is by events, which stay correct -- conservatively
 // so -- when a stream carries another circuit's work too).  Pool streams live as long as the process.
-#ifndef P25_STREAM_POOL
-#define P25_STREAM_POOL 16
-#endif
+constexpr size_t STREAM_POOL = 16;
 namespace {
 struct StreamPool {
   std::mutex mu;
   std::map<int, std::vector<hipStream_t>> per_device;
   size_t cursor = 0;
-  size_t width = P25_STREAM_POOL;
+  size_t width = STREAM_POOL;
   // a block of `count` consecutive pool positions (the caller's contexts first .. first + count - 1)
   size_t reserve(size_t count, size_t want_width) {
     std::lock_guard<std::mutex> l(mu);
@@ -255,8 +253,7 @@ struct DeviceCircuit::Ctx {
   FriWork fri;
   DevMem proof, status;
   hipEvent_t ev[12];
-  hipStream_t st = nullptr;   // a stream of the process-wide pool (P25_STREAM_POOL != 0) or the context's own
-  bool own_stream = false;
+  hipStream_t st = nullptr;   // a stream of the process-wide pool (never destroyed)
   // done[b]: recorded after the context's latest read of witness-value buffer b (DeviceCircuit::vals_[b])
   hipEvent_t done[2] = {nullptr, nullptr};
   hipEvent_t join = nullptr;   // DeviceCircuit::stream_join
@@ -267,7 +264,6 @@ struct DeviceCircuit::Ctx {
     for (auto& e : done)
       if (e) (void)hipEventDestroy(e);
     if (join) (void)hipEventDestroy(join);
-    if (st && own_stream) (void)hipStreamDestroy(st);
   }
 };
 
@@ -279,11 +275,7 @@ DeviceCircuit::DeviceCircuit(Circuit c) : c_(std::move(c)) {
   if (c_.num_partial_products + 1 > MAX_CHUNKS || c_.cfg.num_routed_wires > MAX_ROUTED ||
       c_.cfg.num_challenges * (2 + c_.num_partial_products) >= ALPHA_POWS || c_.num_gate_constraints > ALPHA_POWS)
     throw std::invalid_argument("circuit exceeds the permutation-argument / quotient kernels' capacities");
-  if (P25_STREAM_POOL) {
-    stream_ = g_stream_pool.main_acquire(main_lease_);
-  } else {
-    P25_HIP(hipStreamCreate(&stream_));
-  }
+  stream_ = g_stream_pool.main_acquire(main_lease_);
   layout_ = make_proof_layout(c_);
   const size_t n = c_.degree();
   const int ncs = (int)c_.constants_sigmas.size();
@@ -420,7 +412,6 @@ DeviceCircuit::~DeviceCircuit() {
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
     }
-  if (main_lease_.slot < 0 && stream_) (void)hipStreamDestroy(stream_);   // a pooled main stream goes back with main_lease_
 }
 
 void DeviceCircuit::commitment_to_host(std::vector<u64>& coeffs, std::vector<u64>& lde, std::vector<u64>& tree) {
@@ -439,14 +430,9 @@ void DeviceCircuit::ensure_ctx(size_t count) {
   while (ctxs_.size() < count) {
   ctxs_.emplace_back(new Ctx());
   Ctx& x = *ctxs_.back();
-  if (P25_STREAM_POOL) {
-    if (ctxs_.size() == 1) pool_first_ = g_stream_pool.reserve(count, (size_t)streams_);
-    else g_stream_pool.widen((size_t)streams_);
-    x.st = g_stream_pool.at(pool_first_ + ctxs_.size() - 1);
-  } else {
-    P25_HIP(hipStreamCreate(&x.st));
-    x.own_stream = true;
-  }
+  if (ctxs_.size() == 1) pool_first_ = g_stream_pool.reserve(count, (size_t)streams_);
+  else g_stream_pool.widen((size_t)streams_);
+  x.st = g_stream_pool.at(pool_first_ + ctxs_.size() - 1);
   for (auto& e : x.done) P25_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const size_t n = c_.degree(), B = big();
   const int W = c_.cfg.num_wires, NC = c_.cfg.num_challenges, NP = c_.num_partial_products;

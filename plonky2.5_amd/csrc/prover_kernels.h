@@ -78,9 +78,6 @@ struct QuotientArgs {
   u64 zh[8], zh_inv[8];  // Z_H on the coset (index = i mod 2^rate_bits), and inverses
   const u64* l0_inv;     // [big] 1 / (n (x - 1)) at bit-reversed positions (per circuit)
   const u64* pi_hash;    // [4] public-inputs hash of this proof (PublicInputGate: wire_i - hash_i)
-#ifdef P25_PROFILE_GATE_MASK
-  uint32_t debug_gate_mask;  // profiling builds only (tools/qmask.sh)
-#endif
 };
 void launch_l0_inv(const u64* d_pow_big, uint32_t degree_bits, uint32_t rate_bits, u64* d_out, hipStream_t st);
 void launch_alpha_pows(const u64* d_chal, u64* d_alpha_pows, hipStream_t st);

@@ -40,3 +40,24 @@ def test_c_client_chains_two_circuits_on_the_device(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "C CHAIN OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_c_client_gathers_over_a_library_owned_rccl_communicator(tmp_path):
+    """tests/c_abi/gather.c: p25_comm_unique_id / p25_comm_init / p25_gather_proofs / p25_comm_barrier / p25_comm_max_f64 from
+    plain C -- the final aggregation step of north_star behind the C ABI (no torch in the process), a world of one rank on the
+    one GPU: three pipelined steps gathered on the communicator's stream behind p25_circuit_mark, bytes == the host path."""
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    libdir = os.path.join(ROOT, "plonky2.5_amd")
+    exe = str(tmp_path / "c_gather")
+    r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-D__HIP_PLATFORM_AMD__",
+                        "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "gather.c"),
+                        "-L" + libdir, "-lp25", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                        "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)     # the client checks that the library's own request is the one in force
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "C GATHER OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-# needs the profiling build: make -C plonky2.5_amd/csrc profile  (the shipped libp25.so has no gate mask)
+# needs the profiling build: tools/exp/build_gatemask.sh  (the shipped libp25.so has no gate mask)
 LIB=$PWD/tools/build/libp25_gatemask.so
 for M in 0xFFFFFFFF 0x0 $*; do
   rm -rf gpurun_out/_pmc
