@@ -37,8 +37,8 @@ N_SIMD, NOMINAL_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; the clock is measu
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="proofs per GPU per step")
     ap.add_argument("--log-n", type=int, default=6, help="log2 rows of the inner Fibonacci STARK (6 = the artifact)")
     ap.add_argument("--distinct", type=int, default=8, help="number of distinct plonky3 proofs cycled through the batch")
@@ -67,6 +67,11 @@ def parse_args():
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL over xGMI, one GPU per rank (the real thing); gloo = test mode: every rank on GPU 0, "
                          "collectives on host copies (exercises the multi-rank path on a one-GPU box)")
+    ap.add_argument("--dist-native", action="store_true",
+                    help="the gather of the finished proofs through the library's own communicator (p25_comm_init / "
+                         "p25_gather_proofs: librccl called from libp25 on a library-owned side stream, include/p25.h) instead of "
+                         "torch.distributed -- what a Rust host runs; torch.distributed stays the launcher's out-of-band channel "
+                         "(unique id, barriers, the timing reductions).  Needs --dist-backend nccl")
     return ap.parse_args()
 
 
@@ -341,7 +346,22 @@ def main():
     n_steps_all = args.warmup + args.steps
     d_proofs = [torch.zeros((max(B, 1), pw), dtype=torch.int64, device=dev)[:B] for _ in range(2)]
     d_status_all = torch.zeros((max(n_steps_all, 1), max(B, 1)), dtype=torch.int32, device=dev)[:, :B]
-    gatherer = pdist.ProofGatherer(n_step_total, pw, cdev, slots=2) if distributed else None   # buffers allocated once
+    native = distributed and args.dist_native
+    if args.dist_native and args.dist_backend != "nccl":
+        fail("--dist-native is the RCCL path: it needs --dist-backend nccl")
+    gatherer = pdist.ProofGatherer(n_step_total, pw, cdev, slots=2) if (distributed and not native) else None   # buffers allocated once
+    comm, n_all, n_st, counts = None, None, None, None
+    if native:
+        # the launcher's out-of-band channel hands rank 0's unique id to every rank; everything on the data path is the library's
+        uid = torch.zeros(128, dtype=torch.uint8, device=cdev)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(p25.comm_unique_id()), dtype=torch.uint8).to(cdev)
+        dist.broadcast(uid, src=0)
+        comm = p25.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        counts = pdist.shard_sizes(n_step_total, world) if args.total else [B] * world
+        if rank == 0:      # receive buffers, one per pipelined slot, allocated once
+            n_all = [torch.zeros((n_step_total, pw), dtype=torch.int64, device=dev) for _ in range(2)]
+            n_st = [torch.full((n_step_total,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
     # device memory: the library adapts the number of proofs in flight to what is free, which would silently change the
     # schedule being measured -- refuse instead (one JSON error line, all ranks exit 2)
     nW, NCh, NPp = int(info.num_wires), int(info.num_challenges), int(info.num_partial_products)
@@ -371,7 +391,9 @@ def main():
     # hardware queue, the library's pool (16) + one main stream per circuit + torch's + RCCL's come close to the 24 there
     # are, and streams sharing a queue run in order (profiles/r04_stream_pool.txt: the distributed branch lost 2.5 % of
     # the pipelined tree with two).  Gather k-1 is issued after step k, so at step k the stream holds gather k-2 at most.
-    side = [torch.cuda.Stream(device=dev)] * 2 if distributed else None
+    side = [torch.cuda.Stream(device=dev)] * 2 if (distributed and not native) else None
+    if native:      # the communicator's own stream, seen through torch only to time the gathers with events
+        side = [torch.cuda.ExternalStream(comm.stream, device=dev)] * 2
     g_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps_all)] if nccl else None
     torch.cuda.synchronize()  # inputs are resident in HBM before anything is timed
 
@@ -393,6 +415,17 @@ def main():
         """The final aggregation step of batch k: finished proofs gathered onto rank 0 (RCCL over xGMI) on a side stream
         that waits -- on the device -- for the mark taken when step k had been enqueued."""
         buf = k & 1
+        if native:     # p25_gather_proofs: waits for the mark on the device, grouped ncclSend / ncclRecv, all on the library's stream
+            circuit.stream_wait_mark(GATHER_MARK + buf, comm.stream)    # (also inside the call; here so that the events time the gather alone)
+            g_ev[k][0].record(side[buf])
+            comm.gather(circuit, GATHER_MARK + buf, d_proofs[buf].data_ptr(), pw, d_status_all[k].data_ptr(), counts, 0,
+                        n_all[buf].data_ptr() if rank == 0 else None, n_st[buf].data_ptr() if rank == 0 else None)
+            g_ev[k][1].record(side[buf])
+            if rank == 0:
+                offs = [sum(counts[:q]) for q in range(world + 1)]
+                gathered[0] = [n_all[buf][offs[q]:offs[q + 1]] for q in range(world)]
+                gathered[1] = [n_st[buf][offs[q]:offs[q + 1]] for q in range(world)]
+            return
         with torch.cuda.stream(side[buf]):
             circuit.stream_wait_mark(GATHER_MARK + buf, side[buf].cuda_stream)
             if nccl:
@@ -432,6 +465,8 @@ def main():
         while pending:
             gather_on_host(*pending.pop(0))
         circuit.sync()
+        if native:
+            comm.sync()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -702,14 +737,19 @@ def main():
                                    + ("sharded over the GPUs " if args.total else "per GPU ") +
                                    f"(n = 2^{int(info.degree_bits)} rows x 135 wires, LDE 2^{int(info.degree_bits) + 3}), "
                                    f"{world} GPU(s), replicas + RCCL gather"
+                                   + (" (p25_gather_proofs: librccl behind the C ABI)" if native else "")
                                    + ("" if args.dist_backend == "nccl" else " [TEST MODE: all ranks on GPU 0, gloo]"),
                        "proofs_per_gpu_per_step": B, "proofs_per_step_total": n_step_total,
                        "all_statuses_ok": ok, "gathered_complete_and_ok": gathered_ok,
                        "oracle_verifier_accepts": not ver_fail, "oracle_verified_indices": ver_idx,
-                       "circuit_build_s": round(build_s, 2), "head": head,
+                       "circuit_build_s": round(build_s, 2), "head": head, "runtime": p25.runtime_info().as_dict(),
                        "single_proof_latency_ms": round(tmd["total_ms"], 3),
                        "phase_ms_single_proof": {k: round(v, 3) for k, v in tmd.items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_hash_leaves_wide (Poseidon sponge, 2^19 leaves x 135 words)",
+            "roofline": {"bound": "valu",
+                         "view": "achieved / peak / frac are the HBM view the contract prescribes (algorithmic bytes of the dominant "
+                                 "kernel per launch / its launch duration against 8 TB/s); the roof that BINDS is integer-VALU issue: "
+                                 "`valu` below (wave-instructions per second against 1 per SIMD per 4 cycles)",
+                         "kernel": "k_hash_leaves_wide (Poseidon sponge, 2^19 leaves x 135 words)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "avg_launch_ms": ms_alone, "launches": int(k_launches_alone), "algorithmic_bytes": algo_bytes,
@@ -873,6 +913,8 @@ def main():
         out["rank0_post_region_s"] = round(time.perf_counter() - t_region_end, 2)
         out["collective_timeout_s"] = COLLECTIVE_TIMEOUT_S
         print(json.dumps(out), flush=True)
+    if native:
+        comm.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

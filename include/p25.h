@@ -338,6 +338,9 @@ p25_status p25_prove_batch_dev(p25_circuit* c, const uint64_t* d_inputs, size_t 
  * child's identifier = its own public inputs if it has any, hash_no_pad(its wires cap) otherwise); levels repeat until one
  * proof is left; with N ranks every rank folds its own shard this way and one N-to-1 aggregate over the shard roots (rank
  * order) is the final proof.  Children in an overlap are verified twice and appear twice under the root. */
+/* Every window holds num_inputs words (p25_circuit_info_t): d_buffer must be readable up to last_window_offset_words +
+ * num_inputs; a stride below num_inputs makes consecutive windows overlap, which is legal.  window_stride_words >= 1 and
+ * n_proofs * window_stride_words < 2^60, P25_ERR_INVALID_ARG otherwise. */
 p25_status p25_prove_batch_dev_windows(p25_circuit* c, const uint64_t* d_buffer, size_t window_stride_words,
                                        size_t last_window_offset_words, size_t n_proofs, const uint64_t* d_seeds,
                                        uint64_t* d_proofs, size_t proof_stride_words, uint32_t* d_status);

@@ -80,21 +80,34 @@ def group_bounds(n, k):
     return [(k * i, k * (i + 1)) for i in range(groups - 1)] + [(n - k, n)]
 
 
-def fold(circuit, leaves, arity=8, warm=True, in_flight=16):
+def fold(circuit, leaves, arity=8, warm=True, in_flight=16, streams=None, circuits=None):
     """Folds `leaves` (flat proofs of `circuit`, any number of them: `level_plan`) into one root proof.  Returns a dict with the
     root proof, the circuit it belongs to (`top`; the caller closes `owned` when done), per-level records and the time
-    spent proving (`tree_s`) and building circuits (`build_s`, once per shape).  One leaf: the leaf is the root."""
+    spent proving (`tree_s`) and building circuits (`build_s`, once per shape).  One leaf: the leaf is the root.
+    `streams`: proofs every level circuit keeps in flight (None = the library's 16; fewer when several processes share one GPU's
+    memory).  `circuits`: the level circuits of an earlier fold of the SAME shape (its `owned`), reused instead of rebuilt --
+    the shards of one batch all fold through the same circuits; they stay the earlier fold's to close."""
     n = len(leaves)
     if n < 1:
         raise ValueError("fold needs at least one leaf")
     level, circ, levels, owned, tree_s, build_s = list(leaves), circuit, [], [], 0.0, 0.0
-    for k in level_plan(n, arity):
+    plan = level_plan(n, arity)
+    if circuits is not None and len(circuits) != len(plan):
+        raise ValueError("fold: `circuits` does not have one circuit per level of this shape")
+    for li, k in enumerate(plan):
         t = time.perf_counter()
-        nxt = circ.build_aggregator(k)
-        nxt.digest()
+        if circuits is not None:
+            nxt = circuits[li]
+            if int(nxt.info.num_inputs) != k * int(circ.info.proof_words):
+                raise ValueError(f"fold: circuit {li} of `circuits` does not aggregate {k} proofs of the level below")
+        else:
+            nxt = circ.build_aggregator(k)
+            nxt.digest()
+            if streams:
+                nxt.set_streams(max(1, int(streams)))
+            owned.append(nxt)
         bs = time.perf_counter() - t
         build_s += bs
-        owned.append(nxt)
         n_children = len(level)
         groups = np.stack([np.concatenate(level[a:b]) for a, b in group_bounds(n_children, k)])
         if warm:   # this circuit's contexts and tables: once per shape, like the build

@@ -707,7 +707,9 @@ p25_status p25_prove_batch_dev_windows(p25_circuit* c, const uint64_t* d_buffer,
   return guarded([&]() -> p25_status {
     if (!c || !d_buffer || !d_seeds || !d_proofs || !d_status) throw std::invalid_argument("null argument");
     if (window_stride_words == 0) throw std::invalid_argument("window stride is zero");
-    if (n_proofs > ((size_t)1 << 32) || window_stride_words > ((size_t)1 << 40)) throw std::invalid_argument("windows out of range");
+    // every offset the witness pass forms, (first proof + p) * stride, stays below 2^60 words: no size_t product can wrap
+    if (n_proofs > ((size_t)1 << 32) || window_stride_words > ((size_t)1 << 60) / (n_proofs ? n_proofs : 1))
+      throw std::invalid_argument("windows out of range (n_proofs * window_stride_words must stay below 2^60)");
     if (n_proofs && last_window_offset_words > (n_proofs - 1) * window_stride_words)
       throw std::invalid_argument("last window lies beyond the windows before it");
     P25_LOCK(c);

@@ -19,6 +19,7 @@
 // of a butterfly and the explicit s_nop between dependent steps.  (A timing-only build without them bounds their cost at
 // <= 0.3 % of the pipeline: profiles/r05_v_hazard_nops_bound.txt.)
 #pragma once
+#include <cassert>
 #include "gl.h"
 
 namespace gl {
@@ -44,6 +45,19 @@ GL_HD u64 sub_nc_c(u64 a, u64 b) {
     if (d < EPS) t -= EPS;
     d = t;
   }
+  return d;
+}
+// The single-correction forms: the SECOND operand is at most p (a canonical value, or p itself).
+// a + b with a carry: s = a + b - 2^64 <= p - 1, so s + EPS <= 2^64 - 1 cannot wrap.
+GL_HD u64 add_c_c(u64 a, u64 b) {
+  u64 s = a + b;
+  if (s < a) s += EPS;
+  return s;
+}
+// a - b with a borrow: a < b <= p, d = a - b + 2^64 >= 2^64 - p = EPS, so d - EPS cannot borrow.
+GL_HD u64 sub_c_c(u64 a, u64 b) {
+  u64 d = a - b;
+  if (a < b) d -= EPS;
   return d;
 }
 // x * 2^e, 0 <= e < 96 (2^96 = -1 mod p: larger exponents are a sign, absorbed by the caller)
@@ -243,19 +257,24 @@ GL_HD u64 sub_nc(u64 a, u64 b) {
 #endif
 }
 // any + (b <= p), any - (b <= p): one correction.  The caller guarantees the bound on b (a value read from a committed
-// matrix, a challenge, a compile-time constant below p).
+// matrix, a challenge, a compile-time constant below p).  The host forms are the SAME single-correction definitions and assert
+// the bound, so the CPU and sanitizer builds exercise the contract the gfx950 sequences rely on (a caller that broke it would
+// otherwise go wrong on the device only); tools/exp/lazy_contract_check.patch adds the same checks -- and the wave-uniformity
+// of mad_nc_s's second factor -- to the device paths for a debug run of the GPU suite.
 GL_HD u64 add_c(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return add_c_asm(a, b);
 #else
-  return add_nc_c(a, b);
+  assert(b <= P && "gl::add_c: second operand above p");
+  return add_c_c(a, b);
 #endif
 }
 GL_HD u64 sub_c(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return sub_c_asm(a, b);
 #else
-  return sub_nc_c(a, b);
+  assert(b <= P && "gl::sub_c: second operand above p");
+  return sub_c_c(a, b);
 #endif
 }
 // a - k (mod 2^64, NOT mod p) for a canonical a and a small k: a factor of a vanishing product a (a - 1) ... (a - m), m >= k.

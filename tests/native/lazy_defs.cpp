@@ -18,6 +18,10 @@ static void pair(u64 a, u64 b) {
   const u64 ca = a % P, cb = b % P;
   CHECK(gl::add_nc_c(a, b) % P == md((u128)ca + cb), "add_nc %016llx %016llx", (unsigned long long)a, (unsigned long long)b);
   CHECK(gl::sub_nc_c(a, b) % P == md((u128)ca + P - cb), "sub_nc %016llx %016llx", (unsigned long long)a, (unsigned long long)b);
+  if (b <= P) {   // the single-correction forms: second operand at most p (the contract of gl::add_c / gl::sub_c)
+    CHECK(gl::add_c_c(a, b) % P == md((u128)ca + cb) && gl::add_c(a, b) == gl::add_c_c(a, b), "add_c %016llx %016llx", (unsigned long long)a, (unsigned long long)b);
+    CHECK(gl::sub_c_c(a, b) % P == md((u128)ca + P - cb) && gl::sub_c(a, b) == gl::sub_c_c(a, b), "sub_c %016llx %016llx", (unsigned long long)a, (unsigned long long)b);
+  }
   CHECK(gl::mad_nc_s(a, b, a ^ b) % P == md((u128)ca * cb + ((a ^ b) % P)), "mad_nc_s %016llx %016llx", (unsigned long long)a, (unsigned long long)b);
   u64 s, d;
   gl::bfly_nc(a, b, false, s, d);

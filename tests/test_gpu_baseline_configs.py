@@ -87,3 +87,31 @@ def test_config4_sharding_real_prover_two_ranks():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "DIST_REAL_OK 7" in out.stdout
+
+
+def test_config4_batch_2048_in_eight_shards_on_one_gpu(tmp_path):
+    """BASELINE config 4's workload -- 2048 fib-64 verifier proofs sharded 8 x 256 -- through the HIP path on the one GPU
+    there is (tests/_config4_worker.py): eight gloo ranks, each proving ITS 256 proofs of the global batch and folding them to
+    its shard root (256 -> 20 -> 2 -> 1) in a GPU child process, four shard processes on the card at a time (the box admits
+    six); all 2048 proofs + statuses gathered onto rank 0 (bench.py's ProofGatherer at world size 8), every status checked,
+    the 16 proofs either side of the seven shard boundaries and at the two ends byte-compared with the oracle's, and the
+    8-to-1 cross-rank aggregate proved over EIGHT DISTINCT shard roots: its public inputs are the commitment to all 2048
+    leaves in global order and the oracle's verifier accepts it.  Path sharded: `prove(&self, ..)` borrows the circuit
+    immutably, /root/reference/src/p3/mod.rs:260.  The JSON record goes to gpurun_out/ (committed under profiles/)."""
+    import json
+    import shutil
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out_dir = str(tmp_path)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "_config4_worker.py"), "ranks", "2048", out_dir, "--wave", "4", "--streams", "8"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1700)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-4000:])
+    assert "CONFIG4_ONE_GPU_OK 2048" in out.stdout
+    rec = json.load(open(os.path.join(out_dir, "config4_one_gpu.json")))
+    assert rec["total_proofs"] == 2048 and rec["ranks"] == 8 and len(rec["byte_equal_to_oracle_indices"]) == 16
+    assert [s["proofs"] for s in rec["shards"]] == [256] * 8 and all(s["levels"] == [[13, 20], [10, 2], [2, 1]] for s in rec["shards"])
+    assert rec["cross_rank_aggregate"]["arity"] == 8
+    dst = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(dst) and os.access(dst, os.W_OK):
+        shutil.copy(os.path.join(out_dir, "config4_one_gpu.json"), os.path.join(dst, "config4_one_gpu.json"))

@@ -370,40 +370,53 @@ def test_device_tree_a_failed_leaf_fails_its_branch_only(gpu):
 
 
 def test_cross_rank_aggregate_at_the_shapes_of_2_4_and_8_gpus(gpu, oracle, fib_circuit, fib_inputs):
-    """BASELINE config 4's final aggregation at N = 2, 4, 8 on the one GPU there is: 64 fib-64 leaves fold to a shard root
-    (13 at a time: 64 -> 5 -> 1, bench.py's default), then rank 0's step -- `fold_roots(top, N shard roots)`, the N-to-1
-    aggregate over proofs of the shard trees' top circuit -- is built and proved for N = 2, 4, 8 (identical shard roots:
-    the circuit, its witness generation and its proof are the ones an N-GPU run needs; only the public-input values
-    differ).  The oracle's verifier accepts each root and its public inputs are the commitment to N x 64 leaves in
-    global order (`expected_commitment(..., n_shards=N)`)."""
+    """BASELINE config 4's final aggregation at N = 2, 4, 8 on the one GPU there is, over N DISTINCT shard roots: eight
+    different shards of 64 fib-64 leaves (other plonky3 proofs in another rotation, other filler seeds: every leaf of the 512
+    is a different proof) each fold to their own shard root (13 at a time: 64 -> 5 -> 1, bench.py's default; the shards share
+    the level circuits, as the ranks of one job build the same ones), then rank 0's step -- `fold_roots(top, roots[:N])`, the
+    N-to-1 aggregate over proofs of the shard trees' top circuit -- is built and proved for N = 2, 4, 8.  The oracle's
+    verifier accepts each root and its public inputs are the commitment to the N x 64 leaves in global order
+    (`expected_commitment(..., n_shards=N)`); swapping two shard roots changes the commitment."""
     from plonky25_amd import aggregate as ag
-    n_leaves, arity = 64, 13
-    variants = [fib_inputs] + [gpu.p3_prove_fibonacci(6, 100, 16, pow_start=v << 24)[0] for v in (1, 2)]
-    batch = np.stack([variants[i % 3] for i in range(n_leaves)])
-    leaves, st = fib_circuit.prove(batch, seeds=np.arange(n_leaves, dtype=np.uint64) + np.uint64(500))
-    assert (st == 0).all()
-    f = ag.fold(fib_circuit, [leaves[i] for i in range(n_leaves)], arity=arity, warm=False)
-    assert [l["arity"] for l in f["levels"]] == [13, 5] and [l["proofs"] for l in f["levels"]] == [5, 1]
-    caps = [leaves[i][:ag.CAP_WORDS] for i in range(n_leaves)]
-    assert [int(v) for v in f["top"].public_inputs(f["root"])] == ag.expected_commitment(caps, arity, oracle.hash_no_pad)
+    n_leaves, arity, n_shards = 64, 13, 8
+    variants = [fib_inputs] + [gpu.p3_prove_fibonacci(6, 100, 16, pow_start=v << 24)[0] for v in (1, 2, 3, 4)]
+    folds, caps, level_circs = [], [], None
+    for q in range(n_shards):
+        batch = np.stack([variants[(q * n_leaves + i) % 5] for i in range(n_leaves)])
+        leaves, st = fib_circuit.prove(batch, seeds=np.arange(n_leaves, dtype=np.uint64) + np.uint64(500 + 1000 * q))
+        assert (st == 0).all()
+        f = ag.fold(fib_circuit, [leaves[i] for i in range(n_leaves)], arity=arity, warm=False, circuits=level_circs)
+        if level_circs is None:
+            level_circs = f["owned"]
+            assert [l["arity"] for l in f["levels"]] == [13, 5] and [l["proofs"] for l in f["levels"]] == [5, 1]
+        shard_caps = [leaves[i][:ag.CAP_WORDS] for i in range(n_leaves)]
+        assert [int(v) for v in f["top"].public_inputs(f["root"])] == ag.expected_commitment(shard_caps, arity, oracle.hash_no_pad)
+        folds.append(f)
+        caps.extend(shard_caps)
+    top, roots = folds[0]["top"], [f["root"] for f in folds]
+    assert len({r.tobytes() for r in roots}) == n_shards and len({c.tobytes() for c in caps}) == n_shards * n_leaves
     shapes = {}
     for n in (2, 4, 8):
-        fin = ag.fold_roots(f["top"], [f["root"]] * n, warm=False)
+        fin = ag.fold_roots(top, roots[:n], warm=False)
         rec = fin["levels"][0]
         assert rec["level"] == "cross-rank" and rec["arity"] == n and rec["proofs"] == 1
         shapes[n] = (rec["rows_used"], rec["circuit_rows_log2"], rec["ms_per_proof"])
         got = [int(v) for v in fin["top"].public_inputs(fin["root"])]
-        assert got == ag.expected_commitment(caps * n, arity, oracle.hash_no_pad, n_shards=n), n
+        assert got == ag.expected_commitment(caps[:n * n_leaves], arity, oracle.hash_no_pad, n_shards=n), n
         oc = oracle.load_circuit(fin["top"].to_blob())
         dg, cap = fin["top"].digest()
         code, msg = oc.verify(fin["root"], dg, cap)
         assert code == 0, (n, msg)
+        # rank order matters: the same roots with two shards swapped commit to another batch
+        swapped = [roots[1], roots[0]] + roots[2:n]
+        out, st = fin["top"].prove(np.concatenate(swapped)[None, :], seeds=[0])
+        assert st.tolist() == [0] and [int(v) for v in fin["top"].public_inputs(out[0])] != got
         # a shard root that is not a valid proof has no cross-rank aggregate
-        bad = np.concatenate([f["root"]] * n)
+        bad = np.concatenate(roots[:n])
         bad[100] = (int(bad[100]) + 1) % P
         assert fin["top"].prove(bad[None, :], seeds=[0])[1].tolist() != [0]
         for c in fin["owned"]:
             c.close()
     print("cross-rank aggregation circuits (rows used, log2 rows, ms per proof, cold):", shapes)
-    for c in f["owned"]:
+    for c in level_circs:
         c.close()
