@@ -55,17 +55,17 @@ void intt(std::vector<u64>& a) {
   u64 ni = gl::inv((u64)a.size());
   for (auto& x : a) x = gl::mul(x, ni);
 }
-// values of the polynomial with coefficients c (len n) on shift*<w_{2n}>, natural order
-std::vector<u64> lde2(const std::vector<u64>& c, u64 shift) {
+// values of the polynomial with coefficients c (len n) on shift*<w_{n 2^log_blowup}>, natural order
+std::vector<u64> lde(const std::vector<u64>& c, u64 shift, int log_blowup) {
   const size_t n = c.size();
-  std::vector<u64> v(2 * n, 0);
+  std::vector<u64> v(n << log_blowup, 0);
   u64 p = 1;
   for (size_t k = 0; k < n; k++) {
     v[k] = gl::mul(c[k], p);
     p = gl::mul(p, shift);
   }
   unsigned lg = 0;
-  while (((size_t)1 << lg) < 2 * n) lg++;
+  while (((size_t)1 << lg) < v.size()) lg++;
   ntt(v, gl::root_of_unity(lg));
   return v;
 }
@@ -188,11 +188,14 @@ std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg) {
 
 std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vector<u64>>& col, const P3ProveParams& prm,
                               P3Config& cfg) {
-  if (prm.log_n < 1 || prm.log_n > 22 || prm.log_blowup != 1 || prm.num_queries < 1 || prm.pow_bits < 0 || prm.pow_bits > 30)
+  // FriConfig.log_blowup (src/p3/mod.rs:242-246; verifier.rs uses config.log_blowup generically): the LDE domain is
+  // 7*H_{n 2^B}; B = 1 is the reference's artifact, B = 2, 3 hold AIRs of constraint degree up to 5 / 9 (four / eight chunks)
+  if (prm.log_n < 1 || prm.log_n > 22 || prm.log_blowup < 1 || prm.log_blowup > 3 || prm.log_n + prm.log_blowup > 24 ||
+      prm.num_queries < 1 || prm.pow_bits < 0 || prm.pow_bits > 30)
     throw std::invalid_argument("p3_prove: unsupported parameters");
   air.validate();
-  const int k = prm.log_n, L = k + 1, T = prm.threads;
-  const size_t n = (size_t)1 << k, N2 = 2 * n;
+  const int k = prm.log_n, B = prm.log_blowup, L = k + B, T = prm.threads;
+  const size_t n = (size_t)1 << k, N2 = n << B;      // N2: the LDE domain's size (2 n for the reference's log_blowup 1)
   const u64 w_n = gl::root_of_unity(k), w_2n = gl::root_of_unity(L);
   const int W = air.width;
   if ((int)col.size() != W) throw std::invalid_argument("p3_prove: trace width does not match the AIR");
@@ -205,7 +208,7 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
   for (auto& c : coef) intt(c);
   // LDE on 7*H_{2n}: natural order, then the committed matrix in bit-reversed row order
   std::vector<std::vector<u64>> lde_nat(W);
-  for (int c = 0; c < W; c++) lde_nat[c] = lde2(coef[c], gl::GENERATOR);
+  for (int c = 0; c < W; c++) lde_nat[c] = lde(coef[c], gl::GENERATOR, B);
   std::vector<u64> trace_rows(N2 * W);
   for (size_t i = 0; i < N2; i++) {
     size_t r = gl::bitrev((u32)i, L);
@@ -219,13 +222,14 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
 
   // Quotient chunks: 2^lqd of them, lqd = log2_ceil(max constraint degree - 1) with the selector's degree counted (uni-stark's
   // get_log_quotient_degree).  Degree <= 2 (every AIR the reference can verify: serde/proof.rs:41-48 holds one chunk): lqd = 0;
-  // degree 3: lqd = 1.  The quotient domain is the disjoint coset 7*H_{n 2^lqd} (verifier.rs:120-124): points
-  // x_j = 7 w^j = LDE natural index j * (2 >> lqd), so with log_blowup = 1 the trace's LDE already holds the trace there.
-  int max_deg = 1;
-  for (const auto& c : air.constraints) max_deg = std::max(max_deg, air.node_degree(c.node) + (c.when == AirProgram::ALWAYS ? 0 : 1));
-  const int lqd = max_deg <= 2 ? 0 : 1;
+  // degree 3: lqd = 1; degree 4, 5: lqd = 2 (needs log_blowup >= 2).  The quotient domain is the disjoint coset 7*H_{n 2^lqd}
+  // (verifier.rs:120-124): points x_j = 7 w^j = LDE natural index j * 2^(B - lqd), so the trace's LDE already holds the trace
+  // there as long as lqd <= log_blowup.
+  const int lqd = air.log_quotient_degree();
+  if (lqd > B) throw std::invalid_argument("p3_prove: the AIR's constraint degree needs more quotient chunks than log_blowup holds");
   const size_t Q = (size_t)1 << lqd, nq = n << lqd;          // chunks, quotient-domain size
-  const size_t lde_step = 2 >> lqd;                            // LDE index step between quotient-domain points
+  const size_t lde_step = (size_t)1 << (B - lqd);              // LDE index step between quotient-domain points
+  const size_t row_step = (size_t)1 << B;                      // ... and between a row and the next (x w_n)
   std::vector<u64> q0(nq), q1(nq);
   {
     const u64 g_inv = gl::inv(w_n);
@@ -241,7 +245,7 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
     BaseOps ops;
     std::vector<u64> loc(W), nxt(W);
     for (size_t j = 0; j < nq; j++, x = gl::mul(x, w_q)) {
-      const size_t i0 = lde_step * j, i1 = (lde_step * j + 2) % N2;   // the next ROW is x w_n = two LDE points on
+      const size_t i0 = lde_step * j, i1 = (lde_step * j + row_step) % N2;   // the next ROW is x w_n = 2^B LDE points on
       for (int c = 0; c < W; c++) {
         loc[c] = lde_nat[c][i0];
         nxt[c] = lde_nat[c][i1];
@@ -276,7 +280,7 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
         const std::vector<u64>& src = comp ? q1 : q0;
         for (size_t j = 0; j < n; j++) v[j] = src[j * Q + c];
         intt(v);
-        std::vector<u64> l = lde2(v, gl::mul(gl::GENERATOR, gl::inv(s_c[c])));
+        std::vector<u64> l = lde(v, gl::mul(gl::GENERATOR, gl::inv(s_c[c])), B);
         for (size_t i = 0; i < N2; i++) quot_rows[i * 2 * Q + 2 * c + comp] = l[gl::bitrev((u32)i, L)];
         qcoef[2 * c + comp] = std::move(v);
       }
@@ -380,7 +384,9 @@ std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vect
       m >>= 1;
       lm--;
     }
-    if (folded.size() != 2 || !gl::eq(folded[0], folded[1])) throw std::logic_error("p3 prover: FRI did not fold to a constant");
+    bool constant = folded.size() == ((size_t)1 << B);     // k folds leave 2^B values of a constant polynomial
+    for (size_t i = 1; constant && i < folded.size(); i++) constant = gl::eq(folded[0], folded[i]);
+    if (!constant) throw std::logic_error("p3 prover: FRI did not fold to a constant");
   }
   const E2 final_poly = folded[0];
   // proof of work (challenger.rs:159-168): observe the witness, sample_bits(pow_bits) must be 0

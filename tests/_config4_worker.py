@@ -4,8 +4,11 @@ once more (tests/test_gpu_baseline_configs.py::test_config4_batch_2048_in_eight_
 
 A GPU box admits at most 6 processes on its card, so the 8 ranks cannot all hold the GPU.  The job is therefore:
 
-  python -m torch.distributed.run --nproc-per-node 8 tests/_config4_worker.py ranks TOTAL OUTDIR [--wave 4] [--streams 8]
-      eight gloo ranks that never touch the GPU themselves.  Rank r runs ITS shard's GPU work -- p25_prove_batch over proofs
+  RANK=r WORLD_SIZE=8 MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/_config4_worker.py ranks TOTAL OUTDIR [--wave 4] [--streams 8]
+      (once per rank; the test starts the eight itself -- `python -m torch.distributed.run` opens the GPU in the launcher)
+      eight gloo ranks that never touch the GPU themselves (measured on the box, tools/probe/: importing torch, gloo init,
+      all_reduce, all_gather_object and the gatherer leave /dev/kfd closed; `dist.barrier()` opens it -- torch picks a device for
+      it -- so the ranks synchronise with an all_reduce instead).  Rank r runs ITS shard's GPU work -- p25_prove_batch over proofs
       [256 r, 256 r + 256) of the global batch, then the shard's aggregation tree 256 -> 20 -> 2 -> 1 -- in a CHILD process
       (`shard` mode below), `--wave` ranks at a time (barrier between the waves: 4 children + the test's own process on the
       card at once); then the collective path of bench.py at world size 8: `ProofGatherer` over all 2048 proofs + statuses,
@@ -198,7 +201,7 @@ def main_ranks(total, outdir):
         with open(os.path.join(outdir, "config4_one_gpu.json"), "w") as f:
             json.dump(out, f, indent=1)
         print("CONFIG4_ONE_GPU_OK", total, flush=True)
-    dist.barrier()
+    agree(True)       # NOT dist.barrier(): that opens the GPU in every rank (nine processes on the card: the box kills the run)
     dist.destroy_process_group()
 
 

@@ -100,14 +100,30 @@ def test_config4_batch_2048_in_eight_shards_on_one_gpu(tmp_path):
     immutably, /root/reference/src/p3/mod.rs:260.  The JSON record goes to gpurun_out/ (committed under profiles/)."""
     import json
     import shutil
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out_dir = str(tmp_path)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "_config4_worker.py"), "ranks", "2048", out_dir, "--wave", "4", "--streams", "8"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1700)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-4000:])
-    assert "CONFIG4_ONE_GPU_OK 2048" in out.stdout
+    import time
+    out_dir, port, world = str(tmp_path), str(free_port()), 8
+    ranks = []
+    for r in range(world):      # the ranks started directly: torch.distributed.run would be one more process holding the GPU
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        log = open(os.path.join(out_dir, f"rank_{r}.log"), "w")
+        ranks.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_config4_worker.py"), "ranks", "2048", out_dir,
+                                        "--wave", "4", "--streams", "8"], env=env, stdout=log, stderr=subprocess.STDOUT), log))
+    deadline = time.time() + 1700
+    while time.time() < deadline:      # a rank that fails leaves the others in a collective: end them instead of waiting them out
+        codes = [p.poll() for p, _ in ranks]
+        if all(c is not None for c in codes) or any(c not in (None, 0) for c in codes):
+            break
+        time.sleep(0.5)
+    for p, log in ranks:
+        if p.poll() is None:
+            p.kill()
+        p.wait()
+        log.close()
+    codes = [p.returncode for p, _ in ranks]
+    logs = [open(os.path.join(out_dir, f"rank_{r}.log")).read() for r in range(world)]
+    assert codes == [0] * world, (codes, logs[0][-3000:], logs[next((i for i, c in enumerate(codes) if c), 0)][-2000:])
+    assert "CONFIG4_ONE_GPU_OK 2048" in logs[0]
     rec = json.load(open(os.path.join(out_dir, "config4_one_gpu.json")))
     assert rec["total_proofs"] == 2048 and rec["ranks"] == 8 and len(rec["byte_equal_to_oracle_indices"]) == 16
     assert [s["proofs"] for s in rec["shards"]] == [256] * 8 and all(s["levels"] == [[13, 20], [10, 2], [2, 1]] for s in rec["shards"])

@@ -143,3 +143,25 @@ def test_poseidon_gate_wires_same_in_fast_and_naive_form(oracle):
         out_f, pin = oracle.poseidon_fast_partial_inputs(st)
         assert (out_n == out_f).all() and (out_n == oracle.poseidon_permute(st)[0]).all()
         assert (tr[36:58] == pin).all()
+
+
+def test_avx512_code_stays_in_the_x8_functions():
+    """oracle/ref_quotient_x8.cpp is compiled for AVX-512 as a whole and includes the shared oracle headers; an inline or
+    template helper it instantiated must never be the copy the scalar checker runs (SIGILL on a host without AVX-512, with the
+    tuned leg off).  Every function of libp25_oracle.so that touches a zmm register must be one of the eight-lane ones."""
+    import re
+    import shutil
+    import subprocess
+    objdump = shutil.which("objdump")
+    if not objdump:
+        pytest.skip("objdump not available")
+    lib = os.path.join(ROOT, "oracle", "libp25_oracle.so")
+    out = subprocess.run([objdump, "-d", "--no-show-raw-insn", "-C", lib], capture_output=True, text=True, timeout=600).stdout
+    fn, offenders = None, set()
+    for line in out.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            fn = m.group(1)
+        elif "zmm" in line and fn is not None and not re.search(r"FB8|_x8|^v_(poseidon|mds)\b", fn):
+            offenders.add(fn)
+    assert not offenders, sorted(offenders)[:10]

@@ -9,9 +9,14 @@
 set -u
 TAG=${1:-rXX}
 WHAT=${2:-all}
+case "$TAG" in -*|"") echo "usage: tools/collect_profiles.sh <tag> [tests|pmc|bench|agg|config5|micro ...]   (a tag names the output files: it cannot start with '-')" >&2; exit 2;; esac
 OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+# rocprofv3's preloaded tool library opens the GPU runtime before the program starts: a GPU_MAX_HW_QUEUES that libp25 sets at its
+# own first call may come too late then (p25_runtime_info: hw_queues_setting_late) and the prover would run its 16 streams on
+# the runtime's default 4 hardware queues -- exported here, so every pass is taken in the regime the product runs in.
+export GPU_MAX_HW_QUEUES=24
 want() { [ "$WHAT" = all ] || [[ " $WHAT " == *" $1 "* ]]; }
 if want tests; then
 # (written as it runs: output held back by a pipe into tail makes a long run look hung to gpurun's silence detector)

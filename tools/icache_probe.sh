@@ -4,6 +4,10 @@ set -u
 TAG=${1:-icache}
 OUT=gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+# rocprofv3's preloaded tool library opens the GPU runtime before the program starts: a GPU_MAX_HW_QUEUES that libp25 sets at its
+# own first call may come too late then (p25_runtime_info: hw_queues_setting_late) and the prover would run its 16 streams on
+# the runtime's default 4 hardware queues -- exported here, so every pass is taken in the regime the product runs in.
+export GPU_MAX_HW_QUEUES=24
 rocprofv3 -L 2>/dev/null | grep -i -o "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQ_INST_LEVEL_[A-Z_]*\|SQC_TC_INST[A-Z_]*" | sort -u > $OUT/${TAG}_counters.txt
 cat $OUT/${TAG}_counters.txt | tr '\n' ' '; echo
 for C in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do

@@ -4,6 +4,10 @@ set -u
 TAG=$1; shift
 OUT=gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+# rocprofv3's preloaded tool library opens the GPU runtime before the program starts: a GPU_MAX_HW_QUEUES that libp25 sets at its
+# own first call may come too late then (p25_runtime_info: hw_queues_setting_late) and the prover would run its 16 streams on
+# the runtime's default 4 hardware queues -- exported here, so every pass is taken in the regime the product runs in.
+export GPU_MAX_HW_QUEUES=24
 for V in "$@"; do
   NAME=${V%%=*}; LIB=${V#*=}
   ARGS=""; [ "$LIB" != base ] && ARGS="--lib $LIB"

@@ -10,7 +10,8 @@ if "--lib" in sys.argv:   # profiling builds only (tools/qmask.sh): an explicit 
     i = sys.argv.index("--lib")
     sys.modules["plonky25_amd.binding"].lib_path = sys.argv[i + 1]
     del sys.argv[i:i + 2]
-p25.device_init(0)
+late = p25.device_init(0)
+print("runtime:", p25.runtime_info().as_dict(), "hw-queue request late:", late)   # under rocprofv3 the profiler opens the GPU first
 if "--log-n" in sys.argv:   # another inner trace height (BASELINE config 5: --log-n 20), from the native plonky3 prover
     i = sys.argv.index("--log-n")
     inputs, cfg = p25.p3_prove_fibonacci(int(sys.argv[i + 1]), 100, 16, threads=os.cpu_count() or 1)

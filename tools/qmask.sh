@@ -1,5 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=24   # the profiler opens the GPU runtime first: libp25's own request would come too late
 # needs the profiling build: tools/exp/build_gatemask.sh  (the shipped libp25.so has no gate mask)
 LIB=$PWD/tools/build/libp25_gatemask.so
 for M in 0xFFFFFFFF 0x0 $*; do
