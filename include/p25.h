@@ -149,7 +149,8 @@ p25_status p25_circuit_build_p3_verifier(const p25_p3_config* cfg, int32_t air, 
  * an expression DAG.  node.op: 0 LOCAL(column a of the current row)  1 NEXT(column a of the next row)
  * 2 CONST(value)  3 ADD(a,b)  4 SUB(a,b)  5 MUL(a,b), a/b = indices of EARLIER nodes.  A constraint is a
  * node that must vanish on the rows `when` selects (0 always, 1 first row, 2 last row, 3 transition),
- * folded in order like VerifierConstraintFolder (air.rs:69-118).  Degree (selector included) <= 2: ONE quotient chunk,
+ * folded in order like VerifierConstraintFolder (air.rs:69-118).  Degree 4-5 / 6-9: FOUR / EIGHT chunks with log_blowup >= 2 / 3
+ * (round 6, p25_p3_prove_air_ex).  Degree (selector included) <= 2: ONE quotient chunk,
  * the reference's proof model (serde/proof.rs:41-48 `(0..1)`), p25_p3_config.log_quotient_degree = 0.  Degree 3: TWO chunks
  * (log_quotient_degree = 1; round 5): the reference's verifier (verifier.rs:115-221) and its shape derivation (mod.rs:76)
  * handle any power of two, only that `(0..1)` fixes the count -- the flat input then carries the second chunk's two
@@ -175,6 +176,17 @@ p25_status p25_circuit_build_p3_verifier_air(const p25_p3_config* cfg, const p25
 p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t log_n, int32_t num_queries,
                             int32_t pow_bits, uint64_t pow_start, int32_t threads, uint64_t* inputs_out, size_t cap,
                             size_t* n_out, p25_p3_config* cfg_out);
+/* The same with FriConfig.log_blowup explicit (src/p3/mod.rs:242-246; the reference's verifier reads config.log_blowup
+ * generically: verifier.rs:264, 299, 378, 397).  log_blowup 1 = p25_p3_prove_air = the reference's artifact.  log_blowup 2 / 3:
+ * the LDE domain is 7*H_{4n} / 7*H_{8n}, which holds the quotient domain of AIRs of constraint degree up to 5 / 9 (selector
+ * included): 2^log_quotient_degree = 4 / 8 quotient chunks, log_quotient_degree = log2_ceil(degree - 1) as in uni-stark.  The
+ * flat input then carries every chunk's two openings in order, one matrix per chunk in every query's quotient batch, input
+ * Merkle paths of log_n + log_blowup digests and commit-phase paths of log_n + log_blowup - 1 - i (the reference's data model,
+ * serde/proof.rs:204-205, writes log_n - i: the log_blowup-1 case).  P25_ERR_INVALID_ARG if the AIR's degree needs more chunks
+ * than log_blowup holds. */
+p25_status p25_p3_prove_air_ex(const p25_air* air, const uint64_t* trace, int32_t log_n, int32_t log_blowup, int32_t num_queries,
+                               int32_t pow_bits, uint64_t pow_start, int32_t threads, uint64_t* inputs_out, size_t cap,
+                               size_t* n_out, p25_p3_config* cfg_out);
 
 /* Small circuits mirroring the reference's gadget tests (src/p3/mod.rs:271-494 test_p3_and / xor / lsh /
  * rsh / reverse, src/p3/commit.rs:173-198 test_compress): kind 0 and(x,y) 1 xor(x,y) 2 lsh(x,param)

@@ -188,6 +188,8 @@ EXPORTED_SYMBOLS = {
     "p25_p3_prove_fibonacci": (i32, [i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz), C.POINTER(P3Config)]),
     "p25_p3_inputs_to_json": (i32, [vp, sz, C.POINTER(P3Config), vp, sz, C.POINTER(sz)]),
     "p25_circuit_build_p3_verifier_air": (i32, [C.POINTER(P3Config), C.POINTER(AirC), C.POINTER(vp)]),
+    "p25_p3_prove_air_ex": (i32, [C.POINTER(AirC), vp, i32, i32, i32, i32, C.c_uint64, i32, vp, sz, C.POINTER(sz),
+                                  C.POINTER(P3Config)]),
     "p25_runtime_info": (i32, [C.POINTER(RuntimeInfo)]),
     "p25_comm_unique_id": (i32, [vp]),
     "p25_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
@@ -276,7 +278,7 @@ class Comm:
     def gather(self, circuit, mark_slot, d_proofs, proof_stride, d_status, counts, dst, d_all_proofs, d_all_status):
         """p25_gather_proofs with device addresses (ints); circuit may be None (no device-side wait)."""
         cnt = (C.c_size_t * self.world)(*[int(x) for x in counts])
-        _check(lib().p25_gather_proofs(self.h, circuit.h if circuit is not None else None, int(mark_slot), d_proofs,
+        _check(lib().p25_gather_proofs(self.h, circuit._h if circuit is not None else None, int(mark_slot), d_proofs,
                                        proof_stride, d_status, cnt, dst, d_all_proofs, d_all_status))
 
     def sync(self):
@@ -414,8 +416,9 @@ def p3_prove_fibonacci(log_n=6, num_queries=100, pow_bits=16, pow_start=0, threa
     return out, cfg
 
 
-def p3_prove_air(air, trace, num_queries=100, pow_bits=16, pow_start=0, threads=None):
-    """Native plonky3 proof of `air` (binding.Air) on `trace` (uint64[2^log_n][width]) -> (inputs, P3Config)."""
+def p3_prove_air(air, trace, num_queries=100, pow_bits=16, pow_start=0, threads=None, log_blowup=1):
+    """Native plonky3 proof of `air` (binding.Air) on `trace` (uint64[2^log_n][width]) -> (inputs, P3Config).
+    log_blowup: FriConfig.log_blowup (1 = the reference's; 2 / 3 for AIRs of constraint degree up to 5 / 9)."""
     threads = threads or min(16, os.cpu_count() or 1)
     t = np.ascontiguousarray(trace, dtype=np.uint64)
     if t.ndim != 2 or t.shape[1] != air.width or t.shape[0] & (t.shape[0] - 1) or t.shape[0] < 2:
@@ -424,11 +427,11 @@ def p3_prove_air(air, trace, num_queries=100, pow_bits=16, pow_start=0, threads=
     ac = air.to_c()
     n = sz(0)
     cfg = P3Config()
-    _check(lib().p25_p3_prove_air(C.byref(ac), None, log_n, num_queries, pow_bits, pow_start, threads, None, 0,
-                                  C.byref(n), C.byref(cfg)))
+    _check(lib().p25_p3_prove_air_ex(C.byref(ac), None, log_n, log_blowup, num_queries, pow_bits, pow_start, threads, None, 0,
+                                     C.byref(n), C.byref(cfg)))
     out = np.zeros(n.value, dtype=np.uint64)
-    _check(lib().p25_p3_prove_air(C.byref(ac), _ptr(t), log_n, num_queries, pow_bits, pow_start, threads, _ptr(out),
-                                  out.size, C.byref(n), C.byref(cfg)))
+    _check(lib().p25_p3_prove_air_ex(C.byref(ac), _ptr(t), log_n, log_blowup, num_queries, pow_bits, pow_start, threads, _ptr(out),
+                                     out.size, C.byref(n), C.byref(cfg)))
     return out, cfg
 
 

@@ -377,10 +377,13 @@ static p25_status host_guarded(F&& f) {
 extern "C" {
 
 static p25::P3Config checked_p3_config(const p25_p3_config* cfg) {
-  // one quotient chunk is the reference's proof model (proof.rs:41-48); two (constraint degree 3) is the round-5 extension
-  if (cfg->log_quotient_degree != 0 && cfg->log_quotient_degree != 1)
-    throw std::invalid_argument("one or two quotient chunks are supported (log_quotient_degree 0 or 1)");
+  // one quotient chunk is the reference's proof model (proof.rs:41-48); two (constraint degree 3) is the round-5 extension,
+  // four / eight (degree 4-5 / 6-9, with log_blowup 2 / 3) round 6's
+  if (cfg->log_quotient_degree < 0 || cfg->log_quotient_degree > 3)
+    throw std::invalid_argument("1, 2, 4 or 8 quotient chunks are supported (log_quotient_degree 0..3)");
   if (cfg->log_quotient_degree > cfg->log_blowup) throw std::invalid_argument("log_quotient_degree above log_blowup");
+  if (cfg->opening_matrix_log_max_height != cfg->log_trace_height + cfg->log_blowup)
+    throw std::invalid_argument("opening_matrix_log_max_height must be log_trace_height + log_blowup");
   if (cfg->trace_width < 1 || cfg->trace_width > 64 || cfg->log_trace_height < 1 || cfg->log_trace_height > 24 ||
       cfg->num_queries < 1 || cfg->num_queries > 1000 || cfg->degree_bits < 1 || cfg->degree_bits > cfg->log_trace_height ||
       cfg->opening_matrix_log_max_height < 1 || cfg->opening_matrix_log_max_height > 30 || cfg->quotient_opened_len < 1 ||
@@ -434,12 +437,9 @@ p25_status p25_circuit_build_p3_verifier_air(const p25_p3_config* cfg, const p25
     if (!cfg || !air || !out) throw std::invalid_argument("null argument");
     p25::AirProgram prog = air_from_c(air);
     // the chunk count follows from the AIR (uni-stark get_log_quotient_degree): the shape must say the same
-    int max_deg = 1;
-    for (const auto& c : prog.constraints)
-      max_deg = std::max(max_deg, prog.node_degree(c.node) + (c.when == p25::AirProgram::ALWAYS ? 0 : 1));
-    if ((max_deg <= 2 ? 0 : 1) != cfg->log_quotient_degree)
-      throw std::invalid_argument(max_deg <= 2 ? "AIR of degree <= 2 has ONE quotient chunk (log_quotient_degree 0)"
-                                               : "AIR of constraint degree 3 needs TWO quotient chunks (log_quotient_degree 1)");
+    if (prog.log_quotient_degree() != cfg->log_quotient_degree)
+      throw std::invalid_argument("an AIR of constraint degree " + std::to_string(prog.max_constraint_degree()) + " has 2^" +
+                                  std::to_string(prog.log_quotient_degree()) + " quotient chunks: log_quotient_degree must say so");
     p25::ProgramAir pa(std::move(prog));
     return build_verifier(cfg, pa, out);
   });
@@ -983,27 +983,33 @@ p25_status p25_p3_prove_fibonacci(int32_t log_n, int32_t num_queries, int32_t po
 p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t log_n, int32_t num_queries,
                             int32_t pow_bits, uint64_t pow_start, int32_t threads, uint64_t* inputs_out, size_t cap,
                             size_t* n_out, p25_p3_config* cfg_out) {
+  return p25_p3_prove_air_ex(air, trace, log_n, 1, num_queries, pow_bits, pow_start, threads, inputs_out, cap, n_out, cfg_out);
+}
+p25_status p25_p3_prove_air_ex(const p25_air* air, const uint64_t* trace, int32_t log_n, int32_t log_blowup, int32_t num_queries,
+                               int32_t pow_bits, uint64_t pow_start, int32_t threads, uint64_t* inputs_out, size_t cap,
+                               size_t* n_out, p25_p3_config* cfg_out) {
   return host_guarded([&]() -> p25_status {
     if (!air || !n_out) throw std::invalid_argument("null argument");
     p25::AirProgram prog = air_from_c(air);
+    if (log_blowup < 1 || log_blowup > 3) throw std::invalid_argument("log_blowup must be 1, 2 or 3");
+    if (prog.log_quotient_degree() > log_blowup)
+      throw std::invalid_argument("an AIR of constraint degree " + std::to_string(prog.max_constraint_degree()) + " needs log_blowup >= " +
+                                  std::to_string(prog.log_quotient_degree()));
     p25::P3ProveParams prm;
     prm.log_n = log_n;
+    prm.log_blowup = log_blowup;
     prm.num_queries = num_queries;
     prm.pow_bits = pow_bits;
     prm.pow_start = pow_start;
     prm.threads = threads < 1 ? 1 : threads;
     p25::P3Config pc;
+    pc.fri_config.log_blowup = log_blowup;
     pc.fri_config.num_queries = num_queries;
     pc.log_trace_height = log_n;
     pc.trace_width = prog.width;
-    pc.opening_matrix_log_max_height = log_n + 1;
+    pc.opening_matrix_log_max_height = log_n + log_blowup;
     pc.degree_bits = log_n;
-    {   // the number of quotient chunks follows from the AIR's degree (p3_prove_air)
-      int max_deg = 1;
-      for (const auto& c : prog.constraints)
-        max_deg = std::max(max_deg, prog.node_degree(c.node) + (c.when == p25::AirProgram::ALWAYS ? 0 : 1));
-      pc.log_quotient_degree = max_deg <= 2 ? 0 : 1;
-    }
+    pc.log_quotient_degree = prog.log_quotient_degree();   // the number of quotient chunks follows from the AIR's degree (p3_prove_air)
     if (!inputs_out) {  // size query only
       if (log_n < 1 || log_n > 22 || num_queries < 1) throw std::invalid_argument("bad parameters");
       *n_out = pc.num_inputs();

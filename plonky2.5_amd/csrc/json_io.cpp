@@ -178,8 +178,14 @@ void p3_proof_from_json(const char* json, size_t len, std::vector<u64>& inputs, 
   cfg.opening_proof_query_openings_opened_values_length = (int)qo.arr[0].arr[1].at("opened_values").arr.at(0).arr.size();
   cfg.degree_bits = (int)root.at("degree_bits").num;
   cfg.fri_config.num_queries = (int)fp.at("query_proofs").arr.size();
-  if (ov.at("quotient_chunks").arr.size() != 1 && ov.at("quotient_chunks").arr.size() != 2)
-    throw std::invalid_argument("p3 proof JSON: one quotient chunk (proof.rs:41-48) or two (degree-3 AIRs) are supported");
+  // the FriConfig is not part of the proof (src/p3/mod.rs:242-246 passes it beside it); its log_blowup shows in the shape:
+  // input Merkle paths are log_max_height = log_trace_height + log_blowup digests long (verifier.rs:264)
+  cfg.fri_config.log_blowup = cfg.opening_matrix_log_max_height - cfg.log_trace_height;
+  const size_t n_chunks = ov.at("quotient_chunks").arr.size();
+  if (n_chunks != ((size_t)1 << cfg.log_quotient_degree) || n_chunks > 8)
+    throw std::invalid_argument("p3 proof JSON: 1 quotient chunk (proof.rs:41-48), or 2 / 4 / 8 (AIRs of degree 3 / 4-5 / 6-9)");
+  if (cfg.fri_config.log_blowup < 1 || cfg.fri_config.log_blowup > 3 || cfg.log_quotient_degree > cfg.fri_config.log_blowup)
+    throw std::invalid_argument("p3 proof JSON: Merkle path lengths imply an unsupported log_blowup");
   if (inputs.size() != cfg.num_inputs()) throw std::invalid_argument("p3 proof JSON: shape is not rectangular");
 }
 

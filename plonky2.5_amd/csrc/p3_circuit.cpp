@@ -405,10 +405,22 @@ void AirProgram::validate() const {
     if (c.node >= nodes.size() || c.when > TRANSITION) throw std::invalid_argument("AIR: bad constraint");
     // degree <= 2: one quotient chunk, the reference's proof model (serde/proof.rs:41-48).  Degree 3: two chunks -- the
     // reference's verifier (verifier.rs:115-221) and its P3Config (mod.rs:76) already handle any power of two, only
-    // `OpenedValues::add_virtual_to` fixes the count; round 5 lifts that.  More needs log_blowup > 1.
-    if (node_degree(c.node) + (c.when == ALWAYS ? 0 : 1) > 3)
-      throw std::invalid_argument("AIR: constraint degree > 3 needs more than two quotient chunks (log_blowup 1 holds two)");
+    // `OpenedValues::add_virtual_to` fixes the count; round 5 lifted that.  Degree 4..5 (four chunks) needs log_blowup >= 2,
+    // 6..9 (eight) log_blowup 3: the quotient domain 7*H_{n 2^lqd} must lie inside the LDE domain (round 6).
+    if (node_degree(c.node) + (c.when == ALWAYS ? 0 : 1) > 9)
+      throw std::invalid_argument("AIR: constraint degree > 9 needs more than eight quotient chunks");
   }
+}
+int AirProgram::max_constraint_degree() const {
+  int d = 1;
+  for (const Constraint& c : constraints) d = std::max(d, node_degree(c.node) + (c.when == ALWAYS ? 0 : 1));
+  return d;
+}
+int AirProgram::log_quotient_degree() const {
+  const int d = std::max(max_constraint_degree(), 2) - 1;
+  int l = 0;
+  while ((1 << l) < d) l++;
+  return l;
 }
 AirProgram AirProgram::fibonacci() {
   AirProgram p;
@@ -448,7 +460,9 @@ size_t P3Config::num_inputs() const {
   size_t n = 8 + (size_t)trace_width * 4 + 4 * chunks;
   n += (size_t)log_trace_height * 4;
   size_t per_query = 0;
-  for (int i = 0; i < log_trace_height; i++) per_query += 2 + 4 * (size_t)(log_trace_height - i);
+  // round i's layer has 2^(log_max_height - i) values committed in pairs: Merkle paths of log_max_height - 1 - i digests
+  // (= log_trace_height - i for the reference's log_blowup 1: proof.rs:204-205)
+  for (int i = 0; i < log_trace_height; i++) per_query += 2 + 4 * (size_t)(opening_matrix_log_max_height - 1 - i);
   n += per_query * fri_config.num_queries + 3;
   n += (size_t)fri_config.num_queries *
        ((trace_width + 4 * opening_matrix_log_max_height) +
@@ -480,7 +494,7 @@ static P3ProofTarget add_virtual_proof(CircuitBuilder& cb, const P3Config& cfg) 
     for (int i = 0; i < cfg.log_trace_height; i++) {
       P3CommitPhaseStep s;
       s.sibling_value = vext();
-      for (int k = 0; k < cfg.log_trace_height - i; k++) s.opening_proof.push_back(v4());
+      for (int k = 0; k < cfg.opening_matrix_log_max_height - 1 - i; k++) s.opening_proof.push_back(v4());
       steps.push_back(std::move(s));
     }
     p.query_proofs.push_back(std::move(steps));

@@ -90,10 +90,15 @@ struct AirProgram {
   int width = 0;
   std::vector<Node> nodes;
   std::vector<Constraint> constraints;
-  // throws std::invalid_argument on malformed programs and on constraint degree > 2 (selector included):
-  // the reference's proof model carries exactly one quotient chunk (serde/proof.rs:41-48)
+  // throws std::invalid_argument on malformed programs and on constraint degree > 9 (selector included; eight quotient
+  // chunks).  The reference's proof model carries exactly one chunk (serde/proof.rs:41-48, degree <= 2); more chunks are this
+  // library's extension of it, and log_quotient_degree() of them must not exceed the FRI log_blowup (checked by the callers).
   void validate() const;
   int node_degree(uint32_t i) const;
+  // max over the constraints of their degree with the selector's counted, and uni-stark's get_log_quotient_degree of it:
+  // log2_ceil(max(degree, 2) - 1) -- 0 for degree <= 2, 1 for 3, 2 for 4..5, 3 for 6..9
+  int max_constraint_degree() const;
+  int log_quotient_degree() const;
   // the test AIR of src/p3/mod.rs:176-221 in this form (same constraints, same order)
   static AirProgram fibonacci();
 

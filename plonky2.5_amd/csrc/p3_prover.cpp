@@ -493,7 +493,7 @@ std::string p3_inputs_to_json(const std::vector<u64>& in, const P3Config& cfg) {
       s += "{\"sibling_value\":";
       val(2);
       s += ",\"opening_proof\":";
-      list(k - i, [&] { arr(4); });
+      list(cfg.opening_matrix_log_max_height - 1 - i, [&] { arr(4); });
       s += '}';
       i++;
     });

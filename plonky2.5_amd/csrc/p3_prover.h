@@ -22,7 +22,7 @@ namespace p25 {
 
 struct P3ProveParams {
   int log_n = 6;             // trace height 2^log_n (the artifact: 64 rows)
-  int log_blowup = 1;
+  int log_blowup = 1;        // FriConfig.log_blowup (src/p3/mod.rs:242-246 uses 1); 2 / 3 hold AIRs of degree up to 5 / 9
   int num_queries = 100;
   int pow_bits = 16;
   // proof-of-work witness search starts here (plonky3 grinds with find_any, so any valid witness
@@ -33,7 +33,7 @@ struct P3ProveParams {
 // Returns the proof as the flat input vector (add_virtual_to order) and its shape.
 std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg_out);
 // Same prover for any AIR given as a program (p3_circuit.h: AirProgram) and its trace, col[c][row];
-// constraint degree <= 2 (one quotient chunk, as the reference's proof model has).  Throws
+// constraint degree <= 2^log_blowup + 1 (2^log_quotient_degree quotient chunks; the reference's proof model has one).  Throws
 // std::logic_error("quotient identity ...") if the trace does not satisfy the AIR.
 std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vector<u64>>& col, const P3ProveParams& prm,
                               P3Config& cfg_out);

@@ -166,3 +166,57 @@ def cubic_transition_trace(log_n):
         t[i] = (x, y, x * y % P)
         x, y = (x * y + 5) % P, (y + x) % P
     return t
+
+
+def quartic_map(p25, seed):
+    """Seeded family, constraint degree 4 in an ALWAYS constraint (FOUR quotient chunks, needs log_blowup >= 2):
+    width 2, y = x^4 + a x + b on every row; next x = y + c x (transition); first row x = x0.  Returns (air, (a, b, c, x0))."""
+    rng = np.random.default_rng(seed)
+    a, b, c, x0 = (int(v) for v in rng.integers(1, P, size=4, dtype=np.uint64))
+    air = p25.Air(2)
+    x, y = air.local(0), air.local(1)
+    x2 = air.mul(x, x)
+    x4 = air.mul(x2, x2)
+    air.assert_zero(air.sub(air.add(air.add(x4, air.mul(air.const(a), x)), air.const(b)), y))
+    air.when_first_row(air.sub(x, air.const(x0)))
+    air.when_transition(air.sub(air.next(0), air.add(y, air.mul(air.const(c), x))))
+    return air, (a, b, c, x0)
+
+
+def quartic_map_trace(par, log_n):
+    a, b, c, x = par
+    n = 1 << log_n
+    t = np.zeros((n, 2), dtype=np.uint64)
+    for i in range(n):
+        y = (pow(x, 4, P) + a * x + b) % P
+        t[i] = (x, y)
+        x = (y + c * x) % P
+    return t
+
+
+def quintic_selector(p25, seed):
+    """Seeded family, constraint degree 5 THROUGH THE SELECTOR (four quotient chunks): width 3, the transition constraint
+    next x = x^2 y^2 + k is quartic, times is_transition; next y = y + d x; z = x y on every row (degree 2); the last row pins
+    z - x y once more under when_last_row (degree 3).  Returns (air, (k, d, x0, y0))."""
+    rng = np.random.default_rng(seed)
+    k, d, x0, y0 = (int(v) for v in rng.integers(1, P, size=4, dtype=np.uint64))
+    air = p25.Air(3)
+    x, y, z = air.local(0), air.local(1), air.local(2)
+    air.assert_zero(air.sub(air.mul(x, y), z))
+    air.when_first_row(air.sub(x, air.const(x0)))
+    air.when_first_row(air.sub(y, air.const(y0)))
+    xy = air.mul(x, y)
+    air.when_transition(air.sub(air.next(0), air.add(air.mul(xy, xy), air.const(k))))
+    air.when_transition(air.sub(air.next(1), air.add(y, air.mul(air.const(d), x))))
+    air.when_last_row(air.sub(air.mul(x, y), z))
+    return air, (k, d, x0, y0)
+
+
+def quintic_selector_trace(par, log_n):
+    k, d, x, y = par
+    n = 1 << log_n
+    t = np.zeros((n, 3), dtype=np.uint64)
+    for i in range(n):
+        t[i] = (x, y, x * y % P)
+        x, y = (pow(x * y % P, 2, P) + k) % P, (y + d * x) % P
+    return t
