@@ -23,7 +23,7 @@ def flatten_p3_proof(obj):
         out += _ext(e)
     for e in ov["trace_next"]:
         out += _ext(e)
-    assert len(ov["quotient_chunks"]) in (1, 2)  # proof.rs:41-48 hard-codes one chunk; two = the degree-3 extension
+    assert len(ov["quotient_chunks"]) in (1, 2, 4, 8)  # proof.rs:41-48 hard-codes one chunk; 2 / 4 / 8 = the degree 3 / 4-5 / 6-9 extensions
     for chunk in ov["quotient_chunks"]:
         for e in chunk:
             out += _ext(e)
@@ -57,6 +57,9 @@ def p3_shape(obj):
         "quotient_opened_len": len(obj["opening_proof"]["query_openings"][0][1]["opened_values"][0]),
         "degree_bits": obj["degree_bits"],
         "num_queries": len(obj["opening_proof"]["fri_proof"]["query_proofs"]),
+        # FriConfig.log_blowup is not in the proof; the input Merkle paths are log_trace_height + log_blowup long (verifier.rs:264)
+        "log_blowup": len(obj["opening_proof"]["query_openings"][0][0]["opening_proof"])
+                      - len(obj["opening_proof"]["fri_proof"]["commit_phase_commits"]),
     }
 
 

@@ -1,4 +1,4 @@
-"""GPU: a short, seeded run of tools/fuzz_parity.py -- random AIR families (degree 1..3), trace heights, query counts, PoW bits,
+"""GPU: a short, seeded run of tools/fuzz_parity.py -- random AIR families (degree 1..5, FriConfig.log_blowup 1..3), trace heights, query counts, PoW bits,
 gadget operands and corrupted inputs; every status and every proof byte must equal the oracle's."""
 import os
 import subprocess

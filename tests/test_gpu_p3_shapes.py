@@ -87,3 +87,35 @@ def test_gpu_equals_oracle_on_seeded_air_families(gpu, oracle, family, seed, arg
     assert sto == 0, msg
     assert (proofs[0] == po).all()
     assert oc.verify(proofs[0], dg, capg)[0] == 0
+
+
+@pytest.mark.parametrize("family,seed,log_n,log_blowup", [("quartic_map", 21, 4, 2), ("quartic_map", 23, 5, 3),
+                                                          ("quintic_selector", 31, 5, 2), ("quintic_selector", 33, 3, 2)])
+def test_gpu_equals_oracle_on_degree_four_and_five_airs_with_log_blowup_two(gpu, oracle, family, seed, log_n, log_blowup):
+    """FriConfig.log_blowup 2 / 3 (src/p3/mod.rs:242-246) and AIRs of constraint degree 4 and 5 -- FOUR quotient chunks --
+    through `p25_p3_prove_air_ex` -> `p25_circuit_build_p3_verifier_air` -> the GPU prover: circuit digest and proof bytes
+    equal the oracle's, the oracle's verifier accepts, and a flipped input (one of the chunk openings, and a word in the
+    middle of the query openings) has no witness on either side."""
+    import air_cases
+    air, par = getattr(air_cases, family)(gpu, seed)
+    trace = getattr(air_cases, family + "_trace")(par, log_n)
+    inp, cfg = gpu.p3_prove_air(air, trace, num_queries=8, pow_bits=6, log_blowup=log_blowup)
+    assert (cfg.log_blowup, cfg.log_quotient_degree) == (log_blowup, 2)
+    alt, _ = gpu.p3_prove_air(air, trace, num_queries=8, pow_bits=6, pow_start=1 << 20, log_blowup=log_blowup)
+    c = gpu.Circuit.build_p3_verifier_air(cfg, air)
+    oc = oracle.load_circuit(c.to_blob())
+    dg, capg = c.digest()
+    do, capo = oc.digest()
+    assert (dg == do).all() and (capg == capo).all()
+    bad1, bad2 = inp.copy(), inp.copy()
+    k1, k2 = 8 + 4 * air.width + 5, (2 * inp.size) // 3
+    bad1[k1] = (int(bad1[k1]) + 1) % 0xFFFFFFFF00000001
+    bad2[k2] = (int(bad2[k2]) + 1) % 0xFFFFFFFF00000001
+    proofs, st = c.prove(np.stack([inp, bad1, alt, bad2]), seeds=[5, 6, 7, 8])
+    assert st.tolist() == [0, 4, 0, 4]
+    for row, seed_ in ((inp, 5), (alt, 7)):
+        po, sto, _tm, msg = oc.prove(row, seed=seed_)
+        assert sto == 0, msg
+        assert (proofs[0 if seed_ == 5 else 2] == po).all()
+    assert oc.witness(bad1, seed=6)[1] == 4 and oc.witness(bad2, seed=8)[1] == 4
+    assert oc.verify(proofs[0], dg, capg)[0] == 0 and oc.verify(proofs[2], dg, capg)[0] == 0

@@ -36,7 +36,7 @@ def check(name, circ, inputs, seeds):
 
 
 while time.time() - t0 < budget:
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 6))
     seed = int(rng.integers(1, 1 << 30))
     if kind == 0:
         width = int(rng.integers(2, 10))
@@ -55,6 +55,13 @@ while time.time() - t0 < budget:
         log_n = int(rng.integers(2, 7))
         trace = getattr(air_cases, which + "_trace")(log_n)
         name = f"{which} 2^{log_n}"
+    elif kind == 5:      # degree 4 / 5: four quotient chunks, FriConfig.log_blowup 2 or 3 (round 6)
+        which = "quartic_map" if seed & 1 else "quintic_selector"
+        air, par = getattr(air_cases, which)(p25, seed)
+        log_n = int(rng.integers(2, 6))
+        trace = getattr(air_cases, which + "_trace")(par, log_n)
+        blowup = 2 + int(seed >> 1 & 1)
+        name = f"{which} 2^{log_n} log_blowup {blowup}"
     elif kind == 3:
         c = p25.Circuit.build_gadget(14, 0)
         ins = [reference_gates_inputs(ora, *(int(v) for v in rng.integers(0, 1 << 32, size=3))) for _ in range(3)]
@@ -67,8 +74,9 @@ while time.time() - t0 < budget:
         check(f"gadget {nm}", c, [np.array(vals, dtype=np.uint64)], [seed])
         continue
     q, pw = int(rng.integers(1, 9)), int(rng.integers(1, 9))
-    inp, cfg = p25.p3_prove_air(air, trace, num_queries=q, pow_bits=pw)
-    alt, _ = p25.p3_prove_air(air, trace, num_queries=q, pow_bits=pw, pow_start=1 << 20)
+    lb = blowup if kind == 5 else 1
+    inp, cfg = p25.p3_prove_air(air, trace, num_queries=q, pow_bits=pw, log_blowup=lb)
+    alt, _ = p25.p3_prove_air(air, trace, num_queries=q, pow_bits=pw, pow_start=1 << 20, log_blowup=lb)
     circ = p25.Circuit.build_p3_verifier_air(cfg, air)
     bad = inp.copy()
     k = int(rng.integers(0, inp.size))
