@@ -891,7 +891,7 @@ def main():
             if args.cpu_baseline == "full":
                 # (ii) the whole host: G proofs in flight, each on T threads of the oracle's persistent pool,
                 # G x T = the physical cores.  (One single-threaded proof per core was measured too: 128 working sets
-                # of ~4 GB compete for the memory system and the host delivers 0.21 proofs/s -- DESIGN.md section 4.)
+                # of ~4 GB compete for the memory system and the host delivers 0.21 proofs/s -- docs/HISTORY.md section 4.)
                 cores = physical_cores()
                 if args.cpu_cores:
                     cores = cores[:args.cpu_cores]

@@ -322,7 +322,7 @@ typedef struct {
  * verifier / aggregator holds the INNER circuit's lock for the duration of the build, and p25_circuit_wait_mark takes both
  * circuits' locks); their proofs share the device through ONE pool of 16
  * proving streams + 2 main streams per process (a stream set per circuit oversubscribes the hardware queues as soon as
- * two circuits are alive: DESIGN.md section 3).  With `timings` != NULL, or a batch of one, the proofs run one
+ * two circuits are alive: DESIGN.md section 3, docs/HISTORY.md section 3).  With `timings` != NULL, or a batch of one, the proofs run one
  * at a time with latency-oriented kernel forms; otherwise up to 16 proofs are in flight (p25_circuit_set_streams). */
 p25_status p25_prove_batch(p25_circuit* c, const uint64_t* inputs, size_t n_proofs, const uint64_t* seeds,
                            uint64_t* proofs_out, size_t proof_stride_words, p25_status* per_proof_status,

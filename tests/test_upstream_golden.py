@@ -120,7 +120,7 @@ need_rec = pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "upstream_re
 def test_recursive_verifier_shape_vs_upstream(p25, fib_circuit, fib_oracle):
     """The day cargo exists: how far `p25_circuit_build_recursive_verifier` is from upstream's `builder.verify_proof`
     circuit for one fib-64 proof.  The gate SET must agree (the library claims upstream's gate set); rows per gate and
-    the digest are reported, and asserted only once DESIGN.md section 6 stops disclaiming row-for-row equality."""
+    the digest are reported, and asserted only once DESIGN.md section 7 stops disclaiming row-for-row equality."""
     up = json.load(open(os.path.join(GOLD, "upstream_recursive_circuit.json")))
     dg, cap = fib_oracle.digest()
     rc = fib_circuit.build_recursive_verifier(1, dg, cap)

@@ -3,7 +3,7 @@
 // `mds_layer`, called from /root/reference/src/p3/mod.rs:260 through PoseidonHash).
 //
 // Why: a full round is 12 S-boxes (672 VALU) + an MDS layer of 24 v_mad_u64_u32 + 5 per output word (348 VALU),
-// and the chip is VALU-issue bound on exactly this (DESIGN.md section 3).  The MDS layer is a 12x12 matrix with
+// and the chip is VALU-issue bound on exactly this (DESIGN.md section 5).  The MDS layer is a 12x12 matrix with
 // 6-bit entries applied to 64-bit words: on the bytes of the state it is an integer GEMM.
 // v_mfma_i32_32x32x32_i8 computes, per instruction,  D[32 x 32] += A[32 x 32] B[32 x 32]  in the otherwise idle
 // matrix pipe and costs the VALU stream ~0-3 issue cycles when >= 24 VALU instructions separate two of them
