@@ -1,5 +1,6 @@
 // C ABI of libp25 (declared in include/p25.h).  Thin: argument checks, device buffers, launches.
 #include <stdlib.h>
+#include <dirent.h>
 #include <unistd.h>
 #include <cstring>
 #include <memory>
@@ -32,15 +33,23 @@ static HwQueueState g_hwq;
 // True if this process already holds /dev/kfd: the ROCm runtime under HIP has been initialised (by the host, by torch, or by
 // a profiler's preloaded tool library), so an environment variable set NOW may no longer be read.
 static bool gpu_driver_open() {
-  char link[64], target[256];
-  for (int fd = 0; fd < 1024; fd++) {
-    snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
-    ssize_t k = readlink(link, target, sizeof target - 1);
+  DIR* d = opendir("/proc/self/fd");
+  if (!d) return false;
+  bool found = false;
+  char link[300], target[256];
+  while (struct dirent* e = readdir(d)) {
+    if (e->d_name[0] == '.') continue;
+    snprintf(link, sizeof link, "/proc/self/fd/%s", e->d_name);
+    const ssize_t k = readlink(link, target, sizeof target - 1);
     if (k <= 0) continue;
     target[k] = 0;
-    if (!strcmp(target, "/dev/kfd")) return true;
+    if (!strcmp(target, "/dev/kfd")) {
+      found = true;
+      break;
+    }
   }
-  return false;
+  closedir(d);
+  return found;
 }
 
 // Ask the HIP runtime for `hw_queues` hardware queues (never overriding a value the host exported) BEFORE the library's first
