@@ -137,6 +137,55 @@ int main() {
     printf("CircuitData bytes fuzz: %d rejected, %d accepted\n", rejected, accepted);
     CHECK(rejected > 20);
   }
+  // round 6: FriConfig.log_blowup 2 with a degree-4 AIR (four quotient chunks): y = x^4 + 3 x + 5 on every row, next x = y + 7 x
+  {
+    AirProgram q;
+    q.width = 2;
+    auto nd = [&](uint32_t op, uint32_t a, uint32_t b, u64 v) { q.nodes.push_back(AirProgram::Node{op, a, b, v}); return (uint32_t)q.nodes.size() - 1; };
+    const uint32_t x = nd(AirProgram::LOCAL, 0, 0, 0), y = nd(AirProgram::LOCAL, 1, 0, 0), nx = nd(AirProgram::NEXT, 0, 0, 0);
+    const uint32_t x2 = nd(AirProgram::MUL, x, x, 0), x4 = nd(AirProgram::MUL, x2, x2, 0);
+    const uint32_t c3 = nd(AirProgram::CONST, 0, 0, 3), c5 = nd(AirProgram::CONST, 0, 0, 5), c7 = nd(AirProgram::CONST, 0, 0, 7), c2 = nd(AirProgram::CONST, 0, 0, 2);
+    const uint32_t rhs = nd(AirProgram::ADD, nd(AirProgram::ADD, x4, nd(AirProgram::MUL, c3, x, 0), 0), c5, 0);
+    q.constraints.push_back({nd(AirProgram::SUB, rhs, y, 0), AirProgram::ALWAYS});
+    q.constraints.push_back({nd(AirProgram::SUB, x, c2, 0), AirProgram::FIRST_ROW});
+    q.constraints.push_back({nd(AirProgram::SUB, nx, nd(AirProgram::ADD, y, nd(AirProgram::MUL, c7, x, 0), 0), 0), AirProgram::TRANSITION});
+    q.validate();
+    CHECK(q.max_constraint_degree() == 4 && q.log_quotient_degree() == 2);
+    const size_t n = 16;
+    std::vector<std::vector<u64>> col(2, std::vector<u64>(n));
+    u64 xv = 2;
+    for (size_t i = 0; i < n; i++) {
+      const u64 x2v = gl::mul(xv, xv), yv = gl::add(gl::add(gl::mul(x2v, x2v), gl::mul(3, xv)), 5);
+      col[0][i] = xv;
+      col[1][i] = yv;
+      xv = gl::add(yv, gl::mul(7, xv));
+    }
+    P3ProveParams p2;
+    p2.log_n = 4; p2.log_blowup = 2; p2.num_queries = 4; p2.pow_bits = 4; p2.threads = 2;
+    P3Config c2cfg;
+    std::vector<u64> in2 = p3_prove_air(q, col, p2, c2cfg);
+    CHECK(c2cfg.fri_config.log_blowup == 2 && c2cfg.log_quotient_degree == 2 && c2cfg.opening_matrix_log_max_height == 6);
+    CHECK(in2.size() == c2cfg.num_inputs());
+    std::string j2 = p3_inputs_to_json(in2, c2cfg);
+    CHECK(j2.size() > in2.size());
+    CircuitBuilder cbq;
+    ProgramAir paq(q);
+    p3_verify_proof(cbq, c2cfg, paq);
+    std::vector<uint8_t> bq = circuit_to_blob(cbq.build());
+    void* hq = p25o_circuit_load(bq.data(), bq.size());
+    CHECK(hq != nullptr);
+    char m2[256] = {0};
+    std::vector<u64> wq((size_t)circuit_from_blob(bq.data(), bq.size()).degree() * 135);
+    CHECK(p25o_witness(hq, in2.data(), 1, wq.data(), m2, sizeof m2) == 0);
+    CHECK(p25o_check_constraints(hq, wq.data(), m2, sizeof m2) == 0);
+    in2[8 + 4 * 2 + 5] ^= 1;      // one of the four chunks' openings
+    CHECK(p25o_witness(hq, in2.data(), 1, wq.data(), m2, sizeof m2) != 0);
+    bool threw = false;
+    p2.log_blowup = 1;              // four chunks do not fit the LDE domain of log_blowup 1
+    try { p3_prove_air(q, col, p2, c2cfg); } catch (const std::exception&) { threw = true; }
+    CHECK(threw);
+    p25o_circuit_free(hq);
+  }
   // oracle on a small verifier circuit
   prm.log_n = 3; prm.num_queries = 3; prm.pow_bits = 4;
   inp = p3_prove_fibonacci(prm, cfg);
