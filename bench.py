@@ -745,7 +745,7 @@ def main():
                        "circuit_build_s": round(build_s, 2), "head": head, "runtime": p25.runtime_info().as_dict(),
                        "single_proof_latency_ms": round(tmd["total_ms"], 3),
                        "phase_ms_single_proof": {k: round(v, 3) for k, v in tmd.items()}},
-            "roofline": {"bound": "valu",
+            "roofline": {"bound": "valu", "contract_view": "hbm",   # achieved / peak / unit / frac / traffic below: the contract's HBM roof
                          "view": "achieved / peak / frac are the HBM view the contract prescribes (algorithmic bytes of the dominant "
                                  "kernel per launch / its launch duration against 8 TB/s); the roof that BINDS is integer-VALU issue: "
                                  "`valu` below (wave-instructions per second against 1 per SIMD per 4 cycles)",
