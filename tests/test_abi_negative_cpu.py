@@ -93,3 +93,42 @@ def test_blob_beyond_kernel_capacities_is_rejected(p25):
     with pytest.raises(p25.P25Error) as e:
         p25.Circuit.from_blob(bytes(blob))
     assert e.value.status == 1
+
+
+def test_runtime_info_and_comm_entry_points_without_a_gpu(p25):
+    """Round 6's entry points on a box without a GPU: p25_runtime_info answers (it touches no device), p25_device_init_ex
+    validates its arguments before anything else, and the communicator calls report P25_ERR_NO_DEVICE -- never a crash, never a
+    CPU stand-in for the collective."""
+    lib = p25.lib()
+    ri = p25.runtime_info().as_dict()
+    assert ri["proving_streams"] == 16 and ri["main_streams"] == 2 and ri["hw_queues_setting_late"] == 0
+    assert lib.p25_runtime_info(None) == 1
+    assert lib.p25_device_init_ex(0, -1) == 1 and lib.p25_device_init_ex(0, 1000) == 1       # before any HIP call
+    st = lib.p25_device_init_ex(0, 0)
+    assert st in (0, 2)                                  # 2 = no device here; hw_queues 0 leaves the environment alone
+    buf = (C.c_uint8 * 128)()
+    assert lib.p25_comm_unique_id(buf) in (2, 10)        # NO_DEVICE (or RCCL absent)
+    h = C.c_void_p()
+    assert lib.p25_comm_init(buf, 0, 1, C.byref(h)) in (2, 10) and not h.value
+    assert lib.p25_comm_rank(None) == -1 and lib.p25_comm_world(None) == 0 and not lib.p25_comm_stream(None)
+    assert lib.p25_comm_destroy(None) == 0
+    cnt = (C.c_size_t * 1)(0)
+    assert lib.p25_gather_proofs(None, None, -1, None, 1, None, cnt, 0, None, None) in (1, 2, 10)
+    with pytest.raises(p25.P25Error):
+        p25.comm_unique_id()
+
+
+def test_p3_prove_air_ex_argument_checks(p25):
+    """log_blowup out of range, a degree the blow-up cannot hold, a shape whose Merkle-path length disagrees with its FriConfig."""
+    import air_cases
+    air, par = air_cases.quartic_map(p25, 5)
+    trace = air_cases.quartic_map_trace(par, 3)
+    for lb in (0, 1, 4):
+        with pytest.raises(p25.P25Error) as e:
+            p25.p3_prove_air(air, trace, num_queries=3, pow_bits=3, log_blowup=lb)
+        assert e.value.status == 1
+    inp, cfg = p25.p3_prove_air(air, trace, num_queries=3, pow_bits=3, log_blowup=2)
+    bad = p25.P3Config(2, 3, 3, 2, 3, 2, 4, 2, 3)       # opening_matrix_log_max_height 4 != log_trace_height 3 + log_blowup 2
+    with pytest.raises(p25.P25Error):
+        p25.Circuit.build_p3_verifier_air(bad, air)
+    assert int(p25.Circuit.build_p3_verifier_air(cfg, air).info.num_inputs) == inp.size
