@@ -278,8 +278,14 @@ def main():
         # above that, instead of inheriting the backend's default watchdog.
         import datetime
         pg_timeout = datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S)
-        if args.dist_backend == "nccl":
+        if args.dist_backend == "nccl" and not args.dist_native:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
+        elif args.dist_native:
+            # the library's own communicator carries the data path; torch.distributed is only the launcher's out-of-band channel
+            # here (unique id, barriers, timing reductions, the input broadcast) and runs on gloo / host tensors -- a SECOND RCCL
+            # communicator in the process would add its streams to the 24 hardware queues the proving streams live on
+            # (profiles/r06_z_dist_native_vs_torch.txt: 124.5 instead of 145.4 proofs/s with both alive)
+            dist.init_process_group(backend="gloo", timeout=pg_timeout)
         else:
             dist.init_process_group(backend="gloo", timeout=pg_timeout)
 
@@ -288,7 +294,7 @@ def main():
     from plonky25_amd import dist as pdist
     from plonky25_amd import aggregate as pagg
     dev = torch.device("cuda", local_rank)
-    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
+    cdev = dev if (args.dist_backend == "nccl" and not args.dist_native) else torch.device("cpu")   # where torch's collectives' tensors live
     host_threads = max(1, (os.cpu_count() or 1) // world)                 # host-side helpers: share the cores
     # Per-proof inputs: plonky3 proofs of the Fibonacci AIR.  Generated ONCE, on rank 0 (item 0 for log_n = 6 is the
     # reference's artifact through the library's own reader; further valid proofs of the same statement -- other

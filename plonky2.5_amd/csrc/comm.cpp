@@ -119,9 +119,8 @@ p25_status comm_guarded(F&& f) {
 
 using namespace p25;
 
-// The root's own block moves with a copy KERNEL, not hipMemcpyAsync: a device-to-device hipMemcpyAsync on a stream whose head is
-// a not-yet-satisfied event wait blocks the HOST until the wait resolves (measured: bench.py --dist-native 123.4 against 143.8
-// proofs/s -- the host could no longer enqueue the next steps ahead of the GPU); a kernel launch is enqueue-only.
+// The root's own block moves with a copy KERNEL rather than hipMemcpyAsync: a launch is enqueue-only by construction, whatever
+// path the runtime would pick for a device-to-device copy on a stream whose head is a not-yet-satisfied event wait.
 namespace {
 template <class T>
 __global__ __launch_bounds__(256) void k_copy_words(const T* __restrict__ src, T* __restrict__ dst, size_t n) {
