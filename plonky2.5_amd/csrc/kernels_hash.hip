@@ -67,7 +67,11 @@ __global__ __launch_bounds__(64, 6) void k_hash_leaves_wide(const u64* __restric
 }
 
 // parents[m] = two_to_one(children[2m], children[2m+1])
-__global__ __launch_bounds__(64, 6) void k_tree_level(const u64* __restrict__ children,
+// Compiled for 8 waves per SIMD: one permutation with a zero capacity needs 57 VGPRs, and the issue rate of this instruction mix
+// still rises from 6 to 8 resident waves (profiles/r06_instr_rates.txt: 4.35-4.42 -> 4.28-4.32 cycles per instruction); in the
+// pipeline 145.7 against 145.3 proofs/s in every round of three (profiles/r06_ab_hash_occupancy_7_8.txt).  The leaf sponges stay
+// at 6 (79 VGPRs: 7 waves = 71 VGPRs and 8 = 63 VGPRs + 28 B of scratch measure the same as 6 there).
+__global__ __launch_bounds__(64, 8) void k_tree_level(const u64* __restrict__ children,
                                                     u64* __restrict__ parents, size_t n_parents) {
   size_t m = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (m >= n_parents) return;
