@@ -177,7 +177,7 @@ p25_status p25_p3_prove_air(const p25_air* air, const uint64_t* trace, int32_t l
                             int32_t pow_bits, uint64_t pow_start, int32_t threads, uint64_t* inputs_out, size_t cap,
                             size_t* n_out, p25_p3_config* cfg_out);
 /* The same with FriConfig.log_blowup explicit (src/p3/mod.rs:242-246; the reference's verifier reads config.log_blowup
- * generically: verifier.rs:264, 299, 378, 397).  log_blowup 1 = p25_p3_prove_air = the reference's artifact.  log_blowup 2 / 3:
+ * generically: verifier.rs:264, 299, 378, 397).  log_blowup 1..4; 1 = p25_p3_prove_air = the reference's artifact.  log_blowup 2 / 3:
  * the LDE domain is 7*H_{4n} / 7*H_{8n}, which holds the quotient domain of AIRs of constraint degree up to 5 / 9 (selector
  * included): 2^log_quotient_degree = 4 / 8 quotient chunks, log_quotient_degree = log2_ceil(degree - 1) as in uni-stark.  The
  * flat input then carries every chunk's two openings in order, one matrix per chunk in every query's quotient batch, input

@@ -1000,7 +1000,7 @@ p25_status p25_p3_prove_air_ex(const p25_air* air, const uint64_t* trace, int32_
   return host_guarded([&]() -> p25_status {
     if (!air || !n_out) throw std::invalid_argument("null argument");
     p25::AirProgram prog = air_from_c(air);
-    if (log_blowup < 1 || log_blowup > 3) throw std::invalid_argument("log_blowup must be 1, 2 or 3");
+    if (log_blowup < 1 || log_blowup > 4) throw std::invalid_argument("log_blowup must be 1..4");
     if (prog.log_quotient_degree() > log_blowup)
       throw std::invalid_argument("an AIR of constraint degree " + std::to_string(prog.max_constraint_degree()) + " needs log_blowup >= " +
                                   std::to_string(prog.log_quotient_degree()));

@@ -184,7 +184,7 @@ void p3_proof_from_json(const char* json, size_t len, std::vector<u64>& inputs, 
   const size_t n_chunks = ov.at("quotient_chunks").arr.size();
   if (n_chunks != ((size_t)1 << cfg.log_quotient_degree) || n_chunks > 8)
     throw std::invalid_argument("p3 proof JSON: 1 quotient chunk (proof.rs:41-48), or 2 / 4 / 8 (AIRs of degree 3 / 4-5 / 6-9)");
-  if (cfg.fri_config.log_blowup < 1 || cfg.fri_config.log_blowup > 3 || cfg.log_quotient_degree > cfg.fri_config.log_blowup)
+  if (cfg.fri_config.log_blowup < 1 || cfg.fri_config.log_blowup > 4 || cfg.log_quotient_degree > cfg.fri_config.log_blowup)
     throw std::invalid_argument("p3 proof JSON: Merkle path lengths imply an unsupported log_blowup");
   if (inputs.size() != cfg.num_inputs()) throw std::invalid_argument("p3 proof JSON: shape is not rectangular");
 }

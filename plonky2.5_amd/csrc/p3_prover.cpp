@@ -189,8 +189,9 @@ std::vector<u64> p3_prove_fibonacci(const P3ProveParams& prm, P3Config& cfg) {
 std::vector<u64> p3_prove_air(const AirProgram& air, const std::vector<std::vector<u64>>& col, const P3ProveParams& prm,
                               P3Config& cfg) {
   // FriConfig.log_blowup (src/p3/mod.rs:242-246; verifier.rs uses config.log_blowup generically): the LDE domain is
-  // 7*H_{n 2^B}; B = 1 is the reference's artifact, B = 2, 3 hold AIRs of constraint degree up to 5 / 9 (four / eight chunks)
-  if (prm.log_n < 1 || prm.log_n > 22 || prm.log_blowup < 1 || prm.log_blowup > 3 || prm.log_n + prm.log_blowup > 24 ||
+  // 7*H_{n 2^B}, B = 1..4 (what p25_circuit_build_p3_verifier accepts); B = 1 is the reference's artifact, B = 2, 3 hold AIRs of
+  // constraint degree up to 5 / 9 (four / eight chunks)
+  if (prm.log_n < 1 || prm.log_n > 22 || prm.log_blowup < 1 || prm.log_blowup > 4 || prm.log_n + prm.log_blowup > 24 ||
       prm.num_queries < 1 || prm.pow_bits < 0 || prm.pow_bits > 30)
     throw std::invalid_argument("p3_prove: unsupported parameters");
   air.validate();

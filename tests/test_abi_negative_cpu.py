@@ -123,7 +123,7 @@ def test_p3_prove_air_ex_argument_checks(p25):
     import air_cases
     air, par = air_cases.quartic_map(p25, 5)
     trace = air_cases.quartic_map_trace(par, 3)
-    for lb in (0, 1, 4):
+    for lb in (0, 1, 5):
         with pytest.raises(p25.P25Error) as e:
             p25.p3_prove_air(air, trace, num_queries=3, pow_bits=3, log_blowup=lb)
         assert e.value.status == 1

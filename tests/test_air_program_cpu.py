@@ -130,7 +130,7 @@ def test_degree_three_air_two_quotient_chunks(p25, oracle, name, log_n):
         p25.p3_prove_air(air, wrong, num_queries=6, pow_bits=6)
 
 
-@pytest.mark.parametrize("family,seed,log_n,log_blowup", [("quartic_map", 21, 4, 2), ("quartic_map", 22, 3, 3),
+@pytest.mark.parametrize("family,seed,log_n,log_blowup", [("quartic_map", 21, 4, 2), ("quartic_map", 22, 3, 3), ("quartic_map", 24, 2, 4),
                                                           ("quintic_selector", 31, 5, 2), ("quintic_selector", 32, 2, 2)])
 def test_degree_four_and_five_airs_four_quotient_chunks_log_blowup_two(p25, oracle, family, seed, log_n, log_blowup):
     """FriConfig.log_blowup > 1 end to end (src/p3/mod.rs:242-246; verifier.rs:264, 299, 378, 397 read it generically): AIRs
