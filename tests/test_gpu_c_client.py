@@ -61,3 +61,30 @@ def test_c_client_gathers_over_a_library_owned_rccl_communicator(tmp_path):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "C GATHER OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_c_client_multi_rank_gather_through_a_test_double_of_librccl(tmp_path):
+    """tests/c_abi/gather_multi.c: the MULTI-RANK half of p25_gather_proofs on the one GPU there is -- every rank a thread, librccl
+    replaced by the test double tests/c_abi/fake_rccl.cpp (RCCL refuses two ranks on one device): who sends what to whom, receive
+    offsets of uneven and empty shards, roots other than rank 0, gathers in flight on one communicator, the max reduction and the
+    barrier over 2-5 ranks.  Every gathered word is checked; the double's counters prove it carried the traffic."""
+    gcc, gxx = shutil.which("gcc"), shutil.which("g++")
+    if not gcc or not gxx:
+        pytest.skip("gcc / g++ not available")
+    libdir = os.path.join(ROOT, "plonky2.5_amd")
+    fake_dir = tmp_path / "fake"
+    fake_dir.mkdir()
+    r = subprocess.run([gxx, "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-shared", "-fPIC",
+                        "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "fake_rccl.cpp"),
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-soname,librccl.so.1",
+                        "-o", str(fake_dir / "librccl.so.1")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exe = str(tmp_path / "c_gather_multi")
+    r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-D__HIP_PLATFORM_AMD__", "-D_GNU_SOURCE",
+                        "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "gather_multi.c"),
+                        "-L" + libdir, "-lp25", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-ldl", "-Wl,-rpath," + libdir,
+                        "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, LD_LIBRARY_PATH=str(fake_dir) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "C GATHER MULTI OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
