@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential run: GPU proofs against the oracle's, byte for byte, over circuits and inputs the fixed tests do
-not visit -- seeded AIR families (linear recurrences of random width, quadratic pairs, the degree-3 AIRs) at random trace
+not visit -- seeded AIR families (linear recurrences of random width, quadratic pairs, the degree-3 AIRs, the degree-4 / 5 families with FriConfig.log_blowup 2 / 3) at random trace
 heights / query counts / PoW bits, the gadget circuits on random operands, the reference-gates circuit (gadget 14).
 usage: fuzz_parity.py [seconds=240] [seed=1]      prints one line per case and a summary; exit code 1 on any difference."""
 import os, sys, time
