@@ -135,14 +135,104 @@ static void* rank_main(void* p) {
   return NULL;
 }
 
+/* ---- the same with REAL circuits: every rank proves its shard on its own circuit (device-resident, two pipelined steps), marks,
+ * and the gather waits for the mark on the device; the root checks every gathered proof against the host-buffer path. ---- */
+#define CSTEPS 2
+static void gadget_inputs(int rank, int k, size_t i, uint64_t in[3], uint64_t* seed) {
+  const uint64_t x = (0x9E3779B97F4A7C15ull * (uint64_t)(97 * rank + 13 * k + (int)i + 1)) >> 32;
+  const uint64_t y = (0xC2B2AE3D27D4EB4Full * (uint64_t)(31 * rank + 7 * k + 3 * (int)i + 5)) >> 32;
+  in[0] = x;
+  in[1] = y;
+  in[2] = x ^ y;
+  *seed = (uint64_t)(100000 * rank + 100 * k + (int)i);
+}
+static void* rank_main_circuit(void* p) {
+  rank_arg* a = (rank_arg*)p;
+  const scenario* sc = a->sc;
+  const int r = a->rank, W = sc->world;
+  p25_comm* comm = NULL;
+  p25_circuit* c = NULL;
+  CK(p25_comm_init(a->id, r, W, &comm));
+  CK(p25_circuit_build_gadget(1, 0, &c)); /* xor(x, y): inputs x, y, x ^ y */
+  p25_circuit_info_t info;
+  CK(p25_circuit_info(c, &info));
+  const size_t pw = (size_t)info.proof_words, n = sc->counts[r];
+  size_t total = 0;
+  for (int q = 0; q < W; q++) total += sc->counts[q];
+  uint64_t *d_in = NULL, *d_seeds = NULL, *d_p[2] = {0}, *d_all[CSTEPS] = {0};
+  uint32_t *d_st[CSTEPS] = {0}, *d_alls[CSTEPS] = {0};
+  uint64_t h_in[CSTEPS][8][3], h_seeds[CSTEPS][8];
+  if (n > 8) FAIL("shard too large for the test");
+  memset(h_in, 0, sizeof h_in);
+  memset(h_seeds, 0, sizeof h_seeds);
+  for (int k = 0; k < CSTEPS; k++)
+    for (size_t i = 0; i < n; i++) gadget_inputs(r, k, i, h_in[k][i], &h_seeds[k][i]);
+  HIPCK(hipMalloc((void**)&d_in, sizeof h_in));
+  HIPCK(hipMalloc((void**)&d_seeds, sizeof h_seeds));
+  HIPCK(hipMemcpy(d_in, h_in, sizeof h_in, hipMemcpyHostToDevice));
+  HIPCK(hipMemcpy(d_seeds, h_seeds, sizeof h_seeds, hipMemcpyHostToDevice));
+  for (int b = 0; b < 2; b++) HIPCK(hipMalloc((void**)&d_p[b], 8 * pw * 8));
+  for (int k = 0; k < CSTEPS; k++) {
+    HIPCK(hipMalloc((void**)&d_st[k], 8 * 4));
+    if (r == sc->dst) {
+      HIPCK(hipMalloc((void**)&d_all[k], total * pw * 8));
+      HIPCK(hipMalloc((void**)&d_alls[k], total * 4));
+      HIPCK(hipMemset(d_alls[k], 0xEE, total * 4));
+    }
+  }
+  HIPCK(hipDeviceSynchronize());
+  CK(p25_comm_barrier(comm));
+  for (int k = 0; k < CSTEPS; k++) {   /* nothing in this loop waits on the host */
+    const int buf = k & 1;
+    if (k >= 2) CK(p25_circuit_wait_stream(c, p25_comm_stream(comm)));
+    if (n) CK(p25_prove_batch_dev(c, d_in + (size_t)k * 8 * 3, n, d_seeds + (size_t)k * 8, d_p[buf], pw, d_st[k], NULL));
+    CK(p25_circuit_mark(c, (uint32_t)(P25_MAX_MARKS - 1 - buf)));
+    CK(p25_gather_proofs(comm, c, P25_MAX_MARKS - 1 - buf, d_p[buf], pw, d_st[k], sc->counts, sc->dst, d_all[k], d_alls[k]));
+  }
+  CK(p25_comm_sync(comm));
+  if (r == sc->dst) {
+    uint64_t* got = (uint64_t*)malloc(total * pw * 8);
+    uint32_t* got_st = (uint32_t*)malloc(total * 4);
+    uint64_t* want = (uint64_t*)malloc(pw * 8);
+    for (int k = 0; k < CSTEPS; k++) {
+      HIPCK(hipMemcpy(got, d_all[k], total * pw * 8, hipMemcpyDeviceToHost));
+      HIPCK(hipMemcpy(got_st, d_alls[k], total * 4, hipMemcpyDeviceToHost));
+      size_t g = 0;
+      for (int q = 0; q < W; q++)
+        for (size_t i = 0; i < sc->counts[q]; i++, g++) {
+          uint64_t in[3], seed;
+          p25_status st1;
+          gadget_inputs(q, k, i, in, &seed);
+          CK(p25_prove_batch(c, in, 1, &seed, want, pw, &st1, NULL));
+          if (st1 != P25_OK || got_st[g] != 0) FAIL("step %d rank %d proof %zu: statuses %d / %u", k, q, i, (int)st1, got_st[g]);
+          if (memcmp(got + g * pw, want, pw * 8) != 0) FAIL("step %d: gathered proof %zu (rank %d, proof %zu) differs from the host path", k, g, q, i);
+        }
+    }
+    free(got);
+    free(got_st);
+    free(want);
+  }
+  CK(p25_comm_barrier(comm));
+  CK(p25_circuit_sync(c));
+  CK(p25_comm_destroy(comm));
+  p25_circuit_destroy(c);
+  return NULL;
+}
+static const scenario CSCEN[] = {
+    {3, 0, CSTEPS, {2, 3, 1}},
+    {4, 3, CSTEPS, {1, 0, 2, 2}},
+};
+#define NCSCEN ((int)(sizeof CSCEN / sizeof CSCEN[0]))
+
 int main(void) {
   if (p25_device_init(0) != P25_OK) {
     fprintf(stderr, "p25_device_init: %s\n", p25_last_error());
     return 1;
   }
   unsigned long long sends = 0, recvs = 0;
-  for (int s = 0; s < NSCEN; s++) {
-    const scenario* sc = &SCEN[s];
+  for (int s = 0; s < NSCEN + NCSCEN; s++) {
+    const scenario* sc = s < NSCEN ? &SCEN[s] : &CSCEN[s - NSCEN];
+    void* (*body)(void*) = s < NSCEN ? rank_main : rank_main_circuit;
     uint8_t id[P25_COMM_ID_BYTES];
     if (p25_comm_unique_id(id) != P25_OK) {
       fprintf(stderr, "p25_comm_unique_id: %s\n", p25_last_error());
@@ -156,7 +246,7 @@ int main(void) {
     rank_arg args[MAXR];
     for (int r = 0; r < sc->world; r++) {
       args[r] = (rank_arg){r, sc, id, 0, {0}};
-      if (pthread_create(&th[r], NULL, rank_main, &args[r]) != 0) return 1;
+      if (pthread_create(&th[r], NULL, body, &args[r]) != 0) return 1;
     }
     int bad = 0;
     for (int r = 0; r < sc->world; r++) {
@@ -186,7 +276,7 @@ int main(void) {
     fprintf(stderr, "double's counters: %llu sends (%llu expected), %llu receives (%llu expected), %llu all-reduces\n", st[1], sends, st[2], recvs, st[4]);
     return 1;
   }
-  printf("C GATHER MULTI OK: %d scenarios, %llu sends / %llu receives / %llu bytes through the test double, %llu all-reduces\n", NSCEN, st[1], st[2],
-         st[3], st[4]);
+  printf("C GATHER MULTI OK: %d scenarios (%d of them with real circuits, marks and two pipelined steps), %llu sends / %llu receives / %llu bytes through the test double, %llu all-reduces\n", NSCEN + NCSCEN,
+         NCSCEN, st[1], st[2], st[3], st[4]);
   return 0;
 }
