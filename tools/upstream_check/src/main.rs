@@ -26,12 +26,42 @@ use plonky2::util::timing::TimingTree;
 use plonky2_field::types::PrimeField64;
 use serde_json::json;
 
-// names as in the reference's test module (src/p3/mod.rs:160-250)
-use plonky2_5::p3::air::FibonacciAir;                      // the test AIR; make it `pub` in a local checkout if needed
+// names as in the reference (src/p3/mod.rs:29-94, 151-269).  `FibonacciAir` lives in the reference's `#[cfg(test)] mod tests`
+// (src/p3/mod.rs:151-221): README.md "visibility patch" makes that module `pub mod tests` in the checkout this harness builds against.
 use plonky2_5::p3::serde::fri::FriConfig;
 use plonky2_5::p3::serde::proof::{P3ProofField, Proof};
-use plonky2_5::p3::CircuitBuilderP3Verifier;               // trait providing `p3_verify_proof`
+use plonky2_5::p3::tests::FibonacciAir;
+use plonky2_5::p3::CircuitBuilderP3Arithmetic;             // the trait providing `p3_verify_proof` (src/p3/mod.rs:29-48)
+use plonky2::field::goldilocks_field::GoldilocksField;
 use plonky2::hash::poseidon::PoseidonHash;
+
+/// The per-proof input targets in the order `Proof::<Target>::add_virtual_to` creates them (src/p3/serde/proof.rs:357-373 and the
+/// nested `add_virtual_to`s :29-343) = the order libp25 takes a proof's words in (`p25_p3_proof_from_json`, tests/p3json.py).
+fn flat_targets(p: &Proof<Target>) -> Vec<Target> {
+    let mut t = Vec::new();
+    t.extend(p.commitments.trace.value);
+    t.extend(p.commitments.quotient_chunks.value);
+    for e in &p.opened_values.trace_local { t.extend(e.value); }
+    for e in &p.opened_values.trace_next { t.extend(e.value); }
+    for chunk in &p.opened_values.quotient_chunks { for e in chunk { t.extend(e.value); } }
+    let fp = &p.opening_proof.fri_proof;
+    for c in &fp.commit_phase_commits { t.extend(c.value); }
+    for qp in &fp.query_proofs {
+        for step in &qp.commit_phase_openings {
+            t.extend(step.sibling_value.value);
+            for sib in &step.opening_proof { t.extend(sib.iter().copied()); }
+        }
+    }
+    t.extend(fp.final_poly.value);
+    t.push(fp.pow_witness);
+    for qo in &p.opening_proof.query_openings {
+        for batch in qo {
+            for row in &batch.opened_values { t.extend(row.iter().copied()); }
+            for sib in &batch.opening_proof { t.extend(sib.iter().copied()); }
+        }
+    }
+    t
+}
 
 const D: usize = 2;
 type C = PoseidonGoldilocksConfig;
@@ -42,9 +72,9 @@ fn main() -> Result<()> {
     let p3_proof: P3ProofField = serde_json::from_str(&std::fs::read_to_string(artifact)?)?;
 
     let mut builder = CircuitBuilder::<F, D>::new(CircuitConfig::standard_recursion_config());
-    let proof_t = Proof::add_virtual_to(&mut builder, &p3_proof);          // proof.rs:357-373
-    builder.p3_verify_proof::<PoseidonHash>(
-        proof_t.clone(),
+    // creates the proof's virtual targets itself (Proof::add_virtual_to, proof.rs:357-373) and returns them: src/p3/mod.rs:66-94
+    let proof_t: Proof<Target> = builder.p3_verify_proof::<PoseidonHash>(
+        p3_proof.clone(),
         &FibonacciAir {},
         FriConfig { log_blowup: 1, num_queries: 100, proof_of_work_bits: 16 },
     );
@@ -87,7 +117,9 @@ fn main() -> Result<()> {
 
     // ---- witness, filler, proof
     let mut pw = PartialWitness::new();
-    proof_t.set_witness(&mut pw, &p3_proof);                                  // proof.rs:374-383
+    // as the reference's test does (src/p3/mod.rs:254-257): Value<GoldilocksField> and GoldilocksField have the same layout
+    let p: Proof<GoldilocksField> = unsafe { std::mem::transmute(p3_proof) };
+    proof_t.set_witness::<F, D, _>(&mut pw, &p);                              // proof.rs:374-383
     let partition_witness = generate_partial_witness(pw, prover_only, common);
     if let Some(r) = pi_row {
         let filler: Vec<u64> = (4..common.config.num_wires)
@@ -113,7 +145,7 @@ fn main() -> Result<()> {
     }
     data.verify(proof.clone())?;                                              // src/p3/mod.rs:266
     // ---- the recursive verifier of that proof: upstream's own `builder.verify_proof`, so that libp25's
-    // `p25_circuit_build_recursive_verifier` -- restated from memory, NOT claimed row for row (DESIGN.md section 6) -- becomes
+    // `p25_circuit_build_recursive_verifier` -- restated from memory, NOT claimed row for row (DESIGN.md section 7) -- becomes
     // checkable: gate table, rows per gate and circuit digest of the circuit upstream builds for one inner proof with the
     // inner verifier data as constants (tests/test_upstream_golden.py::test_recursive_verifier_shape_vs_upstream).
     {
@@ -148,7 +180,7 @@ fn main() -> Result<()> {
         rdata.verify(rproof)?;
     }
     // the circuit as libp25 takes it (p25_circuit_import): prove it on the GPU, feed the proof back to data.verify
-    std::fs::write("upstream_circuit.p25blob", export_blob::export_p25_blob(&data, &proof_t.flat_targets()))?;   // flat_targets(): the add_virtual_to order, proof.rs:357-373
+    std::fs::write("upstream_circuit.p25blob", export_blob::export_p25_blob(&data, &flat_targets(&proof_t)))?;
     println!("wrote upstream_circuit.json, upstream_proof.json, upstream_filler.json (n = 2^{})", common.degree_bits());
     Ok(())
 }
